@@ -1,0 +1,124 @@
+/*
+ * gten_hip.h -- C-ABI of libgten_hip.so: the MI355X (gfx950) replacement for the
+ * arithmetic underneath tinyllama.cpp's gten API.
+ *
+ * What it replaces (upstream file:line):
+ *   - the ten gten::ops:: entry points gten/modules.cpp calls
+ *       token_embed   gten/ops.h:554   (modules.cpp:23)
+ *       matmul_2d     gten/ops.h:651   (modules.cpp:60,77)
+ *       rms_norm      gten/ops.h:806   (modules.cpp:97)
+ *       rotary_emb    gten/ops.h:757   (modules.cpp:171)
+ *       silu(_inplace)gten/ops.h:700,708 (modules.cpp:144,152)
+ *       mul(_inplace) gten/ops.h:853,861 (modules.cpp:116,125)
+ *       add           gten/ops.h:900   (modules.cpp:40)
+ *       qkv_attn      gten/ops.h:1118  (modules.cpp:219)
+ *   - Tensor storage allocation, gten/tensor.cpp:61 (malloc -> HBM)
+ *   - the quantization block formats of gten/quants.h:17-31 as the activation
+ *     layout in HBM, and a load-time repack of weight blocks (below).
+ *
+ * Conventions (same as the reference operators, gten/ops.h):
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - outputs are caller-allocated; nothing passed in is owned by the library;
+ *   - shapes are [n][d] row-major, pitches are BYTES per row, rows
+ *     [start_pos, n) are computed, rows < start_pos are left untouched;
+ *   - dtype codes follow `enum class Dtype` (gten/gten_types.h:20-26);
+ *   - calls are asynchronous on the library's stream (gten_hip_stream()); host
+ *     visibility needs gten_hip_memcpy_d2h (synchronous) or gten_hip_sync();
+ *   - one calling thread per process/device (the reference ops are not
+ *     re-entrant either, gten/ops.h:37);
+ *   - return 0 on success, a non-zero code otherwise with a message available
+ *     from gten_hip_last_error().  The C++ wrappers in
+ *     tinyllama.cpp_amd/gten/ops.h turn a non-zero return into the reference's
+ *     GTEN_ASSERT behaviour (gten/log.h:6-10: red message, exit(EXIT_FAILURE)).
+ *
+ * Activation layouts in HBM are byte-identical to the reference's host layouts:
+ *   f16: IEEE half;  Q8: 34-byte blocks {f16 delta, int8 q[32]} (quants.h:17-23).
+ * Weight layouts: f16 as in the file; Q8/Q4 are REPACKED once at load by
+ * gten_hip_pack_weight() from the .gten block stream (quants.h:17-31) into
+ *   Q4: [rows][nb][16 B nibbles]            then [rows][nb] f16 deltas
+ *   Q8: [rows][2][nb][16 B int8 half-block] then [rows][nb] f16 deltas
+ * (nb = cols/32), same total bytes, so that one wavefront instruction reads
+ * 1 KiB of contiguous quants.  All ops below take Q8/Q4 WEIGHTS in this packed
+ * form and f16 weights as is.
+ */
+#ifndef GTEN_HIP_H
+#define GTEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GTEN_I32 = 0, GTEN_F16 = 1, GTEN_F32 = 2, GTEN_Q8 = 3, GTEN_Q4 = 4 };
+
+/* ---- runtime ---------------------------------------------------------- */
+int         gten_hip_device_count(void);             /* does not initialise the GPU */
+int         gten_hip_init(int device);               /* idempotent per process */
+const char* gten_hip_last_error(void);
+void*       gten_hip_stream(void);                   /* hipStream_t all work is queued on */
+int         gten_hip_sync(void);
+
+/* replaces std::malloc / std::free of Tensor storage, gten/tensor.cpp:23-25,61 */
+int gten_hip_malloc(void** dptr, size_t nbytes);
+int gten_hip_free(void* dptr);
+int gten_hip_memset(void* dptr, int byte, size_t nbytes);
+/* loader staging, tinyllama.cpp:320 (host file bytes -> HBM) */
+int gten_hip_memcpy_h2d(void* dst, const void* src_host, size_t nbytes);
+/* sampler / debug reads, tinyllama.cpp:414,464 (synchronous) */
+int gten_hip_memcpy_d2h(void* dst_host, const void* src, size_t nbytes);
+int gten_hip_memcpy_d2d(void* dst, const void* src, size_t nbytes);
+
+/* bytes of one storage row (gten/tensor.h:97-117, gten/tensor.cpp:37-57) */
+size_t gten_hip_row_bytes(int dtype, int cols);
+
+/* ---- weights ---------------------------------------------------------- */
+/* src: rows*cols/32 blocks in .gten order (device copy of the file payload);
+ * dst: rows*gten_hip_row_bytes(dtype, cols) bytes, packed layout above.
+ * f16 needs no packing (call is a plain copy). */
+int gten_hip_pack_weight(const void* src_blocks, int dtype, int rows, int cols, void* dst_packed);
+
+/* ---- the ten operators ------------------------------------------------ */
+/* ops::token_embed, gten/ops.h:514-564.  tokens: int32[n] on the device. */
+int gten_hip_token_embed(const void* w, int w_dtype, int n_vocab,
+                         const int32_t* tokens,
+                         void* out, int out_dtype, size_t out_pitch,
+                         int n, int d, int start_pos);
+
+/* ops::matmul_2d, gten/ops.h:613-670.  out[r][c] = dot(x[r,:], w[c,:]).
+ * (x_dtype,w_dtype) in {(f16,f16),(Q8,Q8),(Q8,Q4)}; out_dtype in {f16,Q8,f32}.
+ * The lm_head form (EmbeddingLinear, gten/modules.cpp:70-81) is n rows in, the
+ * last row out: pass x = last row, n = 1, start_pos = 0, out = f32[d_out]. */
+int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch,
+                       const void* w, int w_dtype,
+                       void* out, int out_dtype, size_t out_pitch,
+                       int n, int d_in, int d_out, int start_pos);
+
+/* ops::rms_norm, gten/ops.h:762-814.  w: f16[d]. */
+int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f16,
+                      void* out, size_t out_pitch, int n, int d, int start_pos);
+
+/* ops::rotary_emb, gten/ops.h:714-760.  In place; position = row index. */
+int gten_hip_rotary_emb(void* x, int dtype, size_t pitch, int n, int d, int d_head, int start_pos);
+
+/* ops::silu / silu_inplace (out == x), gten/ops.h:673-711 */
+int gten_hip_silu(const void* x, void* out, int dtype, size_t pitch, int n, int d, int start_pos);
+/* ops::mul / mul_inplace (out == a), gten/ops.h:816-867 */
+int gten_hip_mul(const void* a, const void* b, void* out, int dtype, size_t pitch, int n, int d, int start_pos);
+/* ops::add, gten/ops.h:870-910 */
+int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitch, int n, int d, int start_pos);
+
+/* ops::qkv_attn, gten/ops.h:930-1133.  Causal GQA attention over the K/V
+ * caches (= rows [0,n) of k and v).  The reference's `qk` scratch tensor is
+ * never read by its callers (gten/modules.cpp:216-221) and is not needed:
+ * probabilities are rounded to the activation dtype in flight, exactly as the
+ * reference rounds them when it stores a row (gten/ops.h:996-997). */
+int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, int dtype,
+                      size_t q_pitch, size_t kv_pitch, size_t out_pitch,
+                      int n, int n_heads, int n_kv_heads, int d_head, int start_pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

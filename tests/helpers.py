@@ -57,3 +57,51 @@ def random_weights(oracle, cfg, seed):
 def MODES():
     """(name, wdtype, adtype) as chosen by tinyllama.cpp:258-265."""
     return [("f16", F16, F16), ("q8", Q8, Q8), ("q4", Q4, Q8)]
+
+
+# ---------------------------------------------------------------- comparators
+
+def q8_fields(b, d):
+    """uint8 [n][row_bytes(Q8,d)] -> (deltas f32 [n][nb], quants int8 [n][nb][32]); d % 32 == 0."""
+    n = b.shape[0]
+    blk = b.reshape(n, d // 32, 34)
+    deltas = blk[:, :, :2].copy().view(np.float16).astype(np.float32).reshape(n, d // 32)
+    q = blk[:, :, 2:].copy().view(np.int8)
+    return deltas, q
+
+
+def compare_rows(got, want, dtype, d, what="", min_exact=0.97, steps=1.0):
+    """Storage rows from the HIP path vs the oracle.
+
+    Integer/byte work is exact in both; what can differ is the f32 summation
+    order (and libm's last ulp), which moves a value by ~1e-7 relative and can
+    flip a rounding at a tie.  So: the dequantized values must agree within
+    `steps` quantization steps (Q8: delta of the block; f16: one ulp), and at
+    least `min_exact` of the stored bytes must be identical.
+    """
+    got = np.ascontiguousarray(got).view(np.uint8)
+    want = np.ascontiguousarray(want).view(np.uint8)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if dtype == Q8:
+        dg, qg = q8_fields(got, d)
+        dw, qw = q8_fields(want, d)
+        vg = qg.astype(np.float32) * dg[:, :, None]
+        vw = qw.astype(np.float32) * dw[:, :, None]
+        tol = steps * np.maximum(dg, dw)[:, :, None] * 1.001 + 1e-30
+        err = np.abs(vg - vw)
+        assert (err <= tol).all(), (what, float(err.max()), float(tol.min()))
+        rel_d = np.abs(dg - dw) <= np.maximum(np.abs(dw), 1e-30) * 2.0 ** -9
+        assert rel_d.all(), (what, "block deltas differ by more than one fp16 ulp")
+    elif dtype == F16:
+        vg = got.view(np.float16).astype(np.float32)
+        vw = want.view(np.float16).astype(np.float32)
+        ulp = np.maximum(np.abs(vw), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(vg - vw) <= steps * ulp * 1.001).all(), (what, float(np.abs(vg - vw).max()))
+    else:
+        vg = got.view(np.float32)
+        vw = want.view(np.float32)
+        np.testing.assert_allclose(vg, vw, rtol=2e-5, atol=2e-6, err_msg=what)
+        return 1.0
+    exact = float((got == want).mean())
+    assert exact >= min_exact, (what, f"only {exact:.4f} of the bytes are identical")
+    return exact

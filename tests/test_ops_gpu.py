@@ -1,0 +1,182 @@
+"""-m gpu: every operator of include/gten_hip.h against the oracle, through the C-ABI.
+
+Same seeded inputs on both sides, at sizes the oracle finishes in seconds.
+The comparison rule and its tolerance are in helpers.compare_rows.
+"""
+import numpy as np
+import pytest
+
+from gpu_common import hip  # noqa: F401
+from helpers import F16, F32, MODES, Q4, Q8, act_rows, compare_rows, rng, row_bytes, weight_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def up_weight(hip, blocks, dtype, rows, cols):
+    return hip.upload_weight(blocks, dtype, rows, cols)
+
+
+@pytest.mark.parametrize("wd", [Q8, Q4, F16])
+def test_pack_weight_roundtrip(hip, oracle, wd):
+    """the load-time repack holds exactly the bytes of the .gten block stream"""
+    r = rng(1)
+    rows, cols = 7, 256
+    blocks, _ = weight_rows(oracle, r, rows, cols, wd)
+    dev = up_weight(hip, blocks, wd, rows, cols)
+    packed = dev.download()
+    nb = cols // 32
+    if wd == F16:
+        assert np.array_equal(packed, blocks.reshape(-1))
+        return
+    qbytes = 16 if wd == Q4 else 32
+    src = blocks.reshape(rows, nb, 2 + qbytes)
+    ds = packed[rows * nb * qbytes:].view(np.uint16).reshape(rows, nb)
+    assert np.array_equal(ds, src[:, :, :2].copy().view(np.uint16).reshape(rows, nb))
+    if wd == Q4:
+        assert np.array_equal(packed[: rows * nb * 16].reshape(rows, nb, 16), src[:, :, 2:])
+    else:
+        planes = packed[: rows * nb * 32].reshape(rows, 2, nb, 16)
+        assert np.array_equal(planes[:, 0], src[:, :, 2:18])
+        assert np.array_equal(planes[:, 1], src[:, :, 18:34])
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+@pytest.mark.parametrize("n,d_in,d_out,sp", [(3, 256, 96, 0), (3, 256, 96, 2), (1, 2048, 2048, 0),
+                                            (2, 5632, 64, 1), (1, 2048, 5632, 0)])
+def test_matmul_2d(hip, oracle, name, wd, ad, n, d_in, d_out, sp):
+    r = rng(n * 1000 + d_in + d_out)
+    x, _ = act_rows(oracle, r, n, d_in, ad)
+    w, _ = weight_rows(oracle, r, d_out, d_in, wd)
+    xd, wdv = hip.upload(x), up_weight(hip, w, wd, d_out, d_in)
+    for od in (ad, F32):
+        want = np.full((n, row_bytes(od, d_out)), 0xAB, np.uint8)
+        oracle.matmul_2d(x, ad, w, wd, want, od, n, d_in, d_out, sp)
+        od_dev = hip.upload(np.full_like(want, 0xAB))
+        hip.matmul_2d(xd, ad, wdv, wd, od_dev, od, n, d_in, d_out, sp)
+        got = od_dev.download(shape=want.shape)
+        assert np.array_equal(got[:sp], want[:sp]), "rows below start_pos must be untouched"
+        compare_rows(got[sp:], want[sp:], od, d_out, f"matmul {name}->{od}")
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_lm_head_ragged_width(hip, oracle, name, wd, ad):
+    """d_out = 32003 is not a multiple of anything (EmbeddingLinear, gten/modules.cpp:70-81)"""
+    r = rng(9)
+    d_in, d_out = 256, 1003
+    x, _ = act_rows(oracle, r, 1, d_in, ad)
+    w, _ = weight_rows(oracle, r, d_out, d_in, wd)
+    want = np.zeros((1, d_out * 4), np.uint8)
+    oracle.matmul_2d(x, ad, w, wd, want, F32, 1, d_in, d_out, 0)
+    out = hip.alloc(d_out * 4 + 64)
+    out.zero(0x7F)
+    hip.matmul_2d(hip.upload(x), ad, up_weight(hip, w, wd, d_out, d_in), wd, out, F32, 1, d_in, d_out, 0)
+    got = out.download()
+    compare_rows(got[: d_out * 4].reshape(1, -1), want, F32, d_out, "lm_head")
+    assert (got[d_out * 4:] == 0x7F).all(), "wrote past the ragged end"
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_token_embed(hip, oracle, name, wd, ad):
+    r = rng(5)
+    V, d = 50, 256
+    w, _ = weight_rows(oracle, r, V, d, wd)
+    toks = np.array([3, 49, 0, 7, 7], np.int32)
+    want = np.zeros((5, row_bytes(ad, d)), np.uint8)
+    oracle.token_embed(w, wd, toks, want, ad, d, 1)
+    out = hip.upload(np.zeros_like(want))
+    hip.token_embed(up_weight(hip, w, wd, V, d), wd, V, hip.upload(toks), out, ad, 5, d, 1)
+    got = out.download(shape=want.shape)
+    assert np.array_equal(got, want), "token_embed is a copy / exact requantisation: must be bit-exact"
+
+
+@pytest.mark.parametrize("ad", [F16, Q8])
+@pytest.mark.parametrize("d", [256, 2048, 5632])
+def test_rowwise_ops(hip, oracle, ad, d):
+    r = rng(d)
+    n = 4
+    x, _ = act_rows(oracle, r, n, d, ad)
+    y, _ = act_rows(oracle, r, n, d, ad)
+    w = (1 + 0.05 * r.standard_normal(d)).astype(np.float16)
+    xd, yd, wdv = hip.upload(x), hip.upload(y), hip.upload(w)
+    for sp in (0, 3):
+        want = np.zeros_like(x)
+        out = hip.upload(np.zeros_like(x))
+        oracle.rms_norm(x, ad, w, want, n, d, sp)
+        hip.rms_norm(xd, ad, wdv, out, n, d, sp)
+        compare_rows(out.download(shape=x.shape), want, ad, d, "rms_norm")
+
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.rotary_emb(want, ad, n, d, 64, sp)
+        hip.rotary_emb(buf, ad, n, d, 64, sp)
+        compare_rows(buf.download(shape=x.shape), want, ad, d, "rope", min_exact=0.999)
+
+        want = np.zeros_like(x)
+        out.zero()
+        oracle.silu(x, want, ad, n, d, sp)
+        hip.silu(xd, out, ad, n, d, sp)
+        compare_rows(out.download(shape=x.shape), want, ad, d, "silu", min_exact=0.995)
+
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.silu(want, want, ad, n, d, sp)
+        hip.silu(buf, buf, ad, n, d, sp)
+        compare_rows(buf.download(shape=x.shape), want, ad, d, "silu_inplace", min_exact=0.995)
+
+        want = np.zeros_like(x)
+        out.zero()
+        oracle.mul(x, y, want, ad, n, d, sp)
+        hip.mul(xd, yd, out, ad, n, d, sp)
+        assert np.array_equal(out.download(shape=x.shape), want), "mul must be bit-exact"
+
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.mul(want, y, want, ad, n, d, sp)
+        hip.mul(buf, yd, buf, ad, n, d, sp)
+        assert np.array_equal(buf.download(shape=x.shape), want), "mul_inplace must be bit-exact"
+
+        want = np.zeros_like(x)
+        out.zero()
+        oracle.add(x, y, want, ad, n, d, sp)
+        hip.add(xd, yd, out, ad, n, d, sp)
+        assert np.array_equal(out.download(shape=x.shape), want), "add must be bit-exact"
+
+
+def test_rope_last_position(hip, oracle):
+    """position 2047: the angle table comes from host libm like the reference's"""
+    r = rng(13)
+    n, d = 2048, 128
+    x, _ = act_rows(oracle, r, n, d, F16)
+    want = x.copy()
+    oracle.rotary_emb(want, F16, n, d, 64, 2040)
+    buf = hip.upload(x)
+    hip.rotary_emb(buf, F16, n, d, 64, 2040)
+    compare_rows(buf.download(shape=x.shape), want, F16, d, "rope@2047", min_exact=0.999)
+
+
+@pytest.mark.parametrize("ad", [F16, Q8])
+@pytest.mark.parametrize("n,sp,H,G,dh", [(5, 0, 8, 2, 64), (33, 0, 8, 2, 64), (40, 39, 8, 2, 64), (70, 64, 8, 2, 32),
+                                         (300, 299, 32, 4, 64), (1, 0, 4, 4, 64)])
+def test_qkv_attn(hip, oracle, ad, n, sp, H, G, dh):
+    r = rng(n * 7 + sp)
+    q, _ = act_rows(oracle, r, n, H * dh, ad)
+    k, _ = act_rows(oracle, r, n, G * dh, ad)
+    v, _ = act_rows(oracle, r, n, G * dh, ad)
+    want = np.zeros((n, row_bytes(ad, H * dh)), np.uint8)
+    oracle.qkv_attn(q, k, v, want, ad, n, H, G, dh, sp)
+    out = hip.upload(np.zeros_like(want))
+    hip.qkv_attn(hip.upload(q), hip.upload(k), hip.upload(v), out, ad, n, H, G, dh, sp)
+    got = out.download(shape=want.shape)
+    assert not got[:sp].any()
+    # two chained roundings (probabilities, then the output row): allow 2 steps
+    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0)
+
+
+def test_errors_are_reported_not_swallowed(hip):
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    a = hip.alloc(1024)
+    with pytest.raises(pkg.GtenHipError):
+        hip.matmul_2d(a, F16, a, Q4, a, F16, 1, 256, 32)       # dtype pair the reference does not dispatch
+    with pytest.raises(pkg.GtenHipError):
+        hip.add(a, a, a, Q8, 2, 256, start_pos=2)             # no rows to compute

@@ -1,0 +1,337 @@
+// gten_dev.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Wave64 only (MI355X / CDNA4).  Numerics follow the reference's row codec:
+// every operator reads rows in their storage dtype to f32, computes in f32 and
+// writes the row back in the storage dtype (gten/ops.h:40-96).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gten_hip.h"
+
+#define GTEN_WAVE 64
+#define GTEN_QBLK 32      // gten/quants.h:12-15
+#define GTEN_Q8_BYTES 34  // gten/quants.h:17-23
+#define GTEN_Q4_BYTES 18  // gten/quants.h:25-31
+
+namespace gtd {
+
+// ---- fp16 <-> fp32 (gten/gten_types.h:79-119: IEEE, round to nearest even) ----
+__device__ __forceinline__ float h2f(uint16_t h)
+{
+    _Float16 x;
+    __builtin_memcpy(&x, &h, 2);
+    return (float)x;
+}
+__device__ __forceinline__ uint16_t f2h(float f)
+{
+    const _Float16 x = (_Float16)f;   // v_cvt_f16_f32, RNE, overflow -> inf
+    uint16_t h;
+    __builtin_memcpy(&h, &x, 2);
+    return h;
+}
+
+// ---- wavefront reductions (all 64 lanes end with the same value) ----
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// max over aligned groups of `width` lanes (width = 4, 8, 16 or 32)
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum through LDS scratch (>= 16 floats); every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* scratch)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; i++) t += scratch[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float t = scratch[0];
+    for (int i = 1; i < nw; i++) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+// ---- Q8 activation quantizer pieces (gten/quants.h:52-66) ----
+// delta = absmax/127 in f32; the STORED delta is fp16(delta) but the rounding
+// scale is 1/delta of the unrounded f32 value; roundf = half away from zero.
+struct Q8Scale {
+    float scale;      // 1/delta or 0
+    uint16_t d16;     // stored delta
+    float ddeq;       // fp16_to_fp32(stored delta): what every reader multiplies by
+};
+__device__ __forceinline__ Q8Scale q8_scale_from_absmax(float amax)
+{
+    Q8Scale s;
+    const float delta = amax / 127.0f;
+    s.d16 = f2h(delta);
+    s.ddeq = h2f(s.d16);
+    s.scale = (delta != 0.0f) ? 1.0f / delta : 0.0f;
+    return s;
+}
+__device__ __forceinline__ int q8_round(float x, float scale)
+{
+    return (int)(int8_t)roundf(x * scale);
+}
+
+// ---- storage rows -> f32 in LDS ----
+// Q8 rows are 34-byte blocks (2-byte aligned only): byte loads keep it simple
+// and coalesce (32 consecutive lanes read 32 consecutive bytes).
+__device__ __forceinline__ float load_elem(const uint8_t* row, int dtype, int i)
+{
+    if (dtype == GTEN_Q8) {
+        const uint8_t* blk = row + (size_t)(i >> 5) * GTEN_Q8_BYTES;
+        const uint16_t d = *(const uint16_t*)blk;
+        return (float)(int8_t)blk[2 + (i & 31)] * h2f(d);
+    } else if (dtype == GTEN_F16) {
+        return h2f(((const uint16_t*)row)[i]);
+    } else {
+        return ((const float*)row)[i];
+    }
+}
+
+__device__ __forceinline__ void load_row_f32(const uint8_t* row, int dtype, int d, float* dst)
+{
+    for (int i = threadIdx.x; i < d; i += blockDim.x) dst[i] = load_elem(row, dtype, i);
+}
+
+// ---- f32 in LDS -> storage row (gten/ops.h:73-96) ----
+// `len` may end in a partial Q8 block (attention probability rows,
+// gten/quants.h:103-109): only delta + len%32 quants are written for it.
+// blockDim.x must be a multiple of 32 so that a block never straddles a step.
+__device__ __forceinline__ void store_row(const float* src, int dtype, int len, uint8_t* out)
+{
+    if (dtype == GTEN_Q8) {
+        const int padded = (len + 31) & ~31;
+        for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+            const bool ok = i < len;
+            const float x = ok ? src[i] : 0.0f;
+            const float amax = group_max<32>(fabsf(x));
+            const Q8Scale s = q8_scale_from_absmax(amax);
+            uint8_t* blk = out + (size_t)(i >> 5) * GTEN_Q8_BYTES;
+            if (ok) blk[2 + (i & 31)] = (uint8_t)(int8_t)q8_round(x, s.scale);
+            if ((i & 31) == 0) *(uint16_t*)blk = s.d16;
+        }
+    } else if (dtype == GTEN_F16) {
+        for (int i = threadIdx.x; i < len; i += blockDim.x) ((uint16_t*)out)[i] = f2h(src[i]);
+    } else {
+        for (int i = threadIdx.x; i < len; i += blockDim.x) ((float*)out)[i] = src[i];
+    }
+}
+
+// Round an f32 row held in LDS through the storage dtype IN PLACE (write +
+// read back, without touching global memory).  Same partial-tail rule.
+__device__ __forceinline__ void round_row_inplace(float* v, int dtype, int len)
+{
+    if (dtype == GTEN_Q8) {
+        const int padded = (len + 31) & ~31;
+        for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+            const bool ok = i < len;
+            const float x = ok ? v[i] : 0.0f;
+            const float amax = group_max<32>(fabsf(x));
+            const Q8Scale s = q8_scale_from_absmax(amax);
+            if (ok) v[i] = (float)q8_round(x, s.scale) * s.ddeq;
+        }
+    } else if (dtype == GTEN_F16) {
+        for (int i = threadIdx.x; i < len; i += blockDim.x) v[i] = h2f(f2h(v[i]));
+    }
+}
+
+// ---- packed weight addressing (see include/gten_hip.h) ----
+struct PackedW {
+    const uint8_t* qs;     // quants
+    const uint16_t* ds;    // deltas, [rows][nb]
+    int nb;                // blocks per row
+};
+__device__ __forceinline__ PackedW packed_view(const void* w, int dtype, int rows, int cols)
+{
+    PackedW p;
+    p.nb = cols >> 5;
+    p.qs = (const uint8_t*)w;
+    const size_t qbytes = (size_t)rows * p.nb * (dtype == GTEN_Q4 ? 16 : 32);
+    p.ds = (const uint16_t*)((const uint8_t*)w + qbytes);
+    return p;
+}
+
+// signed 4x int8 dot with accumulate (v_dot4_i32_i8)
+__device__ __forceinline__ int dot4(int a, int b, int c)
+{
+    return __builtin_amdgcn_sdot4(a, b, c, false);
+}
+
+// One Q4 weight block (16 bytes of nibbles: byte i holds element i in the high
+// nibble and element i+16 in the low nibble, gten/quants.h:78-90) against one
+// Q8 activation block held as 8 dwords.  Returns sum a_i * (w_i - 7) exactly.
+__device__ __forceinline__ int dot_q8_q4_block(const int (&a)[8], int asum, const uint4 w)
+{
+    const unsigned m = 0x0f0f0f0fu;
+    int acc = 0;
+    acc = dot4(a[0], (int)((w.x >> 4) & m), acc);
+    acc = dot4(a[1], (int)((w.y >> 4) & m), acc);
+    acc = dot4(a[2], (int)((w.z >> 4) & m), acc);
+    acc = dot4(a[3], (int)((w.w >> 4) & m), acc);
+    acc = dot4(a[4], (int)(w.x & m), acc);
+    acc = dot4(a[5], (int)(w.y & m), acc);
+    acc = dot4(a[6], (int)(w.z & m), acc);
+    acc = dot4(a[7], (int)(w.w & m), acc);
+    return acc - 7 * asum;
+}
+__device__ __forceinline__ int dot_q8_q8_block(const int (&a)[8], const uint4 w0, const uint4 w1)
+{
+    int acc = 0;
+    acc = dot4(a[0], (int)w0.x, acc);
+    acc = dot4(a[1], (int)w0.y, acc);
+    acc = dot4(a[2], (int)w0.z, acc);
+    acc = dot4(a[3], (int)w0.w, acc);
+    acc = dot4(a[4], (int)w1.x, acc);
+    acc = dot4(a[5], (int)w1.y, acc);
+    acc = dot4(a[6], (int)w1.z, acc);
+    acc = dot4(a[7], (int)w1.w, acc);
+    return acc;
+}
+
+// Q8 activation vector staged in LDS in structure-of-arrays form so that a lane
+// can fetch "its" block with two 16-byte reads:
+//   q   : [nb][32] int8  (16-byte aligned)
+//   d   : [nb] f32       (fp16_to_fp32 of the stored delta)
+//   sum : [nb] int32     (sum of the 32 quants, for the Q4 "-7" offset)
+struct ActQ8 {
+    int8_t* q;
+    float* d;
+    int* sum;
+};
+__device__ __forceinline__ size_t actq8_bytes(int nb) { return (size_t)nb * 40; }
+__device__ __forceinline__ ActQ8 actq8_carve(uint8_t* lds, int nb)
+{
+    ActQ8 a;
+    a.q = (int8_t*)lds;
+    a.d = (float*)(lds + (size_t)nb * 32);
+    a.sum = (int*)(lds + (size_t)nb * 36);
+    return a;
+}
+
+// Stage one Q8 storage row (34-byte blocks in global memory) into ActQ8 form.
+__device__ __forceinline__ void stage_q8_row(const uint8_t* row, int nb, ActQ8 a)
+{
+    for (int i = threadIdx.x; i < nb * 32; i += blockDim.x) {
+        const uint8_t* blk = row + (size_t)(i >> 5) * GTEN_Q8_BYTES;
+        const int qv = (int)(int8_t)blk[2 + (i & 31)];
+        a.q[i] = (int8_t)qv;
+        int s = qv;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((i & 31) == 0) {
+            a.d[i >> 5] = h2f(*(const uint16_t*)blk);
+            a.sum[i >> 5] = s;
+        }
+    }
+}
+
+// Quantize an f32 row in LDS into ActQ8 form (gten/quants.h:52-66 per block).
+__device__ __forceinline__ void quantize_to_actq8(const float* v, int nb, ActQ8 a)
+{
+    for (int i = threadIdx.x; i < nb * 32; i += blockDim.x) {
+        const float x = v[i];
+        const float amax = group_max<32>(fabsf(x));
+        const Q8Scale s = q8_scale_from_absmax(amax);
+        const int qv = q8_round(x, s.scale);
+        a.q[i] = (int8_t)qv;
+        int t = qv;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((i & 31) == 0) {
+            a.d[i >> 5] = s.ddeq;
+            a.sum[i >> 5] = t;
+        }
+    }
+}
+
+// ---- one weight row against the staged activation; whole wave cooperates ----
+// Lanes stride over the K blocks (lane L takes blocks L, L+64, ...), so each
+// wave instruction reads 1 KiB of contiguous quants.  Result is wave-uniform.
+__device__ __forceinline__ float wave_dot_q4(const PackedW w, size_t row, const ActQ8 a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint4* qrow = (const uint4*)(w.qs + row * (size_t)w.nb * 16);
+    const uint16_t* drow = w.ds + row * (size_t)w.nb;
+    float acc = 0.f;
+    for (int b = lane; b < w.nb; b += 64) {
+        const uint4 wq = qrow[b];
+        const float dw = h2f(drow[b]);
+        const int4* ap = (const int4*)(a.q + (size_t)b * 32);
+        const int4 a0 = ap[0], a1 = ap[1];
+        const int av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const int isum = dot_q8_q4_block(av, a.sum[b], wq);
+        acc += (float)isum * (a.d[b] * dw);
+    }
+    return wave_sum(acc);
+}
+__device__ __forceinline__ float wave_dot_q8(const PackedW w, size_t row, const ActQ8 a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint4* q0 = (const uint4*)(w.qs + row * (size_t)w.nb * 32);
+    const uint4* q1 = q0 + w.nb;
+    const uint16_t* drow = w.ds + row * (size_t)w.nb;
+    float acc = 0.f;
+    for (int b = lane; b < w.nb; b += 64) {
+        const uint4 w0 = q0[b], w1 = q1[b];
+        const float dw = h2f(drow[b]);
+        const int4* ap = (const int4*)(a.q + (size_t)b * 32);
+        const int4 a0 = ap[0], a1 = ap[1];
+        const int av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const int isum = dot_q8_q8_block(av, w0, w1);
+        acc += (float)isum * (a.d[b] * dw);
+    }
+    return wave_sum(acc);
+}
+// f16 weights x f16 activations (activations staged as f32 in LDS, exact).
+// Lane L takes elements [8L, 8L+8) of every 512-element segment.
+__device__ __forceinline__ float wave_dot_f16(const uint16_t* wrow, const float* act, int d)
+{
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int e = lane * 8; e < d; e += 512) {
+        const uint4 wv = *(const uint4*)(wrow + e);
+        const unsigned u[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc += h2f((uint16_t)(u[j] & 0xffffu)) * act[e + 2 * j];
+            acc += h2f((uint16_t)(u[j] >> 16)) * act[e + 2 * j + 1];
+        }
+    }
+    return wave_sum(acc);
+}
+
+} // namespace gtd

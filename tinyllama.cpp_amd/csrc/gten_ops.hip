@@ -1,0 +1,476 @@
+// gten_ops.hip -- the ten gten::ops:: entry points as gfx950 kernels
+// (include/gten_hip.h).  These are the general forms: any number of new rows
+// [start_pos, n), every dtype pair the reference dispatches on
+// (gten/ops.h:482-512).  The single-row decode fast path lives in
+// gten_decode.hip and produces the same bytes.
+//
+// Every kernel follows the reference's row discipline: storage dtype -> f32,
+// compute in f32, write the row back in the storage dtype (gten/ops.h:40-96).
+#include "gten_dev.h"
+#include "gten_rt.h"
+
+using namespace gtd;
+
+extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
+
+// ------------------------------------------------------------------ pack
+
+// .gten block stream (gten/quants.h:17-31) -> packed planes (include/gten_hip.h)
+__global__ void k_pack_q4(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t nblk)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const uint8_t* s = src + b * GTEN_Q4_BYTES;
+    uint16_t* ds = (uint16_t*)(dst + nblk * 16);
+    ds[b] = *(const uint16_t*)s;
+    uint8_t* q = dst + b * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) q[i] = s[2 + i];
+}
+
+__global__ void k_pack_q8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int nb)
+{
+    const size_t nblk = (size_t)rows * nb;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const size_t row = b / nb, col = b % nb;
+    const uint8_t* s = src + b * GTEN_Q8_BYTES;
+    uint16_t* ds = (uint16_t*)(dst + nblk * 32);
+    ds[b] = *(const uint16_t*)s;
+    uint8_t* p0 = dst + row * (size_t)nb * 32 + col * 16;
+    uint8_t* p1 = p0 + (size_t)nb * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { p0[i] = s[2 + i]; p1[i] = s[18 + i]; }
+}
+
+// ----------------------------------------------------------------- embed
+
+// ops::token_embed, gten/ops.h:514-564
+template <int WT>
+__global__ __launch_bounds__(256) void k_embed(const void* __restrict__ w, int n_vocab, const int32_t* __restrict__ tokens,
+                                               uint8_t* __restrict__ out, int out_dtype, size_t out_pitch, int d, int start_pos)
+{
+    const int r = start_pos + blockIdx.x;
+    const int tok = tokens[r];
+    uint8_t* orow = out + (size_t)r * out_pitch;
+    const int nb = d >> 5;
+    if (WT == GTEN_F16) {
+        // verbatim copy (gten/ops.h:529-532)
+        const uint16_t* src = (const uint16_t*)w + (size_t)tok * d;
+        for (int i = threadIdx.x; i < d; i += blockDim.x) ((uint16_t*)orow)[i] = src[i];
+    } else if (WT == GTEN_Q8) {
+        // verbatim block copy (gten/ops.h:519-521), un-doing the load-time repack
+        const PackedW p = packed_view(w, GTEN_Q8, n_vocab, d);
+        const uint8_t* q0 = p.qs + (size_t)tok * nb * 32;
+        for (int i = threadIdx.x; i < d; i += blockDim.x) {
+            const int b = i >> 5, e = i & 31;
+            uint8_t* blk = orow + (size_t)b * GTEN_Q8_BYTES;
+            blk[2 + e] = q0[(size_t)(e >> 4) * nb * 16 + (size_t)b * 16 + (e & 15)];
+            if (e == 0) *(uint16_t*)blk = p.ds[(size_t)tok * nb + b];
+        }
+    } else {
+        // Q4 row -> f32 -> re-quantized in the activation dtype (gten/ops.h:522-528)
+        float* v = (float*)g_smem;
+        const PackedW p = packed_view(w, GTEN_Q4, n_vocab, d);
+        const uint8_t* q = p.qs + (size_t)tok * nb * 16;
+        for (int i = threadIdx.x; i < d; i += blockDim.x) {
+            const int b = i >> 5, e = i & 31;
+            const uint8_t byte = q[(size_t)b * 16 + (e & 15)];
+            const int nib = (e < 16) ? (byte >> 4) : (byte & 0x0f);
+            v[i] = (float)(nib - 7) * h2f(p.ds[(size_t)tok * nb + b]);
+        }
+        __syncthreads();
+        store_row(v, out_dtype, d, orow);
+    }
+}
+
+// ---------------------------------------------------------------- matmul
+
+// ops::matmul_2d, gten/ops.h:613-670.  One workgroup = one new row x 32
+// consecutive output features (= one Q8 output block); each of the 4 waves
+// walks 8 weight rows, all 64 lanes striding over the K blocks of a row.
+template <int WT>
+__global__ __launch_bounds__(256) void k_matmul(const uint8_t* __restrict__ x, size_t x_pitch, const void* __restrict__ w,
+                                                uint8_t* __restrict__ out, int out_dtype, size_t out_pitch,
+                                                int d_in, int d_out, int start_pos)
+{
+    float* res = (float*)g_smem;                 // 32 results
+    uint8_t* act_mem = g_smem + 128;
+    const int r = start_pos + blockIdx.y;
+    const int c0 = blockIdx.x * 32;
+    const uint8_t* xrow = x + (size_t)r * x_pitch;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nb = d_in >> 5;
+
+    ActQ8 a = actq8_carve(act_mem, nb);
+    float* actf = (float*)act_mem;
+    if (WT == GTEN_F16) load_row_f32(xrow, GTEN_F16, d_in, actf);
+    else stage_q8_row(xrow, nb, a);
+    __syncthreads();
+
+    const PackedW pw = packed_view(w, WT, d_out, d_in);
+#pragma unroll 2
+    for (int j = 0; j < 8; j++) {
+        const int c = c0 + wid * 8 + j;
+        float v = 0.f;
+        if (c < d_out) {
+            if (WT == GTEN_F16) v = wave_dot_f16((const uint16_t*)w + (size_t)c * d_in, actf, d_in);
+            else if (WT == GTEN_Q8) v = wave_dot_q8(pw, (size_t)c, a);
+            else v = wave_dot_q4(pw, (size_t)c, a);
+        }
+        if (lane == 0) res[wid * 8 + j] = v;
+    }
+    __syncthreads();
+
+    // write_row_from_float for this 32-wide slice (gten/ops.h:73-96)
+    if (threadIdx.x < 32) {
+        const int c = c0 + threadIdx.x;
+        const bool ok = c < d_out;
+        const float v = ok ? res[threadIdx.x] : 0.f;
+        uint8_t* orow = out + (size_t)r * out_pitch;
+        if (out_dtype == GTEN_Q8) {
+            const float amax = group_max<32>(fabsf(v));
+            const Q8Scale s = q8_scale_from_absmax(amax);
+            uint8_t* blk = orow + (size_t)blockIdx.x * GTEN_Q8_BYTES;
+            blk[2 + threadIdx.x] = (uint8_t)(int8_t)q8_round(v, s.scale);
+            if (threadIdx.x == 0) *(uint16_t*)blk = s.d16;
+        } else if (out_dtype == GTEN_F16) {
+            if (ok) ((uint16_t*)orow)[c] = f2h(v);
+        } else {
+            if (ok) ((float*)orow)[c] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------ row-wise ops
+
+// ops::rms_norm, gten/ops.h:762-814: out = x / (sqrt(mean x^2) + 1e-6) * w
+__global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x, int dtype, size_t x_pitch,
+                                                  const uint16_t* __restrict__ w, uint8_t* __restrict__ out,
+                                                  size_t out_pitch, int d, int start_pos)
+{
+    float* red = (float*)g_smem;
+    float* v = (float*)(g_smem + 64);
+    const int r = start_pos + blockIdx.x;
+    load_row_f32(x + (size_t)r * x_pitch, dtype, d, v);
+    __syncthreads();
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) ss += v[i] * v[i];
+    ss = block_sum(ss, red);
+    const float rms = sqrtf(ss / (float)d);
+    for (int i = threadIdx.x; i < d; i += blockDim.x) v[i] = v[i] / (rms + 1e-6f) * h2f(w[i]);
+    __syncthreads();
+    store_row(v, dtype, d, out + (size_t)r * out_pitch);
+}
+
+// ops::rotary_emb, gten/ops.h:714-760 (rotate-half pairing, position = row)
+__global__ __launch_bounds__(256) void k_rope(uint8_t* __restrict__ x, int dtype, size_t pitch, int d, int d_head,
+                                              int start_pos, const float2* __restrict__ table)
+{
+    float* v = (float*)g_smem;
+    const int r = start_pos + blockIdx.x;
+    uint8_t* row = x + (size_t)r * pitch;
+    load_row_f32(row, dtype, d, v);
+    __syncthreads();
+    const int half = d_head >> 1;
+    for (int i = threadIdx.x; i < (d >> 1); i += blockDim.x) {
+        const int h = i / half, j = i % half;
+        const float2 cs = table[(size_t)r * half + j];
+        const float x0 = v[h * d_head + j], x1 = v[h * d_head + j + half];
+        v[h * d_head + j] = x0 * cs.x - x1 * cs.y;
+        v[h * d_head + j + half] = x0 * cs.y + x1 * cs.x;
+    }
+    __syncthreads();
+    store_row(v, dtype, d, row);
+}
+
+enum { EW_SILU = 0, EW_MUL = 1, EW_ADD = 2 };
+
+// ops::silu / mul / add, gten/ops.h:673-711, 816-910
+template <int OP>
+__global__ __launch_bounds__(256) void k_elementwise(const uint8_t* a, const uint8_t* b,
+                                                     uint8_t* out, int dtype, size_t pitch, int d, int start_pos)
+{
+    float* v = (float*)g_smem;
+    const int r = start_pos + blockIdx.x;
+    const uint8_t* arow = a + (size_t)r * pitch;
+    const uint8_t* brow = (OP == EW_SILU) ? nullptr : b + (size_t)r * pitch;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        const float xa = load_elem(arow, dtype, i);
+        float o;
+        if (OP == EW_SILU) o = xa / (1.0f + expf(-xa));
+        else if (OP == EW_MUL) o = xa * load_elem(brow, dtype, i);
+        else o = xa + load_elem(brow, dtype, i);
+        v[i] = o;
+    }
+    __syncthreads();   // all reads of this row are done before an in-place write
+    store_row(v, dtype, d, out + (size_t)r * pitch);
+}
+
+// -------------------------------------------------------------- attention
+
+// ops::qkv_attn, gten/ops.h:930-1133.  One workgroup per (head, new row).
+// LDS: p[n] f32 | q staged | reduction scratch | p.V partials.
+__global__ __launch_bounds__(256) void k_attn(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
+                                              const uint8_t* __restrict__ v, uint8_t* __restrict__ out, int dtype,
+                                              size_t q_pitch, size_t kv_pitch, size_t out_pitch,
+                                              int n_heads, int n_kv, int d_head, int start_pos, int p_cap)
+{
+    const int h = blockIdx.x;
+    const int r = start_pos + blockIdx.y;
+    const int g = h / (n_heads / n_kv);
+    const int nk = r + 1;                      // columns c <= r are unmasked (gten/ops.h:957)
+    const int nblk = d_head >> 5;
+    const size_t head_bytes = (dtype == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)d_head * 2;
+
+    float* red = (float*)g_smem;                          // 16
+    float* qf = red + 16;                                 // d_head floats (f16 mode) / ints (Q8 mode)
+    int* qi = (int*)qf;
+    float* qd = qf + d_head;                              // nblk
+    float* outv = qd + 8;                                 // d_head
+    float* part = outv + d_head;                          // 256
+    float* p = part + 256;                                // p_cap
+
+    const uint8_t* qrow = q + (size_t)r * q_pitch + (size_t)h * head_bytes;
+    if (dtype == GTEN_Q8) {
+        if (threadIdx.x < d_head / 4) {
+            const int b = threadIdx.x >> 3, j = threadIdx.x & 7;
+            const uint16_t* qw = (const uint16_t*)(qrow + (size_t)b * GTEN_Q8_BYTES);
+            qi[threadIdx.x] = (int)((unsigned)qw[1 + 2 * j] | ((unsigned)qw[2 + 2 * j] << 16));
+            if (j == 0) qd[b] = h2f(qw[0]);
+        }
+    } else {
+        for (int e = threadIdx.x; e < d_head; e += blockDim.x) qf[e] = h2f(((const uint16_t*)qrow)[e]);
+    }
+    __syncthreads();
+
+    const float scale = 1.0f / sqrtf((float)d_head);
+    float lmax = -INFINITY;
+    for (int c = threadIdx.x; c < nk; c += blockDim.x) {
+        const uint8_t* kp = k + (size_t)c * kv_pitch + (size_t)g * head_bytes;
+        float s = 0.f;
+        if (dtype == GTEN_Q8) {
+            // integer block dots scaled by the two deltas (gten/ops.h:224-316)
+            for (int b = 0; b < nblk; b++) {
+                const uint16_t* kw = (const uint16_t*)(kp + (size_t)b * GTEN_Q8_BYTES);
+                int isum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int kv4 = (int)((unsigned)kw[1 + 2 * j] | ((unsigned)kw[2 + 2 * j] << 16));
+                    isum = dot4(qi[b * 8 + j], kv4, isum);
+                }
+                s += (float)isum * (qd[b] * h2f(kw[0]));
+            }
+        } else {
+            const uint16_t* k16 = (const uint16_t*)kp;
+            for (int e = 0; e < d_head; e++) s += qf[e] * h2f(k16[e]);
+        }
+        s *= scale;
+        p[c] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    const float mx = block_max(lmax, red);
+    float lsum = 0.f;
+    for (int c = threadIdx.x; c < nk; c += blockDim.x) {
+        const float e = expf(p[c] - mx);
+        p[c] = e;
+        lsum += e;
+    }
+    const float tot = block_sum(lsum, red);
+    for (int c = threadIdx.x; c < nk; c += blockDim.x) p[c] = p[c] / tot;
+    __syncthreads();
+    // the probability row is stored in the activation dtype (gten/ops.h:996-997)
+    round_row_inplace(p, dtype, nk);
+    __syncthreads();
+
+    // out[e] = sum_c p[c] * V[c][g][e]  (gten/ops.h:1046-1089)
+    const int ngrp = blockDim.x / d_head;
+    const int e = threadIdx.x % d_head, grp = threadIdx.x / d_head;
+    float acc = 0.f;
+    if (grp < ngrp) {
+        const uint8_t* vbase = v + (size_t)g * head_bytes;
+        for (int c = grp; c < nk; c += ngrp) acc += p[c] * load_elem(vbase + (size_t)c * kv_pitch, dtype, e);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < d_head) {
+        float o = 0.f;
+        for (int gi = 0; gi < ngrp; gi++) o += part[gi * d_head + threadIdx.x];
+        outv[threadIdx.x] = o;
+    }
+    __syncthreads();
+    store_row(outv, dtype, d_head, out + (size_t)r * out_pitch + (size_t)h * head_bytes);
+}
+
+// ------------------------------------------------------------------ C-ABI
+
+using namespace gtr;
+
+static bool act_dtype_ok(int dt) { return dt == GTEN_F16 || dt == GTEN_Q8; }
+
+extern "C" {
+
+int gten_hip_pack_weight(const void* src_blocks, int dtype, int rows, int cols, void* dst_packed)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(src_blocks && dst_packed && rows > 0 && cols > 0, "pack_weight: bad arguments");
+    if (dtype == GTEN_F16) {
+        GTR_CHECK(hipMemcpyAsync(dst_packed, src_blocks, (size_t)rows * cols * 2, hipMemcpyDeviceToDevice, stream()));
+        return 0;
+    }
+    GTR_REQUIRE(dtype == GTEN_Q8 || dtype == GTEN_Q4, "pack_weight: dtype %d is not a weight dtype", dtype);
+    GTR_REQUIRE(cols % 32 == 0, "pack_weight: cols %d not a multiple of the block size 32", cols);
+    const size_t nblk = (size_t)rows * (cols / 32);
+    const unsigned grid = (unsigned)((nblk + 255) / 256);
+    if (dtype == GTEN_Q4)
+        hipLaunchKernelGGL(k_pack_q4, dim3(grid), dim3(256), 0, stream(), (const uint8_t*)src_blocks, (uint8_t*)dst_packed, nblk);
+    else
+        hipLaunchKernelGGL(k_pack_q8, dim3(grid), dim3(256), 0, stream(), (const uint8_t*)src_blocks, (uint8_t*)dst_packed, rows, cols / 32);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_token_embed(const void* w, int w_dtype, int n_vocab, const int32_t* tokens,
+                         void* out, int out_dtype, size_t out_pitch, int n, int d, int start_pos)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(w && tokens && out, "token_embed: null pointer");
+    GTR_REQUIRE(n > 0 && start_pos >= 0 && start_pos < n, "token_embed: bad rows n=%d start_pos=%d", n, start_pos);
+    GTR_REQUIRE(d > 0 && d % 32 == 0 && d <= 8192, "token_embed: unsupported width %d", d);
+    GTR_REQUIRE(act_dtype_ok(out_dtype), "token_embed: bad output dtype %d", out_dtype);
+    GTR_REQUIRE(out_pitch >= gten_hip_row_bytes(out_dtype, d), "token_embed: output pitch too small");
+    const dim3 grid(n - start_pos), block(256);
+    if (w_dtype == GTEN_F16) {
+        GTR_REQUIRE(out_dtype == GTEN_F16, "token_embed: f16 table needs f16 output (row copy, gten/ops.h:529)");
+        hipLaunchKernelGGL(k_embed<GTEN_F16>, grid, block, 0, stream(), w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
+    } else if (w_dtype == GTEN_Q8) {
+        GTR_REQUIRE(out_dtype == GTEN_Q8, "token_embed: Q8 table needs Q8 output (block copy, gten/ops.h:519)");
+        hipLaunchKernelGGL(k_embed<GTEN_Q8>, grid, block, 0, stream(), w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
+    } else if (w_dtype == GTEN_Q4) {
+        GTR_REQUIRE(out_dtype == GTEN_Q8, "token_embed: Q4 table needs Q8 output (gten/ops.h:523)");
+        hipLaunchKernelGGL(k_embed<GTEN_Q4>, grid, block, (size_t)d * 4, stream(), w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
+    } else {
+        return fail(-4, "token_embed: bad table dtype %d", w_dtype);
+    }
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch, const void* w, int w_dtype,
+                       void* out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(x && w && out, "matmul_2d: null pointer");
+    GTR_REQUIRE(n > 0 && start_pos >= 0 && start_pos < n, "matmul_2d: bad rows n=%d start_pos=%d", n, start_pos);
+    GTR_REQUIRE(d_in > 0 && d_in % 32 == 0 && d_in <= 16384, "matmul_2d: unsupported d_in %d", d_in);
+    GTR_REQUIRE(d_out > 0, "matmul_2d: bad d_out %d", d_out);
+    const bool pair_ok = (x_dtype == GTEN_F16 && w_dtype == GTEN_F16) || (x_dtype == GTEN_Q8 && (w_dtype == GTEN_Q8 || w_dtype == GTEN_Q4));
+    GTR_REQUIRE(pair_ok, "matmul_2d: unsupported dtype pair (%d,%d) (gten/ops.h:482-512)", x_dtype, w_dtype);
+    GTR_REQUIRE(out_dtype == GTEN_F16 || out_dtype == GTEN_Q8 || out_dtype == GTEN_F32, "matmul_2d: bad output dtype %d", out_dtype);
+    GTR_REQUIRE(out_dtype != GTEN_Q8 || d_out % 32 == 0, "matmul_2d: Q8 output needs d_out %% 32 == 0 (got %d)", d_out);
+    GTR_REQUIRE(x_pitch >= gten_hip_row_bytes(x_dtype, d_in), "matmul_2d: input pitch too small");
+    GTR_REQUIRE(out_pitch >= gten_hip_row_bytes(out_dtype, d_out), "matmul_2d: output pitch too small");
+    GTR_REQUIRE(n - start_pos <= 65535, "matmul_2d: too many new rows");
+    const dim3 grid((d_out + 31) / 32, n - start_pos), block(256);
+    const size_t act = (w_dtype == GTEN_F16) ? (size_t)d_in * 4 : (size_t)(d_in / 32) * 40;
+    const size_t smem = 128 + act;
+    if (w_dtype == GTEN_F16)
+        hipLaunchKernelGGL(k_matmul<GTEN_F16>, grid, block, smem, stream(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
+    else if (w_dtype == GTEN_Q8)
+        hipLaunchKernelGGL(k_matmul<GTEN_Q8>, grid, block, smem, stream(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
+    else
+        hipLaunchKernelGGL(k_matmul<GTEN_Q4>, grid, block, smem, stream(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+static int check_rowwise(const char* op, const void* a, const void* out, int dtype, size_t pitch, int n, int d, int start_pos)
+{
+    GTR_REQUIRE(a && out, "%s: null pointer", op);
+    GTR_REQUIRE(act_dtype_ok(dtype), "%s: bad activation dtype %d", op, dtype);
+    GTR_REQUIRE(n > 0 && start_pos >= 0 && start_pos < n, "%s: bad rows n=%d start_pos=%d", op, n, start_pos);
+    GTR_REQUIRE(d > 0 && d % 32 == 0 && d <= 12288, "%s: unsupported width %d", op, d);
+    GTR_REQUIRE(pitch >= gten_hip_row_bytes(dtype, d), "%s: pitch too small", op);
+    return 0;
+}
+
+int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f16,
+                      void* out, size_t out_pitch, int n, int d, int start_pos)
+{
+    GTR_NEED_INIT();
+    if (int rc = check_rowwise("rms_norm", x, out, dtype, x_pitch, n, d, start_pos)) return rc;
+    GTR_REQUIRE(w_f16 && out_pitch >= gten_hip_row_bytes(dtype, d), "rms_norm: bad weight/output");
+    hipLaunchKernelGGL(k_rms_norm, dim3(n - start_pos), dim3(256), 64 + (size_t)d * 4, stream(),
+                       (const uint8_t*)x, dtype, x_pitch, (const uint16_t*)w_f16, (uint8_t*)out, out_pitch, d, start_pos);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_rotary_emb(void* x, int dtype, size_t pitch, int n, int d, int d_head, int start_pos)
+{
+    GTR_NEED_INIT();
+    if (int rc = check_rowwise("rotary_emb", x, x, dtype, pitch, n, d, start_pos)) return rc;
+    GTR_REQUIRE(d_head > 0 && d_head % 2 == 0 && d % d_head == 0, "rotary_emb: bad d_head %d for width %d", d_head, d);
+    GTR_REQUIRE(n <= GTEN_ROPE_MAX_POS, "rotary_emb: position %d beyond the table (%d)", n, GTEN_ROPE_MAX_POS);
+    const float2* table = nullptr;
+    if (int rc = rope_table(d_head, &table)) return rc;
+    hipLaunchKernelGGL(k_rope, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(), (uint8_t*)x, dtype, pitch, d, d_head, start_pos, table);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_silu(const void* x, void* out, int dtype, size_t pitch, int n, int d, int start_pos)
+{
+    GTR_NEED_INIT();
+    if (int rc = check_rowwise("silu", x, out, dtype, pitch, n, d, start_pos)) return rc;
+    hipLaunchKernelGGL(k_elementwise<EW_SILU>, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(),
+                       (const uint8_t*)x, (const uint8_t*)nullptr, (uint8_t*)out, dtype, pitch, d, start_pos);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_mul(const void* a, const void* b, void* out, int dtype, size_t pitch, int n, int d, int start_pos)
+{
+    GTR_NEED_INIT();
+    if (int rc = check_rowwise("mul", a, out, dtype, pitch, n, d, start_pos)) return rc;
+    GTR_REQUIRE(b, "mul: null pointer");
+    hipLaunchKernelGGL(k_elementwise<EW_MUL>, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(),
+                       (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitch, int n, int d, int start_pos)
+{
+    GTR_NEED_INIT();
+    if (int rc = check_rowwise("add", a, out, dtype, pitch, n, d, start_pos)) return rc;
+    GTR_REQUIRE(b, "add: null pointer");
+    hipLaunchKernelGGL(k_elementwise<EW_ADD>, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(),
+                       (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, int dtype,
+                      size_t q_pitch, size_t kv_pitch, size_t out_pitch,
+                      int n, int n_heads, int n_kv_heads, int d_head, int start_pos)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(q && k && v && out, "qkv_attn: null pointer");
+    GTR_REQUIRE(act_dtype_ok(dtype), "qkv_attn: bad activation dtype %d", dtype);
+    GTR_REQUIRE(n > 0 && start_pos >= 0 && start_pos < n, "qkv_attn: bad rows n=%d start_pos=%d", n, start_pos);
+    GTR_REQUIRE(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "qkv_attn: bad head counts %d/%d", n_heads, n_kv_heads);
+    GTR_REQUIRE(d_head % 32 == 0 && d_head >= 32 && d_head <= 256, "qkv_attn: unsupported d_head %d", d_head);
+    GTR_REQUIRE(q_pitch >= gten_hip_row_bytes(dtype, n_heads * d_head) && out_pitch >= gten_hip_row_bytes(dtype, n_heads * d_head) &&
+                kv_pitch >= gten_hip_row_bytes(dtype, n_kv_heads * d_head), "qkv_attn: pitch too small");
+    GTR_REQUIRE(n - start_pos <= 65535 && n <= 12288, "qkv_attn: context %d too long for this kernel", n);
+    const int p_cap = (n + 31) & ~31;
+    const size_t smem = (size_t)(16 + d_head + 8 + d_head + 256 + p_cap) * 4;
+    hipLaunchKernelGGL(k_attn, dim3(n_heads, n - start_pos), dim3(256), smem, stream(),
+                       (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v, (uint8_t*)out, dtype,
+                       q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, d_head, start_pos, p_cap);
+    GTR_LAUNCHED();
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,152 @@
+// gten_runtime.hip -- device selection, stream, HBM allocation and copies
+// behind the C-ABI of include/gten_hip.h (replaces the host malloc/free of
+// Tensor storage, gten/tensor.cpp:23-25,61, and stages the three points where
+// the reference's host code touches tensor bytes, tinyllama.cpp:320,406,414).
+#include "gten_rt.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace gtr {
+
+static char g_err[512] = "";
+static bool g_inited = false;
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static float2* g_rope = nullptr;      // [GTEN_ROPE_MAX_POS][d_head/2] (cos, sin)
+static int g_rope_dhead = 0;
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code ? code : -1;
+}
+
+hipStream_t stream() { return g_stream; }
+bool inited() { return g_inited; }
+
+// RoPE angles use the host libm exactly as the reference does
+// (gten/ops.h:743-746: m * powf(10000, -(2j/d)), then cosf/sinf in f32): device
+// fast-math trig is not accurate at angles up to 2047 rad.
+int rope_table(int d_head, const float2** out)
+{
+    if (g_rope && g_rope_dhead == d_head) { *out = g_rope; return 0; }
+    if (g_rope) { GTR_CHECK(hipStreamSynchronize(g_stream)); GTR_CHECK(hipFree(g_rope)); g_rope = nullptr; }
+    const int half = d_head / 2;
+    std::vector<float2> t((size_t)GTEN_ROPE_MAX_POS * half);
+    const float d = (float)d_head;
+    for (int m = 0; m < GTEN_ROPE_MAX_POS; m++)
+        for (int j = 0; j < half; j++) {
+            const float th = (float)m * std::pow(10000.0f, -(2.0f * j / d));
+            t[(size_t)m * half + j] = make_float2(std::cos(th), std::sin(th));
+        }
+    GTR_CHECK(hipMalloc((void**)&g_rope, t.size() * sizeof(float2)));
+    GTR_CHECK(hipMemcpy(g_rope, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+    g_rope_dhead = d_head;
+    *out = g_rope;
+    return 0;
+}
+
+} // namespace gtr
+
+using namespace gtr;
+
+extern "C" {
+
+int gten_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gten_hip_init(int device)
+{
+    if (g_inited) {
+        if (device != g_device) return fail(-2, "gten_hip_init: already bound to device %d", g_device);
+        return 0;
+    }
+    GTR_CHECK(hipSetDevice(device));
+    GTR_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    g_inited = true;
+    return 0;
+}
+
+const char* gten_hip_last_error(void) { return g_err; }
+void* gten_hip_stream(void) { return (void*)g_stream; }
+
+int gten_hip_sync(void)
+{
+    GTR_NEED_INIT();
+    GTR_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int gten_hip_malloc(void** dptr, size_t nbytes)
+{
+    GTR_NEED_INIT();
+    if (!dptr) return fail(-3, "gten_hip_malloc: null out pointer");
+    GTR_CHECK(hipMalloc(dptr, nbytes ? nbytes : 16));
+    return 0;
+}
+
+int gten_hip_free(void* dptr)
+{
+    GTR_NEED_INIT();
+    if (!dptr) return 0;
+    GTR_CHECK(hipStreamSynchronize(g_stream));
+    GTR_CHECK(hipFree(dptr));
+    return 0;
+}
+
+int gten_hip_memset(void* dptr, int byte, size_t nbytes)
+{
+    GTR_NEED_INIT();
+    GTR_CHECK(hipMemsetAsync(dptr, byte, nbytes, g_stream));
+    return 0;
+}
+
+int gten_hip_memcpy_h2d(void* dst, const void* src_host, size_t nbytes)
+{
+    GTR_NEED_INIT();
+    // pageable source: the runtime stages it before returning, so the caller
+    // may reuse src_host immediately (the loader reuses one read buffer).
+    GTR_CHECK(hipMemcpyAsync(dst, src_host, nbytes, hipMemcpyHostToDevice, g_stream));
+    GTR_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int gten_hip_memcpy_d2h(void* dst_host, const void* src, size_t nbytes)
+{
+    GTR_NEED_INIT();
+    GTR_CHECK(hipMemcpyAsync(dst_host, src, nbytes, hipMemcpyDeviceToHost, g_stream));
+    GTR_CHECK(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+int gten_hip_memcpy_d2d(void* dst, const void* src, size_t nbytes)
+{
+    GTR_NEED_INIT();
+    GTR_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, g_stream));
+    return 0;
+}
+
+size_t gten_hip_row_bytes(int dtype, int cols)
+{
+    switch (dtype) {
+    case GTEN_I32: case GTEN_F32: return (size_t)cols * 4;
+    case GTEN_F16: return (size_t)cols * 2;
+    case GTEN_Q8: return (size_t)((cols + 31) / 32) * 34;
+    case GTEN_Q4: return (size_t)(cols / 32) * 18;
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,196 @@
+"""ctypes binding of include/gten_hip.h (libgten_hip.so).
+
+This is plumbing for tests and bench.py: device buffers are plain HBM
+allocations owned by the library, moved with explicit h2d/d2h copies.  There
+is no CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+I32, F16, F32, Q8, Q4 = 0, 1, 2, 3, 4
+
+
+class GtenHipError(RuntimeError):
+    pass
+
+
+def _sig(lib, name, res, args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = args
+    return f
+
+
+class DeviceBuffer:
+    """A byte range in HBM.  `.ptr` is the raw device address (int)."""
+
+    def __init__(self, api, nbytes):
+        self.api = api
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        api._check(api._malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, api, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(api, arr.nbytes)
+        buf.upload(arr)
+        return buf
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        self.api._check(self.api._h2d(self.ptr + offset, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download(self, dtype=np.uint8, shape=None, offset=0, nbytes=None):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(nbytes, dtype=np.uint8)
+        self.api._check(self.api._d2h(out.ctypes.data_as(C.c_void_p), self.ptr + offset, nbytes))
+        out = out.view(dtype)
+        return out.reshape(shape) if shape is not None else out
+
+    def zero(self, byte=0):
+        self.api._check(self.api._memset(self.ptr, byte, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            self.api._check(self.api._free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GtenHip:
+    """Loaded libgten_hip.so with every symbol of include/gten_hip.h bound."""
+
+    SYMBOLS = [
+        "gten_hip_device_count", "gten_hip_init", "gten_hip_last_error", "gten_hip_stream", "gten_hip_sync",
+        "gten_hip_malloc", "gten_hip_free", "gten_hip_memset", "gten_hip_memcpy_h2d", "gten_hip_memcpy_d2h",
+        "gten_hip_memcpy_d2d", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
+        "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
+        "gten_hip_add", "gten_hip_qkv_attn",
+    ]
+
+    def __init__(self, path=None):
+        path = path or _build.HIP_LIB
+        if not os.path.exists(path):
+            raise GtenHipError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        self.path = path
+        self.lib = L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+        self._count = _sig(L, "gten_hip_device_count", ci, [])
+        self._init = _sig(L, "gten_hip_init", ci, [ci])
+        self._err = _sig(L, "gten_hip_last_error", C.c_char_p, [])
+        self._stream = _sig(L, "gten_hip_stream", vp, [])
+        self._sync = _sig(L, "gten_hip_sync", ci, [])
+        self._malloc = _sig(L, "gten_hip_malloc", ci, [C.POINTER(vp), sz])
+        self._free = _sig(L, "gten_hip_free", ci, [vp])
+        self._memset = _sig(L, "gten_hip_memset", ci, [vp, ci, sz])
+        self._h2d = _sig(L, "gten_hip_memcpy_h2d", ci, [vp, vp, sz])
+        self._d2h = _sig(L, "gten_hip_memcpy_d2h", ci, [vp, vp, sz])
+        self._d2d = _sig(L, "gten_hip_memcpy_d2d", ci, [vp, vp, sz])
+        self._row_bytes = _sig(L, "gten_hip_row_bytes", sz, [ci, ci])
+        self._pack = _sig(L, "gten_hip_pack_weight", ci, [vp, ci, ci, ci, vp])
+        self._embed = _sig(L, "gten_hip_token_embed", ci, [vp, ci, ci, vp, vp, ci, sz, ci, ci, ci])
+        self._matmul = _sig(L, "gten_hip_matmul_2d", ci, [vp, ci, sz, vp, ci, vp, ci, sz, ci, ci, ci, ci])
+        self._rms = _sig(L, "gten_hip_rms_norm", ci, [vp, ci, sz, vp, vp, sz, ci, ci, ci])
+        self._rope = _sig(L, "gten_hip_rotary_emb", ci, [vp, ci, sz, ci, ci, ci, ci])
+        self._silu = _sig(L, "gten_hip_silu", ci, [vp, vp, ci, sz, ci, ci, ci])
+        self._mul = _sig(L, "gten_hip_mul", ci, [vp, vp, vp, ci, sz, ci, ci, ci])
+        self._add = _sig(L, "gten_hip_add", ci, [vp, vp, vp, ci, sz, ci, ci, ci])
+        self._attn = _sig(L, "gten_hip_qkv_attn", ci, [vp, vp, vp, vp, ci, sz, sz, sz, ci, ci, ci, ci, ci])
+        self.initialised = False
+
+    # -- runtime
+    def _check(self, rc):
+        if rc != 0:
+            raise GtenHipError(f"gten_hip error {rc}: {self._err().decode(errors='replace')}")
+
+    def device_count(self):
+        return self._count()
+
+    def init(self, device=0):
+        if self.device_count() <= device:
+            raise GtenHipError(f"no MI355X visible (device_count={self.device_count()}, asked for {device}); "
+                               "there is no CPU fallback for the gten_hip path")
+        self._check(self._init(device))
+        self.initialised = True
+        return self
+
+    def sync(self):
+        self._check(self._sync())
+
+    def stream(self):
+        return self._stream()
+
+    def row_bytes(self, dtype, cols):
+        return self._row_bytes(dtype, cols)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr):
+        return DeviceBuffer.from_numpy(self, arr)
+
+    def upload_weight(self, blocks, dtype, rows, cols):
+        """uint8 [rows][row_bytes] in .gten block order -> packed device weight."""
+        src = self.upload(blocks)
+        dst = self.alloc(src.nbytes)
+        self._check(self._pack(src.ptr, dtype, rows, cols, dst.ptr))
+        self.sync()
+        src.free()
+        return dst
+
+    # -- operators (DeviceBuffers; pitches default to dense rows)
+    def token_embed(self, w, w_dtype, n_vocab, tokens, out, out_dtype, n, d, start_pos=0, out_pitch=None):
+        self._check(self._embed(w.ptr, w_dtype, n_vocab, tokens.ptr, out.ptr, out_dtype,
+                                out_pitch or self.row_bytes(out_dtype, d), n, d, start_pos))
+
+    def matmul_2d(self, x, x_dtype, w, w_dtype, out, out_dtype, n, d_in, d_out, start_pos=0,
+                  x_pitch=None, out_pitch=None):
+        self._check(self._matmul(x.ptr, x_dtype, x_pitch or self.row_bytes(x_dtype, d_in), w.ptr, w_dtype,
+                                 out.ptr, out_dtype, out_pitch or self.row_bytes(out_dtype, d_out),
+                                 n, d_in, d_out, start_pos))
+
+    def rms_norm(self, x, dtype, w, out, n, d, start_pos=0):
+        p = self.row_bytes(dtype, d)
+        self._check(self._rms(x.ptr, dtype, p, w.ptr, out.ptr, p, n, d, start_pos))
+
+    def rotary_emb(self, x, dtype, n, d, d_head, start_pos=0):
+        self._check(self._rope(x.ptr, dtype, self.row_bytes(dtype, d), n, d, d_head, start_pos))
+
+    def silu(self, x, out, dtype, n, d, start_pos=0):
+        self._check(self._silu(x.ptr, out.ptr, dtype, self.row_bytes(dtype, d), n, d, start_pos))
+
+    def mul(self, a, b, out, dtype, n, d, start_pos=0):
+        self._check(self._mul(a.ptr, b.ptr, out.ptr, dtype, self.row_bytes(dtype, d), n, d, start_pos))
+
+    def add(self, a, b, out, dtype, n, d, start_pos=0):
+        self._check(self._add(a.ptr, b.ptr, out.ptr, dtype, self.row_bytes(dtype, d), n, d, start_pos))
+
+    def qkv_attn(self, q, k, v, out, dtype, n, n_heads, n_kv_heads, d_head, start_pos=0):
+        qp = self.row_bytes(dtype, n_heads * d_head)
+        kp = self.row_bytes(dtype, n_kv_heads * d_head)
+        self._check(self._attn(q.ptr, k.ptr, v.ptr, out.ptr, dtype, qp, kp, qp, n, n_heads, n_kv_heads, d_head, start_pos))
+
+
+_api = None
+
+
+def load(device=None):
+    """Process-wide GtenHip; initialised on `device` when given (needs a GPU)."""
+    global _api
+    if _api is None:
+        _api = GtenHip()
+    if device is not None and not _api.initialised:
+        _api.init(device)
+    return _api
