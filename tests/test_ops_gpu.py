@@ -55,7 +55,7 @@ def test_matmul_2d(hip, oracle, name, wd, ad, n, d_in, d_out, sp):
         hip.matmul_2d(xd, ad, wdv, wd, od_dev, od, n, d_in, d_out, sp)
         got = od_dev.download(shape=want.shape)
         assert np.array_equal(got[:sp], want[:sp]), "rows below start_pos must be untouched"
-        compare_rows(got[sp:], want[sp:], od, d_out, f"matmul {name}->{od}")
+        compare_rows(got[sp:], want[sp:], od, d_out, f"matmul {name}->{od}", atol=8e-6)
 
 
 @pytest.mark.parametrize("name,wd,ad", MODES())
@@ -169,7 +169,7 @@ def test_qkv_attn(hip, oracle, ad, n, sp, H, G, dh):
     got = out.download(shape=want.shape)
     assert not got[:sp].any()
     # two chained roundings (probabilities, then the output row): allow 2 steps
-    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0)
+    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0, atol=8e-6)
 
 
 def test_errors_are_reported_not_swallowed(hip):
