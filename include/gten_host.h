@@ -1,0 +1,66 @@
+/*
+ * gten_host.h -- C-ABI of libgten_host.so: the model-level caller of the hot
+ * path, i.e. this repository's counterpart of the
+ * reference's TinyLlama class, .gten loader and greedy loop
+ * (tinyllama.cpp:23-76, 301-440), written in C++ on top of the HBM-backed gten
+ * API (tinyllama.cpp_amd/gten/) and exported flat so that tests and bench.py
+ * can drive it through ctypes.
+ *
+ * All pointers here are HOST pointers.  Functions return 0 on success; contract
+ * violations inside the gten layer follow the reference's convention instead
+ * (red "GTEN ERROR" line on stderr, exit(EXIT_FAILURE), gten/log.h:6-23).
+ */
+#ifndef GTEN_HOST_H
+#define GTEN_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gten_host_model gten_host_model;
+
+/* dims of TinyLLamaParams (tinyllama.cpp:12-20) made configurable so that small
+ * parity models can be built; dtypes use the codes of include/gten_hip.h and the
+ * pairs chosen by tinyllama.cpp:258-265: (f16,f16), (Q8,Q8), (Q4,Q8). */
+typedef struct {
+    int n_vocab, max_ctx, n_embd, n_ffn, n_layers, n_heads, n_kv_heads;
+    int wdtype, adtype;
+} gten_host_config;
+
+void gten_host_default_config(gten_host_config* cfg, int wdtype, int adtype); /* TinyLlama-1.1B */
+
+gten_host_model* gten_host_model_create(const gten_host_config* cfg);
+void gten_host_model_free(gten_host_model* m);
+
+/* weights in .gten order (tinyllama.cpp:345-391): embed; per layer q,k,v,o,gate,
+ * up,down,input_layernorm,post_attention_layernorm; model.norm; lm_head */
+int    gten_host_model_n_weights(const gten_host_model* m);
+size_t gten_host_model_weight_bytes(gten_host_model* m, int idx);
+int    gten_host_model_set_weight(gten_host_model* m, int idx, const void* bytes, size_t nbytes);
+int    gten_host_model_load_gten(gten_host_model* m, const char* path);           /* tinyllama.cpp:336-392 */
+int    gten_host_model_load_synthetic(gten_host_model* m, uint64_t seed);         /* host/synth.h */
+
+/* TinyLlama::logits(tokens, start_pos), tinyllama.cpp:45-61: all n token ids are
+ * passed, rows [start_pos, n) are computed, logits of the last row (f32[n_vocab])
+ * are copied to `logits_out` (may be NULL to skip the copy). */
+int gten_host_model_logits(gten_host_model* m, const int32_t* tokens, int n, int start_pos, float* logits_out);
+
+/* greedy loop of tinyllama.cpp:395-440 on token ids: prefill `n_prompt` ids, then
+ * append argmax ids (strict >, first maximum wins) until `max_tokens` total or
+ * `eos` is produced (pass eos < 0 to never stop).  Returns the total count. */
+int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos);
+
+/* synthetic weight tensor `idx` of a model with config `cfg`, in storage layout */
+int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes);
+/* the same weights as a .gten file (tinyllama_to_gten.py:94-201 layout) */
+int gten_host_write_gten(const gten_host_config* cfg, uint64_t seed, const char* path);
+/* [1] + LCG token ids, SURVEY 8(d) */
+void gten_host_synthetic_tokens(int32_t* out, int count, uint32_t seed, int n_vocab);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -27,6 +27,16 @@ def test_hip_library_exports_every_declared_symbol():
     assert sorted(api.SYMBOLS) == names, "python binding out of sync with the header"
 
 
+def test_host_library_exports_every_declared_symbol():
+    pkg = load_package()
+    pkg.build.build_all()
+    host = pkg.hostabi.GtenHost()
+    names = declared_symbols("gten_host.h")
+    for name in names:
+        assert hasattr(host.lib, name), f"{name} declared in include/gten_host.h but not exported"
+    assert sorted(host.SYMBOLS) == names
+
+
 def test_no_silent_cpu_fallback():
     """without a GPU the product path must fail loudly, not compute on the CPU"""
     pkg = load_package()

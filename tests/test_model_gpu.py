@@ -1,0 +1,86 @@
+"""-m gpu: the C++ model driver on the GPU (gten API mirror -> C-ABI -> HIP kernels)
+against the oracle on a small model: same weights, same token ids, full logits.
+
+Tolerances (stated per SURVEY 8(c), re-derived for this small model): the
+reference's own AVX and scalar builds disagree with each other by the same
+mechanism that separates the GPU from either of them (f32 summation order
+flipping activation roundings), so the bar is set relative to that:
+  f16: greedy ids identical, max |dlogit| <= 0.03
+  q8/q4: rms(dlogit) <= 0.10, max |dlogit| <= 0.5, top-1 equal wherever the
+         oracle's top-1/top-2 gap exceeds 0.5 (scaled by logit std / 0.91).
+"""
+import numpy as np
+import pytest
+
+from gpu_common import hip  # noqa: F401
+from __graft_entry__ import load_package
+from helpers import MODES, tiny_config
+
+pytestmark = pytest.mark.gpu
+
+
+def host_cfg(c):
+    pkg = load_package()
+    return pkg.HostConfig(**{k: getattr(c, k) for k, _ in c._fields_})
+
+
+def check_logits(name, got, want, ref_std):
+    d = got - want
+    rms = float(np.sqrt((d * d).mean()))
+    mx = float(np.abs(d).max())
+    s = ref_std / 0.91
+    if name == "f16":
+        assert mx <= 0.03 * max(s, 1.0), (name, mx)
+    else:
+        assert rms <= 0.10 * max(s, 1.0) and mx <= 0.5 * max(s, 1.0), (name, rms, mx)
+        top2 = np.sort(want)[-2:]
+        if top2[1] - top2[0] > 0.5 * s:
+            assert int(np.argmax(got)) == int(np.argmax(want))
+    return rms, mx
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_tiny_model_logits_prefill_and_decode(hip, oracle, name, wd, ad):
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(wd, ad, n_heads=4, n_kv_heads=2)       # d_head 64 like TinyLlama
+    cfg = host_cfg(ocfg)
+    gm = host.model(cfg)
+    om = oracle.model(ocfg)
+    for i in range(gm.n_weights()):
+        w = host.synth_weight(cfg, 4321, i)
+        gm.set_weight(i, w)
+        om.set_weight(i, w)
+    toks = list(host.synthetic_tokens(9, seed=7, n_vocab=cfg.n_vocab))
+    worst = (0.0, 0.0)
+    for step in range(8):
+        sp = 0 if step == 0 else len(toks) - 1
+        want = om.logits(toks, sp)
+        got = gm.logits(toks, sp)
+        assert np.isfinite(got).all()
+        rms, mx = check_logits(name, got, want, float(want.std()))
+        worst = (max(worst[0], rms), max(worst[1], mx))
+        if name == "f16":
+            assert int(np.argmax(got)) == int(np.argmax(want)), "fp16 greedy token must match"
+        toks.append(int(np.argmax(want)))                     # teacher-force the oracle's choice
+    print(f"{name}: worst rms {worst[0]:.4g} max {worst[1]:.4g} (logit std {want.std():.3f})")
+    gm.close(); om.close()
+
+
+def test_greedy_loop_matches_oracle_f16(hip, oracle):
+    from helpers import F16
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(F16, F16, n_heads=4, n_kv_heads=2)
+    cfg = host_cfg(ocfg)
+    gm, om = host.model(cfg), oracle.model(ocfg)
+    for i in range(gm.n_weights()):
+        w = host.synth_weight(cfg, 11, i)
+        gm.set_weight(i, w); om.set_weight(i, w)
+    prompt = list(host.synthetic_tokens(6, seed=3, n_vocab=cfg.n_vocab))
+    got = gm.greedy(prompt, 20)
+    toks = list(prompt)
+    for i in range(14):
+        lg = om.logits(toks, 0 if i == 0 else len(toks) - 1)
+        toks.append(int(np.argmax(lg)))
+    assert got.tolist() == toks

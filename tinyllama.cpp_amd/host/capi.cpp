@@ -1,0 +1,158 @@
+// capi.cpp -- flat C exports of the model-level host code (include/gten_host.h).
+#include "../../include/gten_host.h"
+
+#include <cstring>
+#include <memory>
+
+#include "tinyllama_model.h"
+
+using namespace gten;
+
+struct gten_host_model {
+    gten_host_config cfg;
+    std::unique_ptr<TinyLlama> model;
+};
+
+namespace {
+
+Dtype to_dtype(int code)
+{
+    switch (code) {
+    case GTEN_I32: return kInt32;
+    case GTEN_F16: return kFloat16;
+    case GTEN_F32: return kFloat32;
+    case GTEN_Q8: return kQint8;
+    case GTEN_Q4: return kQint4;
+    }
+    GTEN_ASSERTM(false, "bad dtype code %d", code);
+    return kFloat32;
+}
+
+TinyLLamaParams to_params(const gten_host_config& c)
+{
+    TinyLLamaParams p;
+    p.n_vocab = c.n_vocab; p.max_ctx = c.max_ctx; p.n_embd = c.n_embd; p.n_ffn = c.n_ffn;
+    p.n_layers = c.n_layers; p.n_heads = c.n_heads; p.n_query_groups = c.n_kv_heads;
+    return p;
+}
+
+} // namespace
+
+extern "C" {
+
+void gten_host_default_config(gten_host_config* cfg, int wdtype, int adtype)
+{
+    const TinyLLamaParams p;
+    cfg->n_vocab = p.n_vocab; cfg->max_ctx = p.max_ctx; cfg->n_embd = p.n_embd; cfg->n_ffn = p.n_ffn;
+    cfg->n_layers = p.n_layers; cfg->n_heads = p.n_heads; cfg->n_kv_heads = p.n_query_groups;
+    cfg->wdtype = wdtype; cfg->adtype = adtype;
+}
+
+gten_host_model* gten_host_model_create(const gten_host_config* cfg)
+{
+    if (!cfg) return nullptr;
+    auto* m = new gten_host_model;
+    m->cfg = *cfg;
+    m->model.reset(new TinyLlama(cfg->max_ctx, ModuleDtype{to_dtype(cfg->wdtype), to_dtype(cfg->adtype)}, to_params(*cfg)));
+    return m;
+}
+
+void gten_host_model_free(gten_host_model* m) { delete m; }
+
+int gten_host_model_n_weights(const gten_host_model* m) { return m->model->n_weights(); }
+
+size_t gten_host_model_weight_bytes(gten_host_model* m, int idx) { return m->model->weight(idx).nbytes(); }
+
+int gten_host_model_set_weight(gten_host_model* m, int idx, const void* bytes, size_t nbytes)
+{
+    if (idx < 0 || idx >= m->model->n_weights()) return -1;
+    Tensor& w = m->model->weight(idx);
+    if (nbytes != w.nbytes()) return -2;
+    std::memcpy(w.data_ptr<char>(), bytes, nbytes);
+    w.device_weight();
+    return 0;
+}
+
+int gten_host_model_load_gten(gten_host_model* m, const char* path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return -1;
+    m->model->load_from_ckpt(f);
+    return 0;
+}
+
+int gten_host_model_load_synthetic(gten_host_model* m, uint64_t seed)
+{
+    m->model->load_synthetic(seed);
+    return 0;
+}
+
+int gten_host_model_logits(gten_host_model* m, const int32_t* tokens, int n, int start_pos, float* logits_out)
+{
+    if (!tokens || n <= 0 || start_pos < 0 || start_pos >= n) return -1;
+    Tensor tk(tokens, {n}, kInt32);
+    const Tensor lg = m->model->logits(tk, start_pos);
+    if (logits_out) std::memcpy(logits_out, lg.data_ptr<float>(), (size_t)lg.numel() * sizeof(float));
+    return 0;
+}
+
+int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos)
+{
+    std::vector<int32_t> t(tokens, tokens + n_prompt);
+    t.reserve((size_t)max_tokens);
+    const int total = greedy_sample(*m->model, t, max_tokens, eos);
+    std::memcpy(tokens, t.data(), (size_t)total * sizeof(int32_t));
+    return total;
+}
+
+int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes)
+{
+    std::vector<float> scratch;
+    TinyLlama::synth_weight_bytes(to_params(*cfg), ModuleDtype{to_dtype(cfg->wdtype), to_dtype(cfg->adtype)}, seed, idx,
+                                  scratch, static_cast<uint8_t*>(out), nbytes);
+    return 0;
+}
+
+// tinyllama_to_gten.py:94-201: magic, then [len][name][len][name][nbytes][payload]
+int gten_host_write_gten(const gten_host_config* cfg, uint64_t seed, const char* path)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return -1;
+    const TinyLLamaParams p = to_params(*cfg);
+    const ModuleDtype md{to_dtype(cfg->wdtype), to_dtype(cfg->adtype)};
+    const int64_t magic = 0x454c49464e455447LL;
+    f.write(reinterpret_cast<const char*>(&magic), 8);
+    const int nw = 1 + 9 * p.n_layers + 2;
+    static const char* kinds[9] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                                   "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj", "input_layernorm", "post_attention_layernorm"};
+    std::vector<float> scratch;
+    std::vector<uint8_t> bytes;
+    for (int i = 0; i < nw; i++) {
+        std::string name;
+        if (i == 0) name = "model.embed_tokens.weight";
+        else if (i == nw - 1) name = "lm_head.weight";
+        else if (i == nw - 2) name = "model.norm.weight";
+        else name = "model.layers." + std::to_string((i - 1) / 9) + "." + kinds[(i - 1) % 9] + ".weight";
+        int rows, cols;
+        Dtype dt;
+        TinyLlama::weight_shape(p, md, i, &rows, &cols, &dt);
+        bytes.resize((size_t)rows * synth::row_bytes(dt, cols));
+        TinyLlama::synth_weight_bytes(p, md, seed, i, scratch, bytes.data(), bytes.size());
+        const int32_t len = (int32_t)name.size(), nbytes = (int32_t)bytes.size();
+        for (int rep = 0; rep < 2; rep++) {
+            f.write(reinterpret_cast<const char*>(&len), 4);
+            f.write(name.data(), len);
+        }
+        f.write(reinterpret_cast<const char*>(&nbytes), 4);
+        f.write(reinterpret_cast<const char*>(bytes.data()), nbytes);
+    }
+    return f.good() ? 0 : -2;
+}
+
+void gten_host_synthetic_tokens(int32_t* out, int count, uint32_t seed, int n_vocab)
+{
+    const std::vector<int32_t> t = synth::synthetic_tokens(count, seed, n_vocab);
+    std::memcpy(out, t.data(), (size_t)count * sizeof(int32_t));
+}
+
+} // extern "C"

@@ -1,0 +1,214 @@
+// tinyllama_model.h -- the caller of the hot path: model wiring, .gten loader
+// and greedy loop, written against the HBM-backed gten API.  Counterpart of the
+// reference's tinyllama.cpp:12-76 (params, TinyLlama), 301-392 (loader) and
+// 395-440 (greedy sampler); CLI, tokenizer and top-k sampling are out of scope
+// (SURVEY 8(f) rank 4).
+#pragma once
+
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../gten/gten.h"
+#include "synth.h"
+
+namespace gten {
+
+// tinyllama.cpp:12-20, but runtime-configurable (small parity models)
+struct TinyLLamaParams {
+    int n_vocab = 32003;
+    int max_ctx = 2048;
+    int n_embd = 2048;
+    int n_ffn = 5632;
+    int n_layers = 22;
+    int n_heads = 32;
+    int n_query_groups = 4;
+};
+
+class TinyLlama {
+public:
+    const TinyLLamaParams params;
+    ModuleDtype dtype_;
+    int n_ctx_;
+
+public:
+    // tinyllama.cpp:30-43
+    TinyLlama(const int n_ctx, ModuleDtype dtype, TinyLLamaParams p = TinyLLamaParams{})
+        : params{p},
+          dtype_{dtype},
+          n_ctx_{n_ctx},
+          tok_emb_{Embedding(p.n_vocab, p.n_embd, n_ctx, dtype)},
+          norm_{RMSNorm(p.n_embd, n_ctx, {kFloat16, dtype.adtype})},
+          lm_head_{EmbeddingLinear{p.n_embd, p.n_vocab, n_ctx, {dtype.wdtype, kFloat32}}}
+    {
+        blocks_.reserve(p.n_layers);
+        for (int i = 0; i < p.n_layers; i++)
+            blocks_.push_back(AttentionBlock(p.n_heads, p.n_embd, p.n_query_groups, p.n_ffn, n_ctx, dtype));
+    }
+
+    // tinyllama.cpp:45-61: the whole token history comes in, rows
+    // [start_pos, n) are computed, the result is the f32 logits of the last row.
+    Tensor logits(const Tensor& tokens, const int start_pos = 0)
+    {
+        if (tokens.numel() > n_ctx_) {
+            std::cerr << "Number of prompt tokens (" << tokens.numel() << ") exceed provided maximum ctx size (" << n_ctx_ << ")\n";
+            std::exit(EXIT_FAILURE);
+        }
+        Tensor x = tok_emb_.forward(tokens, start_pos);
+        for (auto& block : blocks_) x = block.forward(x, start_pos);
+        x = norm_.forward(x, start_pos);
+        return lm_head_.forward(x);
+    }
+
+    int n_weights() const { return 1 + 9 * params.n_layers + 2; }
+
+    // weight tensors in .gten order (tinyllama.cpp:345-391)
+    Tensor& weight(int idx)
+    {
+        const int last = n_weights() - 1;
+        GTEN_ASSERT(idx >= 0 && idx <= last);
+        if (idx == 0) return tok_emb_.weight;
+        if (idx == last) return lm_head_.weight;
+        if (idx == last - 1) return norm_.weight;
+        AttentionBlock& b = blocks_[(idx - 1) / 9];
+        switch ((idx - 1) % 9) {
+        case 0: return b.attn.query.weight;
+        case 1: return b.attn.key.weight;
+        case 2: return b.attn.value.weight;
+        case 3: return b.attn.qkv_proj.weight;
+        case 4: return b.ffn_gate_proj.weight;
+        case 5: return b.ffn_up_proj.weight;
+        case 6: return b.ffn_down_proj.weight;
+        case 7: return b.attn_norm.weight;
+        default: return b.ffn_norm.weight;
+        }
+    }
+
+    // .gten reader (tinyllama.cpp:301-392): magic, then per tensor
+    // [i32 len][name][i32 len][name][i32 nbytes][payload] in fixed order; names
+    // are skipped, the payload size must match the tensor.
+    void load_from_ckpt(std::ifstream& ckpt)
+    {
+        Timer load_timer{&load_time};
+        int64_t magic = 0;
+        ckpt.read(reinterpret_cast<char*>(&magic), sizeof(magic));
+        GTEN_ASSERTM(magic == 0x454c49464e455447LL, "Magic number in the binary does not match the expected one.");
+        for (int i = 0; i < n_weights(); i++) {
+            std::string name;
+            for (int rep = 0; rep < 2; rep++) {
+                int32_t len = 0;
+                ckpt.read(reinterpret_cast<char*>(&len), sizeof(len));
+                GTEN_ASSERTM(ckpt.good() && len >= 0 && len < 4096, "Corrupt tensor header in checkpoint.");
+                name.resize((size_t)len);
+                ckpt.read(name.data(), len);
+            }
+            int32_t nbytes = 0;
+            ckpt.read(reinterpret_cast<char*>(&nbytes), sizeof(nbytes));
+            Tensor& w = weight(i);
+            GTEN_ASSERTM(static_cast<size_t>(nbytes) == w.nbytes(), "Weight `%s` data size: %d does not match the expected size: %zu.",
+                         name.c_str(), nbytes, w.nbytes());
+            ckpt.read(w.data_ptr<char>(), nbytes);      // host mirror; staged to HBM below
+            GTEN_ASSERTM(ckpt.good(), "Checkpoint ended inside weight `%s`.", name.c_str());
+            w.device_weight();                          // upload (+ repack Q8/Q4) and drop the host copy
+        }
+    }
+
+    // Synthetic weights (host/synth.h): generated, quantized like the reference
+    // converter, and staged to HBM tensor by tensor.
+    void load_synthetic(uint64_t seed)
+    {
+        Timer load_timer{&load_time};
+        std::vector<float> f32;
+        for (int i = 0; i < n_weights(); i++) {
+            Tensor& w = weight(i);
+            synth_weight_bytes(params, dtype_, seed, i, f32, w.data_ptr<uint8_t>(), w.nbytes());
+            w.device_weight();
+        }
+    }
+
+    // shape of tensor idx: rows, cols, storage dtype
+    static void weight_shape(const TinyLLamaParams& p, ModuleDtype md, int idx, int* rows, int* cols, Dtype* dt)
+    {
+        const int E = p.n_embd, F = p.n_ffn, V = p.n_vocab, KV = (E / p.n_heads) * p.n_query_groups;
+        const int last = 1 + 9 * p.n_layers + 1;
+        *dt = md.wdtype;
+        if (idx == 0 || idx == last) { *rows = V; *cols = E; return; }
+        if (idx == last - 1) { *rows = 1; *cols = E; *dt = kFloat16; return; }
+        switch ((idx - 1) % 9) {
+        case 0: case 3: *rows = E; *cols = E; break;
+        case 1: case 2: *rows = KV; *cols = E; break;
+        case 4: case 5: *rows = F; *cols = E; break;
+        case 6: *rows = E; *cols = F; break;
+        default: *rows = 1; *cols = E; *dt = kFloat16; break;
+        }
+    }
+
+    static void synth_weight_bytes(const TinyLLamaParams& p, ModuleDtype md, uint64_t seed, int idx,
+                                   std::vector<float>& scratch, uint8_t* out, size_t nbytes)
+    {
+        int rows, cols;
+        Dtype dt;
+        weight_shape(p, md, idx, &rows, &cols, &dt);
+        GTEN_ASSERTM((size_t)rows * synth::row_bytes(dt, cols) == nbytes, "synthetic weight %d: size mismatch", idx);
+        const bool is_norm = (rows == 1 && dt == kFloat16);
+        scratch.resize((size_t)rows * cols);
+        synth::fill_normal(scratch.data(), scratch.size(), seed, (uint64_t)idx, is_norm ? 1.0f : 0.0f, is_norm ? 0.05f : 0.02f);
+        synth::quantize_weight(scratch.data(), rows, cols, dt, out);
+    }
+
+    // Lin / Attn / Other split in the spirit of tinyllama.cpp:515-582.  The times
+    // are meaningful only with GTEN_HIP_SYNC_TIMERS=1 (see gten/modules.h).
+    void print_perf(const int n_pred_tokens)
+    {
+        int64_t lin = lm_head_.exec_time, attn = 0, other = tok_emb_.exec_time + norm_.exec_time;
+        for (auto& b : blocks_) {
+            lin += b.attn.query.exec_time + b.attn.key.exec_time + b.attn.value.exec_time + b.attn.qkv_proj.exec_time +
+                   b.ffn_gate_proj.exec_time + b.ffn_up_proj.exec_time + b.ffn_down_proj.exec_time;
+            attn += b.attn.exec_time_attn;
+            other += b.attn_norm.exec_time + b.ffn_norm.exec_time + b.inp_res.exec_time + b.attn_res.exec_time +
+                     b.ffn_mul.exec_time + b.ffn_silu.exec_time + b.attn.q_rope.exec_time + b.attn.k_rope.exec_time;
+        }
+        const int n = n_pred_tokens > 0 ? n_pred_tokens : 1;
+        std::cout << "tokens: " << n_pred_tokens << "  ms/tok: linear " << lin / n << "  attention " << attn / n << "  other "
+                  << other / n << "  sample " << sample_time / n << "  load " << load_time << " ms  tensor bytes "
+                  << G_TensorMemAllocated / 1000000 << " MB\n";
+    }
+
+private:
+    Embedding tok_emb_;
+    RMSNorm norm_;
+    EmbeddingLinear lm_head_;
+    std::vector<AttentionBlock> blocks_;
+
+public:
+    int64_t load_time = 0;
+    int64_t sample_time = 0;
+};
+
+// Greedy loop of tinyllama.cpp:395-440 on token ids (no tokenizer): iteration 0
+// is the prefill (start_pos 0), later iterations compute one row; argmax with
+// strict '>' so the first maximum wins; stop at `eos`.
+inline int greedy_sample(TinyLlama& model, std::vector<int32_t>& tokens, const int n_predict, const int eos)
+{
+    const int max_iters = n_predict - (int)tokens.size();
+    for (int i = 0; i < max_iters; i++) {
+        Tensor input{tokens.data(), {(int)tokens.size()}, kInt32};
+        const int start_pos = (i == 0) ? 0 : input.numel() - 1;
+        Tensor logits = model.logits(input, start_pos);
+        Timer sample_timer{&model.sample_time};
+        const int n = logits.numel();
+        const float* p = const_cast<const Tensor&>(logits).data_ptr<float>();
+        float best = -std::numeric_limits<float>::infinity();
+        int best_i = 0;
+        for (int j = 0; j < n; j++)
+            if (p[j] > best) { best = p[j]; best_i = j; }
+        if (best_i == eos) break;
+        tokens.push_back(best_i);
+    }
+    return (int)tokens.size();
+}
+
+} // namespace gten

@@ -1,0 +1,155 @@
+"""ctypes binding of include/gten_host.h (libgten_host.so): the C++ model driver."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from .hipabi import GtenHipError, load as _load_hip
+
+
+class HostConfig(C.Structure):
+    _fields_ = [(k, C.c_int) for k in
+                ("n_vocab", "max_ctx", "n_embd", "n_ffn", "n_layers", "n_heads", "n_kv_heads", "wdtype", "adtype")]
+
+    def weight_shapes(self):
+        E, F, V = self.n_embd, self.n_ffn, self.n_vocab
+        KV = (E // self.n_heads) * self.n_kv_heads
+        W, F16 = self.wdtype, 1
+        out = [(V, E, W)]
+        for _ in range(self.n_layers):
+            out += [(E, E, W), (KV, E, W), (KV, E, W), (E, E, W), (F, E, W), (F, E, W), (E, F, W), (1, E, F16), (1, E, F16)]
+        return out + [(1, E, F16), (V, E, W)]
+
+
+def _sig(lib, name, res, args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = args
+    return f
+
+
+class GtenHost:
+    SYMBOLS = [
+        "gten_host_default_config", "gten_host_model_create", "gten_host_model_free", "gten_host_model_n_weights",
+        "gten_host_model_weight_bytes", "gten_host_model_set_weight", "gten_host_model_load_gten",
+        "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy",
+        "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
+    ]
+
+    def __init__(self, path=None):
+        path = path or _build.HOST_LIB
+        if not os.path.exists(path):
+            raise GtenHipError(f"{path} is missing: run __graft_entry__.build()")
+        self.hip = _load_hip()                     # libgten_hip.so first (RTLD_GLOBAL)
+        self.lib = L = C.CDLL(path)
+        vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+        cfgp = C.POINTER(HostConfig)
+        self._defcfg = _sig(L, "gten_host_default_config", None, [cfgp, ci, ci])
+        self._create = _sig(L, "gten_host_model_create", vp, [cfgp])
+        self._free = _sig(L, "gten_host_model_free", None, [vp])
+        self._nw = _sig(L, "gten_host_model_n_weights", ci, [vp])
+        self._wb = _sig(L, "gten_host_model_weight_bytes", sz, [vp, ci])
+        self._setw = _sig(L, "gten_host_model_set_weight", ci, [vp, ci, vp, sz])
+        self._loadg = _sig(L, "gten_host_model_load_gten", ci, [vp, C.c_char_p])
+        self._loads = _sig(L, "gten_host_model_load_synthetic", ci, [vp, C.c_uint64])
+        self._logits = _sig(L, "gten_host_model_logits", ci, [vp, vp, ci, ci, vp])
+        self._greedy = _sig(L, "gten_host_model_greedy", ci, [vp, vp, ci, ci, ci])
+        self._synthw = _sig(L, "gten_host_synth_weight", ci, [cfgp, C.c_uint64, ci, vp, sz])
+        self._writeg = _sig(L, "gten_host_write_gten", ci, [cfgp, C.c_uint64, C.c_char_p])
+        self._stoks = _sig(L, "gten_host_synthetic_tokens", None, [vp, ci, C.c_uint32, ci])
+
+    def default_config(self, wdtype, adtype):
+        cfg = HostConfig()
+        self._defcfg(C.byref(cfg), wdtype, adtype)
+        return cfg
+
+    def synth_weight(self, cfg, seed, idx):
+        rows, cols, dt = cfg.weight_shapes()[idx]
+        out = np.zeros(rows * self.hip.row_bytes(dt, cols), np.uint8)
+        rc = self._synthw(C.byref(cfg), seed, idx, out.ctypes.data_as(C.c_void_p), out.size)
+        if rc:
+            raise GtenHipError(f"gten_host_synth_weight rc={rc}")
+        return out
+
+    def write_gten(self, cfg, seed, path):
+        rc = self._writeg(C.byref(cfg), seed, path.encode())
+        if rc:
+            raise GtenHipError(f"gten_host_write_gten rc={rc}")
+
+    def synthetic_tokens(self, count, seed=12345, n_vocab=32003):
+        out = np.zeros(count, np.int32)
+        self._stoks(out.ctypes.data_as(C.c_void_p), count, seed, n_vocab)
+        return out
+
+    def model(self, cfg):
+        return HostModel(self, cfg)
+
+
+class HostModel:
+    """The C++ TinyLlama driver on the GPU (needs an initialised device)."""
+
+    def __init__(self, host, cfg):
+        self.host = host
+        self.cfg = cfg
+        if host.hip.device_count() < 1:
+            raise GtenHipError("no MI355X visible: the model runs only on the gten_hip path")
+        self.h = host._create(C.byref(cfg))
+
+    def n_weights(self):
+        return self.host._nw(self.h)
+
+    def weight_bytes(self, idx):
+        return self.host._wb(self.h, idx)
+
+    def set_weight(self, idx, data):
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        rc = self.host._setw(self.h, idx, data.ctypes.data_as(C.c_void_p), data.size)
+        if rc:
+            raise GtenHipError(f"set_weight({idx}) rc={rc}")
+
+    def load_gten(self, path):
+        rc = self.host._loadg(self.h, path.encode())
+        if rc:
+            raise GtenHipError(f"load_gten({path}) rc={rc}")
+
+    def load_synthetic(self, seed):
+        rc = self.host._loads(self.h, seed)
+        if rc:
+            raise GtenHipError(f"load_synthetic rc={rc}")
+
+    def logits(self, tokens, start_pos, want=True):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.zeros(self.cfg.n_vocab, np.float32) if want else None
+        rc = self.host._logits(self.h, tokens.ctypes.data_as(C.c_void_p), len(tokens), start_pos,
+                               out.ctypes.data_as(C.c_void_p) if want else None)
+        if rc:
+            raise GtenHipError(f"logits rc={rc}")
+        return out
+
+    def greedy(self, prompt, max_tokens, eos=-1):
+        buf = np.zeros(max_tokens, np.int32)
+        buf[: len(prompt)] = prompt
+        total = self.host._greedy(self.h, buf.ctypes.data_as(C.c_void_p), len(prompt), max_tokens, eos)
+        return buf[:total].copy()
+
+    def close(self):
+        if self.h:
+            self.host._free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is None:
+        _host = GtenHost()
+    return _host
