@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- decode throughput of TinyLlama-1.1B on MI355X through the gten_hip path.
+
+Metric (BASELINE.json): decode tok/s, TinyLlama-1.1B q4, ctx = 2048, one
+MI355X per replica; achieved HBM GB/s vs peak.  One "step" = one decoded token
+= one pass of the hot path (embedding row, 22 blocks, final norm, lm_head,
+greedy argmax) over a context that ENDS at n = 2048: the context is first filled
+by real single-token decode steps (untimed), then W warm-up steps, then exactly
+K timed steps bracketed by barrier + device synchronise.  Synthetic weights
+(seeded generator, quantized with the reference converter's rules) and
+teacher-forced synthetic token ids: there is no network for checkpoints.
+
+N > 1 (`torch.distributed.run`, one rank per GPU): independent replicas, one
+prompt stream per GPU, no collective on the data path; `value`
+is the sum over ranks of tokens decoded / the slowest rank's time.
+
+Output: ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event
+timed on the library's stream) and `cpu_baseline` (the reference's own
+AVX/OpenMP build from oracle/_ref when present, else the oracle port; bounded
+sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MODES = {"q4": (4, 3), "q8": (3, 3), "f16": (1, 1)}   # (wdtype, adtype), tinyllama.cpp:258-265
+N_CTX = 2048
+
+
+def weight_bytes_per_elt(mode):
+    return {"q4": 18 / 32, "q8": 34 / 32, "f16": 2.0}[mode]
+
+
+def algorithmic_bytes(mode, n):
+    """B(n) of SURVEY 8(d): every linear weight once + norm vectors + K/V rows [0,n)."""
+    elts = 1_034_426_368                       # 22*(2*2048^2 + 2*256*2048 + 3*5632*2048) + 32003*2048
+    w = elts * weight_bytes_per_elt(mode)
+    nw = 45 * 2048 * 2
+    kv_row = 2 * 256 * 22 * (2.0 if mode == "f16" else 34 / 32)
+    return w + nw + kv_row * n
+
+
+def linear_shapes():
+    """(family, d_out, d_in, launches per token) of the W.x contractions."""
+    return [("q", 2048, 2048, 22), ("k", 256, 2048, 22), ("v", 256, 2048, 22), ("o", 2048, 2048, 22),
+            ("gate", 5632, 2048, 22), ("up", 5632, 2048, 22), ("down", 2048, 5632, 22), ("lm_head", 32003, 2048, 1)]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--mode", choices=sorted(MODES), default="q4")
+    ap.add_argument("--path", choices=["auto", "ops", "fused"], default="auto",
+                    help="ops: one kernel per gten operator; fused: the decode fast path (default when available)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def cpu_baseline(host, cfg, mode, seed, n_steps):
+    """Time the CPU path on this box's host cores on a bounded sample of the same
+    workload: single-token decode steps ending at n = 2048.  The K/V history below
+    the sampled rows is whatever the freshly allocated caches hold (zero pages):
+    the CPU path has no data-dependent control flow, so its timing is that of a
+    real context of the same length, without spending minutes on a CPU prefill."""
+    from oracle import orc
+    import numpy as np
+    wd, ad = MODES[mode]
+    toks = host.synthetic_tokens(N_CTX, seed=12345)
+    ref = orc.load_ref("avx")
+    path = f"/tmp/gten_bench_{mode}_{seed}.gten"
+    t_build = time.time()
+    if not os.path.exists(path) or os.path.getsize(path) < 1000:
+        host.write_gten(cfg, seed, path + ".tmp")
+        os.replace(path + ".tmp", path)
+    if ref is not None:
+        kind, model = "reference", ref.tinyllama(N_CTX, wd, ad)
+        model.load(path)
+    else:
+        kind = "port"
+        model = orc.load_oracle().model(orc.Config(**{k: getattr(cfg, k) for k, _ in cfg._fields_}))
+        model.load_gten(path)
+    t_build = time.time() - t_build
+    times = []
+    for i in range(n_steps):
+        n = N_CTX - n_steps + 1 + i
+        t0 = time.perf_counter()
+        model.logits(toks[:n], n - 1)
+        times.append(time.perf_counter() - t0)
+    model.close()
+    med = float(np.median(times[1:] if len(times) > 1 else times))
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(1.0 / med, 3), "unit": "tok/s", "cores": cores, "kind": kind,
+            "sample": f"{n_steps} single-token decode steps at n={N_CTX - n_steps + 1}..{N_CTX} (median of all but "
+                      f"the first), {mode} weights, zero-filled K/V history below the sampled rows, "
+                      f"{'reference -O3 -fopenmp -mavx -mf16c build (oracle/_ref)' if kind == 'reference' else 'oracle C port'}",
+            "ms_per_step": round(med * 1e3, 2), "setup_s": round(t_build, 1)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("GTEN_HIP_DEVICE", str(local_rank))
+
+    import numpy as np
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    hip = pkg.hipabi.load(local_rank)
+    host = pkg.load_host()
+
+    wd, ad = MODES[args.mode]
+    cfg = host.default_config(wd, ad)
+    model = host.model(cfg)
+    t0 = time.time()
+    model.load_synthetic(args.seed)
+    load_s = time.time() - t0
+
+    K, W = args.steps, args.warmup
+    toks = host.synthetic_tokens(N_CTX, seed=12345 + rank)
+    fused = hasattr(model, "decode_step") and args.path in ("auto", "fused")
+    if args.path == "fused" and not fused:
+        raise SystemExit("fused decode path requested but not built")
+
+    window = 64                                  # timed steps cycle over n in (N_CTX-window, N_CTX]
+    def n_of(i, total):
+        if total <= N_CTX - 1:
+            return N_CTX - total + 1 + i         # the last step lands on n = N_CTX
+        return N_CTX - window + 1 + (i % window)
+
+    def step(n):
+        if fused:
+            return model.decode_step(toks, n)
+        lg = model.logits(toks[:n], n - 1)       # logits reach the host; greedy argmax there
+        return int(np.argmax(lg))
+
+    # fill the context with real decode steps (untimed), then warm up
+    total = K + W
+    first = n_of(0, total)
+    t_fill = time.time()
+    for n in range(1, first):
+        if fused:
+            model.decode_step(toks, n)
+        else:
+            model.logits(toks[:n], n - 1, want=False)
+    hip.sync()
+    t_fill = time.time() - t_fill
+    for i in range(W):
+        step(n_of(i, total))
+
+    def barrier():
+        hip.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    last = 0
+    for i in range(W, W + K):
+        last = step(n_of(i, total))
+    hip.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # ---- roofline of the dominant kernel: HIP events on the library's stream
+    roofline = None
+    if rank == 0:
+        P = min(16, K)
+        hip.prof_enable(True)
+        for i in range(P):
+            step(n_of(W + K - P + i, total))
+        prof = hip.prof_read()
+        hip.prof_enable(False)
+        fam, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
+        wb = weight_bytes_per_elt(args.mode)
+        act_b = 2.0 if args.mode == "f16" else 34 / 32
+        lin = {name: (dout * din * wb + din * act_b + dout * act_b, cnt) for name, dout, din, cnt in linear_shapes()}
+        per_family_bytes = {
+            "matmul_2d": sum(b * c for b, c in lin.values()),
+            "decode_gemv_qkv": (lin["q"][0] + lin["k"][0] + lin["v"][0]) * 22,
+            "decode_gemv_o": lin["o"][0] * 22,
+            "decode_gemv_gateup": (lin["gate"][0] + lin["up"][0]) * 22,
+            "decode_gemv_down": lin["down"][0] * 22,
+            "decode_gemv_head": lin["lm_head"][0],
+        }
+        per_launch = None
+        if fam in per_family_bytes:
+            per_launch = per_family_bytes[fam] / (launches / P)
+        avg_us = ms * 1e3 / launches
+        achieved = (per_launch / (avg_us * 1e-6) / 1e9) if per_launch else None
+        roofline = {"bound": "hbm", "kernel": fam, "achieved": round(achieved, 1) if achieved else None,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+                    "traffic": None, "avg_launch_us": round(avg_us, 3), "launches_per_step": launches // P,
+                    "algorithmic_bytes_per_launch": int(per_launch) if per_launch else None,
+                    "kernel_time_share_of_step": {k: round(v[1] / P / (elapsed / K * 1e3), 3) for k, v in prof.items()}}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                roofline["traffic"] = json.load(open(tpath)).get(args.mode, {}).get(fam)
+            except Exception:
+                pass
+
+    if rank != 0:
+        return
+    tok_s = world * K / elapsed
+    ms_step = elapsed / K * 1e3
+    n_mid = N_CTX - K // 2 if total <= N_CTX - 1 else N_CTX - window // 2
+    whole = algorithmic_bytes(args.mode, n_mid) / (ms_step * 1e-3) / 1e9
+    out = {
+        "metric": f"decode tok/s TinyLlama-1.1B {args.mode} ctx=2048, 1 GPU; achieved HBM GB/s vs peak",
+        "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"q4": "q4 weights x q8 activations (int8 dot, f32 accumulate)", "q8": "q8 x q8 (int8 dot, f32 accumulate)",
+                  "f16": "f16 (f32 accumulate)"}[args.mode],
+        "data": "synthetic",
+        "config": {"workload": f"TinyLlama-1.1B {args.mode} greedy single-token decode, batch 1 per GPU, steps end at n=2048 "
+                               f"(BASELINE.json configs[{ {'f16': 1, 'q8': 2, 'q4': 3}[args.mode] }])",
+                   "ctx": N_CTX, "kv_cache": "f16" if args.mode == "f16" else "q8 blocks (reference layout)",
+                   "path": "fused" if fused else "ops", "argmax": "device" if fused else "host (128 KB logits D2H per step)",
+                   "parallelism": f"replicas x{world}", "last_token": int(last)},
+        "whole_step_hbm": {"achieved": round(whole, 1), "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBPS, 4),
+                           "algorithmic_bytes_per_step": int(algorithmic_bytes(args.mode, n_mid))},
+        "roofline": roofline,
+        "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1)},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(host, cfg, args.mode, args.seed, args.cpu_steps)
+        except Exception as e:                      # the baseline is a reported extra, never the product path
+            out["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

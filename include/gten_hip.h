@@ -70,6 +70,13 @@ int gten_hip_memcpy_h2d(void* dst, const void* src_host, size_t nbytes);
 int gten_hip_memcpy_d2h(void* dst_host, const void* src, size_t nbytes);
 int gten_hip_memcpy_d2d(void* dst, const void* src, size_t nbytes);
 
+/* HIP-event profiler: while enabled, every kernel launch is bracketed by two
+ * events on the library's stream.  `family` is a kernel-family index
+ * (gten_hip_prof_family_name lists them).  Not usable during graph capture. */
+int         gten_hip_prof_enable(int on);
+int         gten_hip_prof_read(int family, int* launches, double* total_ms);
+const char* gten_hip_prof_family_name(int family);   /* NULL past the last family */
+
 /* bytes of one storage row (gten/tensor.h:97-117, gten/tensor.cpp:37-57) */
 size_t gten_hip_row_bytes(int dtype, int cols);
 

@@ -323,10 +323,9 @@ int gten_hip_pack_weight(const void* src_blocks, int dtype, int rows, int cols, 
     const size_t nblk = (size_t)rows * (cols / 32);
     const unsigned grid = (unsigned)((nblk + 255) / 256);
     if (dtype == GTEN_Q4)
-        hipLaunchKernelGGL(k_pack_q4, dim3(grid), dim3(256), 0, stream(), (const uint8_t*)src_blocks, (uint8_t*)dst_packed, nblk);
+        GTR_LAUNCH(KT_PACK, k_pack_q4, dim3(grid), dim3(256), 0, (const uint8_t*)src_blocks, (uint8_t*)dst_packed, nblk);
     else
-        hipLaunchKernelGGL(k_pack_q8, dim3(grid), dim3(256), 0, stream(), (const uint8_t*)src_blocks, (uint8_t*)dst_packed, rows, cols / 32);
-    GTR_LAUNCHED();
+        GTR_LAUNCH(KT_PACK, k_pack_q8, dim3(grid), dim3(256), 0, (const uint8_t*)src_blocks, (uint8_t*)dst_packed, rows, cols / 32);
     return 0;
 }
 
@@ -342,17 +341,16 @@ int gten_hip_token_embed(const void* w, int w_dtype, int n_vocab, const int32_t*
     const dim3 grid(n - start_pos), block(256);
     if (w_dtype == GTEN_F16) {
         GTR_REQUIRE(out_dtype == GTEN_F16, "token_embed: f16 table needs f16 output (row copy, gten/ops.h:529)");
-        hipLaunchKernelGGL(k_embed<GTEN_F16>, grid, block, 0, stream(), w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
+        GTR_LAUNCH(KT_EMBED, (k_embed<GTEN_F16>), grid, block, 0, w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
     } else if (w_dtype == GTEN_Q8) {
         GTR_REQUIRE(out_dtype == GTEN_Q8, "token_embed: Q8 table needs Q8 output (block copy, gten/ops.h:519)");
-        hipLaunchKernelGGL(k_embed<GTEN_Q8>, grid, block, 0, stream(), w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
+        GTR_LAUNCH(KT_EMBED, (k_embed<GTEN_Q8>), grid, block, 0, w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
     } else if (w_dtype == GTEN_Q4) {
         GTR_REQUIRE(out_dtype == GTEN_Q8, "token_embed: Q4 table needs Q8 output (gten/ops.h:523)");
-        hipLaunchKernelGGL(k_embed<GTEN_Q4>, grid, block, (size_t)d * 4, stream(), w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
+        GTR_LAUNCH(KT_EMBED, (k_embed<GTEN_Q4>), grid, block, (size_t)d * 4, w, n_vocab, tokens, (uint8_t*)out, out_dtype, out_pitch, d, start_pos);
     } else {
         return fail(-4, "token_embed: bad table dtype %d", w_dtype);
     }
-    GTR_LAUNCHED();
     return 0;
 }
 
@@ -375,12 +373,11 @@ int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch, const void* w
     const size_t act = (w_dtype == GTEN_F16) ? (size_t)d_in * 4 : (size_t)(d_in / 32) * 40;
     const size_t smem = 128 + act;
     if (w_dtype == GTEN_F16)
-        hipLaunchKernelGGL(k_matmul<GTEN_F16>, grid, block, smem, stream(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
+        GTR_LAUNCH(KT_MATMUL, (k_matmul<GTEN_F16>), grid, block, smem, (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
     else if (w_dtype == GTEN_Q8)
-        hipLaunchKernelGGL(k_matmul<GTEN_Q8>, grid, block, smem, stream(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
+        GTR_LAUNCH(KT_MATMUL, (k_matmul<GTEN_Q8>), grid, block, smem, (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
     else
-        hipLaunchKernelGGL(k_matmul<GTEN_Q4>, grid, block, smem, stream(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
-    GTR_LAUNCHED();
+        GTR_LAUNCH(KT_MATMUL, (k_matmul<GTEN_Q4>), grid, block, smem, (const uint8_t*)x, x_pitch, w, (uint8_t*)out, out_dtype, out_pitch, d_in, d_out, start_pos);
     return 0;
 }
 
@@ -400,9 +397,8 @@ int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f1
     GTR_NEED_INIT();
     if (int rc = check_rowwise("rms_norm", x, out, dtype, x_pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(w_f16 && out_pitch >= gten_hip_row_bytes(dtype, d), "rms_norm: bad weight/output");
-    hipLaunchKernelGGL(k_rms_norm, dim3(n - start_pos), dim3(256), 64 + (size_t)d * 4, stream(),
+    GTR_LAUNCH(KT_RMSNORM, k_rms_norm, dim3(n - start_pos), dim3(256), 64 + (size_t)d * 4,
                        (const uint8_t*)x, dtype, x_pitch, (const uint16_t*)w_f16, (uint8_t*)out, out_pitch, d, start_pos);
-    GTR_LAUNCHED();
     return 0;
 }
 
@@ -414,8 +410,7 @@ int gten_hip_rotary_emb(void* x, int dtype, size_t pitch, int n, int d, int d_he
     GTR_REQUIRE(n <= GTEN_ROPE_MAX_POS, "rotary_emb: position %d beyond the table (%d)", n, GTEN_ROPE_MAX_POS);
     const float2* table = nullptr;
     if (int rc = rope_table(d_head, &table)) return rc;
-    hipLaunchKernelGGL(k_rope, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(), (uint8_t*)x, dtype, pitch, d, d_head, start_pos, table);
-    GTR_LAUNCHED();
+    GTR_LAUNCH(KT_ROPE, k_rope, dim3(n - start_pos), dim3(256), (size_t)d * 4, (uint8_t*)x, dtype, pitch, d, d_head, start_pos, table);
     return 0;
 }
 
@@ -423,9 +418,8 @@ int gten_hip_silu(const void* x, void* out, int dtype, size_t pitch, int n, int 
 {
     GTR_NEED_INIT();
     if (int rc = check_rowwise("silu", x, out, dtype, pitch, n, d, start_pos)) return rc;
-    hipLaunchKernelGGL(k_elementwise<EW_SILU>, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(),
+    GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_SILU>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)x, (const uint8_t*)nullptr, (uint8_t*)out, dtype, pitch, d, start_pos);
-    GTR_LAUNCHED();
     return 0;
 }
 
@@ -434,9 +428,8 @@ int gten_hip_mul(const void* a, const void* b, void* out, int dtype, size_t pitc
     GTR_NEED_INIT();
     if (int rc = check_rowwise("mul", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "mul: null pointer");
-    hipLaunchKernelGGL(k_elementwise<EW_MUL>, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(),
+    GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_MUL>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
-    GTR_LAUNCHED();
     return 0;
 }
 
@@ -445,9 +438,8 @@ int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitc
     GTR_NEED_INIT();
     if (int rc = check_rowwise("add", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "add: null pointer");
-    hipLaunchKernelGGL(k_elementwise<EW_ADD>, dim3(n - start_pos), dim3(256), (size_t)d * 4, stream(),
+    GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_ADD>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
-    GTR_LAUNCHED();
     return 0;
 }
 
@@ -466,10 +458,9 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
     GTR_REQUIRE(n - start_pos <= 65535 && n <= 12288, "qkv_attn: context %d too long for this kernel", n);
     const int p_cap = (n + 31) & ~31;
     const size_t smem = (size_t)(16 + d_head + 8 + d_head + 256 + p_cap) * 4;
-    hipLaunchKernelGGL(k_attn, dim3(n_heads, n - start_pos), dim3(256), smem, stream(),
+    GTR_LAUNCH(KT_ATTN, k_attn, dim3(n_heads, n - start_pos), dim3(256), smem,
                        (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v, (uint8_t*)out, dtype,
                        q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, d_head, start_pos, p_cap);
-    GTR_LAUNCHED();
     return 0;
 }
 

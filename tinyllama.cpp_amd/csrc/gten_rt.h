@@ -36,3 +36,26 @@ int rope_table(int d_head, const float2** out);
 
 // launch errors surface here (bad grid, missing code object, ...)
 #define GTR_LAUNCHED() GTR_CHECK(hipGetLastError())
+
+// Kernel families for the in-library HIP-event profiler (gten_hip_prof_*): when
+// profiling is on, every launch is bracketed by two events recorded on the
+// library's stream, so bench.py can report per-kernel average durations that
+// are directly comparable with `rocprofv3 --kernel-trace --stats`.
+enum {
+    KT_PACK = 0, KT_EMBED, KT_MATMUL, KT_RMSNORM, KT_ROPE, KT_ELEMWISE, KT_ATTN,
+    KT_DEC_GEMV_QKV, KT_DEC_ATTN_SCORE, KT_DEC_ATTN_PV, KT_DEC_GEMV_O, KT_DEC_GEMV_GATEUP, KT_DEC_GEMV_DOWN,
+    KT_DEC_GEMV_HEAD, KT_DEC_ARGMAX, KT_COUNT
+};
+
+namespace gtr {
+void prof_before(int tag);
+void prof_after(int tag);
+}
+
+#define GTR_LAUNCH(tag, kernel, grid, block, smem, ...)                                        \
+    do {                                                                                       \
+        gtr::prof_before(tag);                                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, smem, gtr::stream(), __VA_ARGS__);             \
+        gtr::prof_after(tag);                                                                  \
+        GTR_LAUNCHED();                                                                        \
+    } while (0)

@@ -53,6 +53,34 @@ int rope_table(int d_head, const float2** out)
     return 0;
 }
 
+// ---- HIP-event profiler -------------------------------------------------
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_ev;          // pairs: 2*i start, 2*i+1 stop
+static std::vector<int> g_ev_tag;
+static size_t g_ev_used = 0;
+static const size_t kMaxPairs = 1 << 16;
+
+void prof_before(int tag)
+{
+    if (!g_prof_on || g_ev_used >= kMaxPairs) return;
+    if (g_ev.size() < 2 * (g_ev_used + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        g_ev.push_back(a);
+        g_ev.push_back(b);
+        g_ev_tag.push_back(tag);
+    }
+    g_ev_tag[g_ev_used] = tag;
+    hipEventRecord(g_ev[2 * g_ev_used], g_stream);
+}
+
+void prof_after(int)
+{
+    if (!g_prof_on || g_ev_used >= kMaxPairs) return;
+    hipEventRecord(g_ev[2 * g_ev_used + 1], g_stream);
+    g_ev_used++;
+}
+
 } // namespace gtr
 
 using namespace gtr;
@@ -136,6 +164,42 @@ int gten_hip_memcpy_d2d(void* dst, const void* src, size_t nbytes)
     GTR_NEED_INIT();
     GTR_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, g_stream));
     return 0;
+}
+
+int gten_hip_prof_enable(int on)
+{
+    GTR_NEED_INIT();
+    GTR_CHECK(hipStreamSynchronize(g_stream));
+    g_prof_on = on != 0;
+    if (on) g_ev_used = 0;
+    return 0;
+}
+
+int gten_hip_prof_read(int family, int* launches, double* total_ms)
+{
+    GTR_NEED_INIT();
+    GTR_CHECK(hipStreamSynchronize(g_stream));
+    int n = 0;
+    double ms = 0.0;
+    for (size_t i = 0; i < g_ev_used; i++) {
+        if (g_ev_tag[i] != family) continue;
+        float t = 0.f;
+        GTR_CHECK(hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]));
+        ms += t;
+        n++;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    return 0;
+}
+
+const char* gten_hip_prof_family_name(int family)
+{
+    static const char* names[KT_COUNT] = {
+        "pack_weight", "token_embed", "matmul_2d", "rms_norm", "rotary_emb", "elementwise", "qkv_attn",
+        "decode_gemv_qkv", "decode_attn_score", "decode_attn_pv", "decode_gemv_o", "decode_gemv_gateup",
+        "decode_gemv_down", "decode_gemv_head", "decode_argmax"};
+    return (family >= 0 && family < KT_COUNT) ? names[family] : nullptr;
 }
 
 size_t gten_hip_row_bytes(int dtype, int cols)

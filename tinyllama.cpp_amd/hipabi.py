@@ -75,7 +75,8 @@ class GtenHip:
     SYMBOLS = [
         "gten_hip_device_count", "gten_hip_init", "gten_hip_last_error", "gten_hip_stream", "gten_hip_sync",
         "gten_hip_malloc", "gten_hip_free", "gten_hip_memset", "gten_hip_memcpy_h2d", "gten_hip_memcpy_d2h",
-        "gten_hip_memcpy_d2d", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
+        "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
+        "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
         "gten_hip_add", "gten_hip_qkv_attn",
     ]
@@ -99,6 +100,9 @@ class GtenHip:
         self._d2h = _sig(L, "gten_hip_memcpy_d2h", ci, [vp, vp, sz])
         self._d2d = _sig(L, "gten_hip_memcpy_d2d", ci, [vp, vp, sz])
         self._row_bytes = _sig(L, "gten_hip_row_bytes", sz, [ci, ci])
+        self._prof_enable = _sig(L, "gten_hip_prof_enable", ci, [ci])
+        self._prof_read = _sig(L, "gten_hip_prof_read", ci, [ci, C.POINTER(ci), C.POINTER(C.c_double)])
+        self._prof_name = _sig(L, "gten_hip_prof_family_name", C.c_char_p, [ci])
         self._pack = _sig(L, "gten_hip_pack_weight", ci, [vp, ci, ci, ci, vp])
         self._embed = _sig(L, "gten_hip_token_embed", ci, [vp, ci, ci, vp, vp, ci, sz, ci, ci, ci])
         self._matmul = _sig(L, "gten_hip_matmul_2d", ci, [vp, ci, sz, vp, ci, vp, ci, sz, ci, ci, ci, ci])
@@ -131,6 +135,24 @@ class GtenHip:
 
     def stream(self):
         return self._stream()
+
+    def prof_enable(self, on):
+        self._check(self._prof_enable(1 if on else 0))
+
+    def prof_read(self):
+        """{family name: (launches, total_ms)} for every family with at least one launch."""
+        out = {}
+        fam = 0
+        while True:
+            name = self._prof_name(fam)
+            if name is None:
+                break
+            n, ms = C.c_int(0), C.c_double(0.0)
+            self._check(self._prof_read(fam, C.byref(n), C.byref(ms)))
+            if n.value:
+                out[name.decode()] = (n.value, ms.value)
+            fam += 1
+        return out
 
     def row_bytes(self, dtype, cols):
         return self._row_bytes(dtype, cols)
