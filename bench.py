@@ -145,9 +145,15 @@ def main():
             return N_CTX - total + 1 + i         # the last step lands on n = N_CTX
         return N_CTX - window + 1 + (i % window)
 
+    if fused:
+        model.decode_begin(toks)                 # teacher-forced ids live on the device
+    else:
+        model.set_fast_decode(False)
+
     def step(n):
         if fused:
-            return model.decode_step(toks, n)
+            model.decode_step(n, True)           # asynchronous graph replay; argmax stays on the device
+            return None
         lg = model.logits(toks[:n], n - 1)       # logits reach the host; greedy argmax there
         return int(np.argmax(lg))
 
@@ -157,7 +163,7 @@ def main():
     t_fill = time.time()
     for n in range(1, first):
         if fused:
-            model.decode_step(toks, n)
+            model.decode_step(n, True)
         else:
             model.logits(toks[:n], n - 1, want=False)
     hip.sync()
@@ -176,6 +182,8 @@ def main():
     last = 0
     for i in range(W, W + K):
         last = step(n_of(i, total))
+    if fused:
+        last = model.decode_result(n_of(W + K - 1, total))     # waits for the stream
     hip.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

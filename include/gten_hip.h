@@ -125,6 +125,43 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
                       size_t q_pitch, size_t kv_pitch, size_t out_pitch,
                       int n, int n_heads, int n_kv_heads, int d_head, int start_pos);
 
+/* ---- single-token decode fast path -------------------------------------
+ * One call = one decoded token = TinyLlama::logits(tokens, start_pos = n-1)
+ * (tinyllama.cpp:45-61) plus the greedy argmax of tinyllama.cpp:416-424, for a
+ * model whose weights / K,V caches are the SAME device tensors the operators
+ * above use (the caches are Linear::acv of the key / value projections,
+ * gten/modules.cpp:188-201).  Results are the bytes the operator-by-operator
+ * path produces (same rounding points); the work is fused into 6 launches per
+ * block and replayed from one hipGraph, with the position n read from device
+ * memory.  Rows < n-1 of the caches must already hold the context (from
+ * earlier steps or from an operator-path prefill). */
+typedef struct {
+    const void *wq, *wk, *wv, *wo, *wgate, *wup, *wdown;   /* packed Q8/Q4 or f16 */
+    const void *attn_norm, *ffn_norm;                      /* f16 [n_embd] */
+    void *kcache, *vcache;                                 /* [max_ctx][kv_dim] activation dtype, dense rows */
+} gten_hip_layer_ptrs;
+
+typedef struct {
+    int n_vocab, max_ctx, n_embd, n_ffn, n_layers, n_heads, n_kv_heads, wdtype, adtype;
+    const void* embed;          /* [n_vocab][n_embd] */
+    const void* final_norm;     /* f16 [n_embd] */
+    const void* lm_head;        /* [n_vocab][n_embd] */
+    float* logits;              /* f32 [n_vocab] output (EmbeddingLinear::acv) */
+} gten_hip_decoder_desc;
+
+typedef struct gten_hip_decoder gten_hip_decoder;
+
+int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, gten_hip_decoder** out);
+int gten_hip_decoder_destroy(gten_hip_decoder* dec);
+/* token ids (host) for positions [first, first+count): the step for context
+ * length n embeds token[n-1]. */
+int gten_hip_decoder_set_tokens(gten_hip_decoder* dec, const int32_t* tokens_host, int first, int count);
+/* asynchronous: computes row n-1, logits and their argmax.  use_graph != 0
+ * replays the captured hipGraph (captured on first use). */
+int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
+/* waits for the stream and returns the argmax produced by step n */
+int gten_hip_decoder_result(gten_hip_decoder* dec, int n, int32_t* argmax_host);
+
 #ifdef __cplusplus
 }
 #endif

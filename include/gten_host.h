@@ -53,6 +53,18 @@ int gten_host_model_logits(gten_host_model* m, const int32_t* tokens, int n, int
  * `eos` is produced (pass eos < 0 to never stop).  Returns the total count. */
 int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos);
 
+/* The fused single-token decode path (include/gten_hip.h) is used by
+ * gten_host_model_logits / _greedy whenever exactly one new row is requested;
+ * this switch forces the operator-by-operator path instead (on = 0). */
+int gten_host_model_set_fast_decode(gten_host_model* m, int on);
+
+/* Throughput-oriented decode: upload token ids once (teacher forcing), then
+ * queue steps without waiting.  Step n embeds tokens[n-1], attends over rows
+ * [0, n) of the caches and leaves logits + argmax on the device. */
+int gten_host_model_decode_begin(gten_host_model* m, const int32_t* tokens, int count);
+int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph);          /* asynchronous */
+int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out);  /* waits */
+
 /* synthetic weight tensor `idx` of a model with config `cfg`, in storage layout */
 int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes);
 /* the same weights as a .gten file (tinyllama_to_gten.py:94-201 layout) */

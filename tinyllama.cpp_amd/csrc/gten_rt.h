@@ -48,6 +48,7 @@ enum {
 };
 
 namespace gtr {
+bool prof_on();
 void prof_before(int tag);
 void prof_after(int tag);
 }

@@ -60,6 +60,8 @@ static std::vector<int> g_ev_tag;
 static size_t g_ev_used = 0;
 static const size_t kMaxPairs = 1 << 16;
 
+bool prof_on() { return g_prof_on; }
+
 void prof_before(int tag)
 {
     if (!g_prof_on || g_ev_used >= kMaxPairs) return;

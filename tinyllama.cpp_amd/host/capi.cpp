@@ -105,6 +105,33 @@ int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, in
     return total;
 }
 
+int gten_host_model_set_fast_decode(gten_host_model* m, int on)
+{
+    m->model->set_fast_decode(on != 0);
+    return 0;
+}
+
+int gten_host_model_decode_begin(gten_host_model* m, const int32_t* tokens, int count)
+{
+    if (!tokens || count <= 0 || count > m->cfg.max_ctx) return -1;
+    m->model->decode_set_tokens(tokens, 0, count);
+    return 0;
+}
+
+int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph)
+{
+    if (n < 1 || n > m->cfg.max_ctx) return -1;
+    m->model->decode_step(n, use_graph != 0);
+    return 0;
+}
+
+int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out)
+{
+    if (!argmax_out) return -1;
+    *argmax_out = m->model->decode_result(n);
+    return 0;
+}
+
 int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes)
 {
     std::vector<float> scratch;

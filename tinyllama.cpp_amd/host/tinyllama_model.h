@@ -57,11 +57,50 @@ public:
             std::cerr << "Number of prompt tokens (" << tokens.numel() << ") exceed provided maximum ctx size (" << n_ctx_ << ")\n";
             std::exit(EXIT_FAILURE);
         }
+        // one new row: the fused decode path (same bytes, 6 launches per block)
+        if (fast_decode_ && tokens.numel() - start_pos == 1 && tokens.is_host_external()) {
+            const int n = tokens.numel();
+            const int32_t* ids = static_cast<const int32_t*>(tokens.host_external_ptr());
+            decode_set_tokens(ids + (n - 1), n - 1, 1);
+            decode_step(n, /*use_graph=*/true);
+            return lm_head_.acv;
+        }
         Tensor x = tok_emb_.forward(tokens, start_pos);
         for (auto& block : blocks_) x = block.forward(x, start_pos);
         x = norm_.forward(x, start_pos);
         return lm_head_.forward(x);
     }
+
+    // ---- single-token decode fast path (include/gten_hip.h, "decode fast path")
+    void set_fast_decode(bool on) { fast_decode_ = on; }
+    bool fast_decode() const { return fast_decode_; }
+
+    // token ids for positions [first, first+count) of the sequence being decoded
+    void decode_set_tokens(const int32_t* ids, int first, int count)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_set_tokens(dec_, ids, first, count));
+    }
+    // asynchronous: row n-1 -> logits (lm_head_.acv, in HBM) and their argmax
+    void decode_step(int n, bool use_graph)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
+    }
+    int decode_result(int n)
+    {
+        ensure_decoder();
+        int32_t tok = -1;
+        GTEN_HIP_OK(gten_hip_decoder_result(dec_, n, &tok));
+        return tok;
+    }
+
+    ~TinyLlama()
+    {
+        if (dec_) gten_hip_decoder_destroy(dec_);
+    }
+    TinyLlama(const TinyLlama&) = delete;
+    TinyLlama& operator=(const TinyLlama&) = delete;
 
     int n_weights() const { return 1 + 9 * params.n_layers + 2; }
 
@@ -182,6 +221,41 @@ private:
     RMSNorm norm_;
     EmbeddingLinear lm_head_;
     std::vector<AttentionBlock> blocks_;
+    gten_hip_decoder* dec_ = nullptr;
+    bool fast_decode_ = [] { const char* e = std::getenv("GTEN_HIP_FAST_DECODE"); return !(e && e[0] == '0'); }();
+
+    // The decoder works on the SAME HBM tensors the modules own: weights (packed
+    // at load), the K/V caches (= attn.key.acv / attn.value.acv) and the logits
+    // buffer (= lm_head_.acv); it only adds small per-step scratch of its own.
+    void ensure_decoder()
+    {
+        if (dec_) return;
+        gten_hip_decoder_desc d{};
+        d.n_vocab = params.n_vocab; d.max_ctx = n_ctx_; d.n_embd = params.n_embd; d.n_ffn = params.n_ffn;
+        d.n_layers = params.n_layers; d.n_heads = params.n_heads; d.n_kv_heads = params.n_query_groups;
+        d.wdtype = dtype_code(dtype_.wdtype); d.adtype = dtype_code(dtype_.adtype);
+        d.embed = tok_emb_.weight.device_weight();
+        d.final_norm = norm_.weight.device_weight();
+        d.lm_head = lm_head_.weight.device_weight();
+        d.logits = static_cast<float*>(lm_head_.acv.device_ptr_mut());
+        std::vector<gten_hip_layer_ptrs> L((size_t)params.n_layers);
+        for (int i = 0; i < params.n_layers; i++) {
+            AttentionBlock& b = blocks_[(size_t)i];
+            gten_hip_layer_ptrs& p = L[(size_t)i];
+            p.wq = b.attn.query.weight.device_weight();
+            p.wk = b.attn.key.weight.device_weight();
+            p.wv = b.attn.value.weight.device_weight();
+            p.wo = b.attn.qkv_proj.weight.device_weight();
+            p.wgate = b.ffn_gate_proj.weight.device_weight();
+            p.wup = b.ffn_up_proj.weight.device_weight();
+            p.wdown = b.ffn_down_proj.weight.device_weight();
+            p.attn_norm = b.attn_norm.weight.device_weight();
+            p.ffn_norm = b.ffn_norm.weight.device_weight();
+            p.kcache = b.attn.key.acv.device_ptr_mut();
+            p.vcache = b.attn.value.acv.device_ptr_mut();
+        }
+        GTEN_HIP_OK(gten_hip_decoder_create(&d, L.data(), &dec_));
+    }
 
 public:
     int64_t load_time = 0;

@@ -35,6 +35,8 @@ class GtenHost:
         "gten_host_model_weight_bytes", "gten_host_model_set_weight", "gten_host_model_load_gten",
         "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy",
         "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
+        "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
+        "gten_host_model_decode_result",
     ]
 
     def __init__(self, path=None):
@@ -55,6 +57,10 @@ class GtenHost:
         self._loads = _sig(L, "gten_host_model_load_synthetic", ci, [vp, C.c_uint64])
         self._logits = _sig(L, "gten_host_model_logits", ci, [vp, vp, ci, ci, vp])
         self._greedy = _sig(L, "gten_host_model_greedy", ci, [vp, vp, ci, ci, ci])
+        self._setfast = _sig(L, "gten_host_model_set_fast_decode", ci, [vp, ci])
+        self._dbegin = _sig(L, "gten_host_model_decode_begin", ci, [vp, vp, ci])
+        self._dstep = _sig(L, "gten_host_model_decode_step", ci, [vp, ci, ci])
+        self._dresult = _sig(L, "gten_host_model_decode_result", ci, [vp, ci, C.POINTER(C.c_int32)])
         self._synthw = _sig(L, "gten_host_synth_weight", ci, [cfgp, C.c_uint64, ci, vp, sz])
         self._writeg = _sig(L, "gten_host_write_gten", ci, [cfgp, C.c_uint64, C.c_char_p])
         self._stoks = _sig(L, "gten_host_synthetic_tokens", None, [vp, ci, C.c_uint32, ci])
@@ -126,6 +132,27 @@ class HostModel:
         if rc:
             raise GtenHipError(f"logits rc={rc}")
         return out
+
+    def set_fast_decode(self, on):
+        self.host._setfast(self.h, 1 if on else 0)
+
+    def decode_begin(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        rc = self.host._dbegin(self.h, tokens.ctypes.data_as(C.c_void_p), len(tokens))
+        if rc:
+            raise GtenHipError(f"decode_begin rc={rc}")
+
+    def decode_step(self, n, use_graph=True):
+        rc = self.host._dstep(self.h, n, 1 if use_graph else 0)
+        if rc:
+            raise GtenHipError(f"decode_step({n}) rc={rc}")
+
+    def decode_result(self, n):
+        out = C.c_int32(-1)
+        rc = self.host._dresult(self.h, n, C.byref(out))
+        if rc:
+            raise GtenHipError(f"decode_result({n}) rc={rc}")
+        return out.value
 
     def greedy(self, prompt, max_tokens, eos=-1):
         buf = np.zeros(max_tokens, np.int32)
