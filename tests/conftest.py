@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The checker libraries use OpenMP over output features like the reference
+# (gten/ops.h:635-637); on a many-core GPU host hundreds of threads on tiny test
+# matrices cost far more than they give, so bound them before libgomp loads.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

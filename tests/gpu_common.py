@@ -13,6 +13,7 @@ from __graft_entry__ import load_package  # noqa: E402
 @pytest.fixture(scope="session")
 def hip():
     pkg = load_package()
+    pkg.build.build_all()               # no-op when the in-tree .so files are newer than their sources
     api = pkg.hipabi.load()
     if api.device_count() < 1:
         pytest.fail("no GPU visible: the gten_hip path has no CPU fallback")

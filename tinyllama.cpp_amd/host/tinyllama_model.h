@@ -63,6 +63,7 @@ public:
             const int32_t* ids = static_cast<const int32_t*>(tokens.host_external_ptr());
             decode_set_tokens(ids + (n - 1), n - 1, 1);
             decode_step(n, /*use_graph=*/true);
+            (void)lm_head_.acv.device_ptr_mut();      // the step wrote the logits in HBM: host mirror is stale
             return lm_head_.acv;
         }
         Tensor x = tok_emb_.forward(tokens, start_pos);
