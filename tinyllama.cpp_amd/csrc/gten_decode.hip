@@ -70,9 +70,7 @@ __device__ __forceinline__ void finish_stage(ActStage s, int adtype, int d)
 // RMSNorm of s.row in place (gten/ops.h:762-778)
 __device__ __forceinline__ void rms_norm_row(ActStage s, const uint16_t* __restrict__ w, int d)
 {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < d; i += blockDim.x) ss += s.row[i] * s.row[i];
-    ss = block_sum(ss, s.red);
+    const float ss = block_sum(row_sumsq8(s.row, d), s.red);
     const float rms = sqrtf(ss / (float)d);
     for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = s.row[i] / (rms + 1e-6f) * h2f(w[i]);
 }
@@ -208,6 +206,266 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const GemvArgs a)
         while (lr >= a.m[k].rows) { lr -= a.m[k].rows; k++; }
         const float v = dec_dot<WT>(a.m[k].w, a.m[k].rows, d, lr, s);
         if (lane == 0) a.out[r] = v;
+    }
+}
+
+// -------------------------------------------- GEMV kernels, Q8 activations
+//
+// The q8/q4 configurations' W.x kernel.  Differences from k_dec_gemv above are
+// organisational only (same values, same rounding points):
+//   * the wave's weight rows are requested from HBM FIRST, then the prologue
+//     runs while they are in flight (hipcc's __syncthreads() here is
+//     lgkmcnt(0)+s_barrier, so the loads stay outstanding across it);
+//   * the prologue keeps 8 consecutive elements per thread in registers, so a
+//     Q8 block is one quad of lanes and its absmax / sum are two DPP steps;
+//   * the residual rows between kernels are kept as f32 (exact storage values).
+
+struct Gemv8Args {
+    const DecStep* step;
+    const uint8_t* qs[3];         // per matrix: packed quants
+    const uint16_t* ds[3];        // per matrix: deltas
+    int rows[3];
+    int n_mats;
+    int d_in;                     // multiple of 32
+    float* out;
+    // prologue inputs
+    const void* table; int n_vocab; const int32_t* tokens;     // PRO_EMBED
+    const float* res_a; const float* res_raw;                   // PRO_RESID (f32 rows)
+    float* x_out;                                               // PRO_EMBED/PRO_RESID: new residual row, f32
+    const uint16_t* norm_w;
+    const float* att_part; int d_head, n_chunks;                // PRO_ATT
+    const float* gate_raw; const float* up_raw;                 // PRO_SILUMUL
+};
+
+// write_row_from_float + read_row_to_float of one Q8 block spread over a quad
+// (8 elements per lane): v <- q * fp16(delta)   (gten/quants.h:52-76)
+__device__ __forceinline__ void q8_round8(float (&v)[8])
+{
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(v[i]));
+    const Q8Scale s = q8_scale_from_absmax(quad_max(amax));
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (float)q8_round(v[i], s.scale) * s.ddeq;
+}
+
+// quantize the quad's block and stage it for the dot products
+__device__ __forceinline__ void q8_stage8(const float (&v)[8], int b, int sub, ActQ8 a)
+{
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(v[i]));
+    const Q8Scale s = q8_scale_from_absmax(quad_max(amax));
+    int q[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { q[i] = q8_round(v[i], s.scale); sum += q[i]; }
+    int2 pk;
+    pk.x = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
+    pk.y = (q[4] & 0xff) | ((q[5] & 0xff) << 8) | ((q[6] & 0xff) << 16) | ((q[7] & 0xff) << 24);
+    *(int2*)(a.q + (size_t)b * 32 + sub * 8) = pk;
+    sum = quad_sum_i(sum);
+    if (sub == 0) { a.d[b] = s.ddeq; a.sum[b] = sum; }
+}
+
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8])
+{
+    const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8])
+{
+    ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <int WT, int PRO, int NCH, int R>
+__global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
+{
+    constexpr int NP = NCH;                       // prologue passes of 2048 elements (d <= NP * 2048)
+    const int d = a.d_in, nb = d >> 5;
+    ActStage s = carve_stage(d);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = a.step->n;
+
+    // ---- 1. request the prologue's inputs (they come back first: vmcnt is in order)
+    float pin0[NP][8], pin1[NP][8];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        // lanes past the end re-read group 0 (never used): an unconditional load has
+        // no select on its result, so nothing has to wait for it here
+        const int gi = threadIdx.x + p * 256, base = (gi * 8 < d) ? gi * 8 : 0;
+        if (PRO == PRO_RESID) { ld8(a.res_raw + base, pin0[p]); ld8(a.res_a + base, pin1[p]); }
+        else if (PRO == PRO_SILUMUL) { ld8(a.gate_raw + base, pin0[p]); ld8(a.up_raw + base, pin1[p]); }
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { pin0[p][i] = 0.f; pin1[p][i] = 0.f; }
+        }
+    }
+    uint4 nw8[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int gi = threadIdx.x + p * 256, base = (gi * 8 < d) ? gi * 8 : 0;
+        nw8[p] = make_uint4(0, 0, 0, 0);
+        if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) nw8[p] = *(const uint4*)(a.norm_w + base);
+    }
+    uint2 emb_bytes = make_uint2(0, 0);
+    float emb_delta = 0.f;
+    if (PRO == PRO_EMBED) {
+        const int tok = a.tokens[n - 1];
+        const int gsafe = (threadIdx.x * 8 < d) ? threadIdx.x : 0;
+        const int b = gsafe >> 2, sub = gsafe & 3;
+        if (WT == GTEN_Q4) {
+            emb_bytes = *(const uint2*)((const uint8_t*)a.table + ((size_t)tok * nb + b) * 16 + (sub & 1) * 8);
+            emb_delta = h2f(((const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 16))[(size_t)tok * nb + b]);
+        } else {
+            emb_bytes = *(const uint2*)((const uint8_t*)a.table + (size_t)tok * nb * 32 + (size_t)(sub >> 1) * nb * 16 + (size_t)b * 16 + (sub & 1) * 8);
+            emb_delta = h2f(((const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 32))[(size_t)tok * nb + b]);
+        }
+    }
+
+    // ---- 2. request this wave's weight rows; they stay in flight during the prologue
+    const int rows0 = a.rows[0], rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
+    const int total = rows0 + rows1 + rows2;
+    const int r0 = (blockIdx.x * 4 + wid) * R;
+    uint4 wq[R][NCH], wq1[R][NCH];
+    uint16_t wd[R][NCH];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        int lr = r0 + j;
+        const bool ok = lr < total;
+        const uint8_t* qbase = a.qs[0];
+        const uint16_t* dbase = a.ds[0];
+        if (lr >= rows0 && rows1 > 0) {
+            lr -= rows0; qbase = a.qs[1]; dbase = a.ds[1];
+            if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; }
+        }
+        if (!ok) lr = 0;                          // clamp: always a valid row, result discarded
+        const uint16_t* drow = dbase + (size_t)lr * nb;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            // out-of-range K blocks read block 0 (finite data) and are zeroed through
+            // the activation scale below: no select on loaded data, so nothing waits here
+            const int b = (c * 64 + lane < nb) ? c * 64 + lane : 0;
+            if (WT == GTEN_Q4) {
+                wq[j][c] = ((const uint4*)(qbase + (size_t)lr * nb * 16))[b];
+            } else {
+                const uint4* q0 = (const uint4*)(qbase + (size_t)lr * nb * 32);
+                wq[j][c] = q0[b];
+                wq1[j][c] = q0[nb + b];
+            }
+            wd[j][c] = drow[b];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);            // keep every request above ahead of the prologue's arithmetic
+
+    // ---- 3. prologue: the element-wise chain of the reference, on chip
+    float ss = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int gi = threadIdx.x + p * 256, base = gi * 8, b = gi >> 2, sub = gi & 3;
+        if (base < d) {
+            float v[8];
+            if (PRO == PRO_EMBED) {
+                // high nibbles are elements 0..15, low nibbles 16..31 (gten/quants.h:78-90)
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const unsigned w = (i < 4) ? emb_bytes.x : emb_bytes.y;
+                    const unsigned byte = (w >> ((i & 3) * 8)) & 0xffu;
+                    if (WT == GTEN_Q4) v[i] = (float)(((sub < 2) ? (int)(byte >> 4) : (int)(byte & 0x0fu)) - 7) * emb_delta;
+                    else v[i] = (float)(int)(int8_t)byte * emb_delta;      // block copied verbatim (gten/ops.h:519-521)
+                }
+                if (WT == GTEN_Q4) q8_round8(v);          // Q4 row is re-quantized to Q8 (gten/ops.h:522-528)
+            } else if (PRO == PRO_RESID) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = pin0[p][i];
+                q8_round8(v);                             // Linear output written as Q8
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = pin1[p][i] + v[i];
+                q8_round8(v);                             // Residual output written as Q8
+            } else if (PRO == PRO_ATT) {
+                const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+                const int h = base / a.d_head, e = base % a.d_head;
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = 0.f;
+                for (int j = 0; j < nch; j++) {
+                    float t[8];
+                    ld8(a.att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] += t[i];
+                }
+            } else {
+                float u[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { v[i] = pin0[p][i]; u[i] = pin1[p][i]; }
+                q8_round8(v);                             // gate written as Q8
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = v[i] / (1.0f + expf(-v[i]));
+                q8_round8(v);                             // silu in place, written as Q8
+                q8_round8(u);                             // up written as Q8
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = v[i] * u[i];
+            }
+            if (PRO == PRO_EMBED || PRO == PRO_RESID) {
+                if (a.x_out && blockIdx.x == 0) st8(a.x_out + base, v);
+                if (a.norm_w) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ss += v[i] * v[i];
+                    st8(s.row + base, v);
+                } else {
+                    q8_stage8(v, b, sub, s.q8);
+                }
+            } else {
+                q8_stage8(v, b, sub, s.q8);
+            }
+        }
+    }
+    if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
+        // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
+        ss = block_sum(ss, s.red);
+        const float rms = sqrtf(ss / (float)d);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int gi = threadIdx.x + p * 256, base = gi * 8;
+            if (base < d) {
+                float v[8];
+                ld8(s.row + base, v);
+                const unsigned wu[4] = {nw8[p].x, nw8[p].y, nw8[p].z, nw8[p].w};
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint16_t hw = (uint16_t)((i & 1) ? (wu[i >> 1] >> 16) : (wu[i >> 1] & 0xffffu));
+                    v[i] = v[i] / (rms + 1e-6f) * h2f(hw);
+                }
+                q8_stage8(v, gi >> 2, gi & 3, s.q8);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. this lane's activation blocks, then the dot products
+    int av[NCH][8], asum[NCH];
+    float ad[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int b = c * 64 + lane;
+        const bool in = b < nb;
+        const int4* ap = (const int4*)(s.q8.q + (size_t)(in ? b : 0) * 32);
+        const int4 a0 = ap[0], a1 = ap[1];
+        av[c][0] = a0.x; av[c][1] = a0.y; av[c][2] = a0.z; av[c][3] = a0.w;
+        av[c][4] = a1.x; av[c][5] = a1.y; av[c][6] = a1.z; av[c][7] = a1.w;
+        ad[c] = in ? s.q8.d[b] : 0.f;
+        asum[c] = in ? s.q8.sum[b] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int isum = (WT == GTEN_Q4) ? dot_q8_q4_block(av[c], asum[c], wq[j][c])
+                                             : dot_q8_q8_block(av[c], wq[j][c], wq1[j][c]);
+            acc += (float)isum * (ad[c] * h2f(wd[j][c]));
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && r0 + j < total) a.out[r0 + j] = acc;
     }
 }
 
@@ -418,6 +676,189 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv(const AttnArgs a)
     }
 }
 
+// ---- d_head = 64 specialisations of the two attention passes (TinyLlama's shape)
+//
+// Same arithmetic as the generic kernels above; what changes is how the cache
+// rows travel: every thread requests all of its K (or V) bytes with plain
+// dword loads up front (a kv-head slice is 68 bytes = 17 dwords in Q8, 128
+// bytes in f16, always 4-byte aligned), so a pass costs one memory latency
+// instead of one per cached row.
+
+template <int ADT>
+__global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a)
+{
+    constexpr int dh = 64, nblk = 2;
+    constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
+    const int n = a.step->n, pos = n - 1;
+    const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= n) return;
+    const int grp = a.n_heads / a.n_kv, g = h / grp;
+    const int kv_dim = a.n_kv * dh;
+    const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
+
+    float* red = (float*)g_smem;                 // 16
+    float* qf = red + 16 + dh;                   // dh
+    float* kf = qf + dh;                         // dh
+    float* qd = kf + dh;                         // 8
+    float* kd = qd + 8;                          // 8
+    uint16_t* d16 = (uint16_t*)(kd + 8);         // 16 halves
+    int8_t* qi8 = (int8_t*)(d16 + 16);           // dh
+    int8_t* ki8 = qi8 + dh;                      // dh
+    int8_t* vi8 = ki8 + dh;                      // dh
+
+    // ---- request this thread's cached K row (rows past n re-read row c0; unused)
+    const int c = c0 + threadIdx.x;
+    const int cs = (c < n && c != pos) ? c : c0;
+    const unsigned* kp = (const unsigned*)(a.kcache + (size_t)cs * a.kv_pitch + (size_t)g * head_bytes);
+    unsigned kw[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) kw[j] = kp[j];
+    __builtin_amdgcn_sched_barrier(0);
+
+    const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
+    const bool writer = has_new && (h % grp == 0);
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        float v = head_prep(a.qkv_raw[h * dh + t], true, true, pos, dh, ADT, a.rope, qi8, qd, d16);
+        qf[t] = v;
+        if (has_new) {
+            v = head_prep(a.qkv_raw[a.n_embd + g * dh + t], true, true, pos, dh, ADT, a.rope, ki8, kd, d16 + 4);
+            kf[t] = v;
+            if (writer) {
+                uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+                if (ADT == GTEN_Q8) {
+                    uint8_t* blk = krow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                    blk[2 + (t & 31)] = (uint8_t)ki8[t];
+                    if ((t & 31) == 0) *(uint16_t*)blk = d16[4 + (t >> 5)];
+                } else {
+                    ((uint16_t*)krow)[t] = f2h(v);
+                }
+                v = head_prep(a.qkv_raw[a.n_embd + kv_dim + g * dh + t], true, false, pos, dh, ADT, a.rope, vi8, kd + 4, d16 + 8);
+                uint8_t* vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+                if (ADT == GTEN_Q8) {
+                    uint8_t* blk = vrow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                    blk[2 + (t & 31)] = (uint8_t)vi8[t];
+                    if ((t & 31) == 0) *(uint16_t*)blk = d16[8 + (t >> 5)];
+                } else {
+                    ((uint16_t*)vrow)[t] = f2h(v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const float scale = 1.0f / sqrtf((float)dh);
+    float sc = -INFINITY;
+    if (c < n) {
+        float acc = 0.f;
+        if (ADT == GTEN_Q8) {
+            const int* qi = (const int*)qi8;
+            if (c == pos) {
+                const int* ki = (const int*)ki8;
+#pragma unroll
+                for (int b = 0; b < nblk; b++) {
+                    int isum = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) isum = dot4(qi[b * 8 + j], ki[b * 8 + j], isum);
+                    acc += (float)isum * (qd[b] * kd[b]);
+                }
+            } else {
+                // slice bytes: [d0 | q0 x32 | d1 | q1 x32]; q0 straddles dwords by 2 bytes
+                int isum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) isum = dot4(qi[j], (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16), isum);
+                acc += (float)isum * (qd[0] * h2f((uint16_t)(kw[0] & 0xffffu)));
+                isum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) isum = dot4(qi[8 + j], (int)kw[9 + j], isum);
+                acc += (float)isum * (qd[1] * h2f((uint16_t)(kw[8] >> 16)));
+            }
+        } else {
+            if (c == pos) {
+                for (int e = 0; e < dh; e++) acc += qf[e] * kf[e];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    acc += qf[2 * j] * h2f((uint16_t)(kw[j] & 0xffffu));
+                    acc += qf[2 * j + 1] * h2f((uint16_t)(kw[j] >> 16));
+                }
+            }
+        }
+        sc = acc * scale;
+        a.scores[(size_t)h * a.max_ctx + c] = sc;
+    }
+    const float mx = block_max(sc, red);
+    const float ex = (c < n) ? expf(sc - mx) : 0.f;
+    const float sm = block_sum(ex, red);
+    if (threadIdx.x == 0) {
+        a.stats[((size_t)h * a.n_chunks + chunk) * 2 + 0] = mx;
+        a.stats[((size_t)h * a.n_chunks + chunk) * 2 + 1] = sm;
+    }
+}
+
+template <int ADT>
+__global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a)
+{
+    constexpr int dh = 64;
+    constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
+    const int n = a.step->n;
+    const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= n) return;
+    const int grp = a.n_heads / a.n_kv, g = h / grp;
+    const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)2 * GTEN_Q8_BYTES : (size_t)dh * 2;
+    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+    const int len = min(DEC_CHUNK, n - c0);
+
+    float* p = (float*)g_smem;                   // 256
+    float* part = p + DEC_CHUNK;                 // 256
+    unsigned* vl = (unsigned*)(part + DEC_CHUNK);// DEC_CHUNK * NW dwords: the chunk's V slices, row-major
+
+    // ---- request the whole V chunk: dword idx -> (row idx / NW, word idx % NW)
+    unsigned vw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int idx = threadIdx.x + k * 256;
+        int row = idx / NW;
+        const int w = idx - row * NW;
+        if (row >= len) row = 0;
+        vw[k] = ((const unsigned*)(a.vcache + (size_t)(c0 + row) * a.kv_pitch + (size_t)g * head_bytes))[w];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float M = -INFINITY;
+    for (int j = 0; j < nch; j++) M = fmaxf(M, a.stats[((size_t)h * a.n_chunks + j) * 2]);
+    float S = 0.f;
+    for (int j = 0; j < nch; j++)
+        S += a.stats[((size_t)h * a.n_chunks + j) * 2 + 1] * expf(a.stats[((size_t)h * a.n_chunks + j) * 2] - M);
+
+    const int c = c0 + threadIdx.x;
+    p[threadIdx.x] = (c < n) ? expf(a.scores[(size_t)h * a.max_ctx + c] - M) / S : 0.f;
+    round_row_inplace(p, ADT, len);
+#pragma unroll
+    for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
+    __syncthreads();
+
+    const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const uint8_t* vb = (const uint8_t*)vl;
+    float acc = 0.f;
+    if (ADT == GTEN_Q8) {
+        const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+        for (int cl = cg; cl < len; cl += 4) {
+            const uint8_t* row = vb + (size_t)cl * 68;
+            acc += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
+        }
+    } else {
+        for (int cl = cg; cl < len; cl += 4) acc += p[cl] * h2f(((const uint16_t*)(vb + (size_t)cl * 128))[e]);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < dh) {
+        float o = 0.f;
+        for (int gi = 0; gi < 4; gi++) o += part[gi * dh + threadIdx.x];
+        a.att_part[((size_t)h * a.n_chunks + chunk) * dh + threadIdx.x] = o;
+    }
+}
+
 // greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424)
 __global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ logits, int n_vocab, DecStep* step,
                                                      int32_t* __restrict__ result)
@@ -477,6 +918,97 @@ static int launch_gemv(int tag, const GemvArgs& a, int total_rows)
     return 0;
 }
 
+static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
+{
+    if (t.d_head == 64) {
+        const size_t nw = (t.adtype == GTEN_Q8) ? 17 : 32;
+        const size_t smem2 = (size_t)2 * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * nw * 4;
+        if (t.adtype == GTEN_Q8) {
+            GTR_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_Q8>), agrid, dim3(256), smem1, t);
+            GTR_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_Q8>), agrid, dim3(256), smem2, t);
+        } else {
+            GTR_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_F16>), agrid, dim3(256), smem1, t);
+            GTR_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_F16>), agrid, dim3(256), smem2, t);
+        }
+        return 0;
+    }
+    GTR_LAUNCH(KT_DEC_ATTN_SCORE, k_dec_attn_score, agrid, dim3(256), smem1, t);
+    GTR_LAUNCH(KT_DEC_ATTN_PV, k_dec_attn_pv, agrid, dim3(256), (size_t)2 * DEC_CHUNK * 4, t);
+    return 0;
+}
+
+template <int WT, int PRO, int NCH, int R>
+static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
+{
+    const dim3 grid((total_rows + 4 * R - 1) / (4 * R)), block(256);
+    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R>), grid, block, stage_bytes(a.d_in), a);
+    return 0;
+}
+
+static void set_mat(Gemv8Args& a, int k, const void* w, int wdtype, int rows, int cols)
+{
+    const size_t nb = (size_t)cols / 32;
+    a.qs[k] = (const uint8_t*)w;
+    a.ds[k] = (const uint16_t*)((const uint8_t*)w + (size_t)rows * nb * (wdtype == GTEN_Q4 ? 16 : 32));
+    a.rows[k] = rows;
+}
+
+// Q8-activation configurations (q8, q4): the register-prologue kernels
+template <int WT>
+static int enqueue_step_q8act(gten_hip_decoder* dc)
+{
+    const gten_hip_decoder_desc& d = dc->d;
+    const int E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads;
+    const size_t kv_pitch = gten_hip_row_bytes(d.adtype, KV);
+    const bool wideF = F > 2048;                  // blocks per row beyond one wave's 64 lanes
+    float* xbuf = (float*)dc->xbuf;
+    float* hbuf = (float*)dc->hbuf;
+    int rc;
+    for (int l = 0; l < d.n_layers; l++) {
+        const gten_hip_layer_ptrs& L = dc->layers[l];
+        Gemv8Args a{};
+        a.step = dc->step; a.d_in = E; a.n_mats = 3;
+        set_mat(a, 0, L.wq, WT, E, E); set_mat(a, 1, L.wk, WT, KV, E); set_mat(a, 2, L.wv, WT, KV, E);
+        a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = xbuf;
+        if (l == 0) {
+            a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
+            rc = launch_gemv8<WT, PRO_EMBED, 1, 2>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
+        } else {
+            a.res_a = hbuf; a.res_raw = dc->down_raw;
+            rc = launch_gemv8<WT, PRO_RESID, 1, 2>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
+        }
+        if (rc) return rc;
+        AttnArgs t{};
+        t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kcache = (uint8_t*)L.kcache; t.vcache = (uint8_t*)L.vcache;
+        t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats; t.att_part = dc->att_part; t.rope = dc->rope;
+        t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
+        t.n_chunks = dc->n_chunks; t.n_embd = E;
+        const dim3 agrid(d.n_heads, dc->n_chunks);
+        const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
+        if (int arc = launch_attention(t, agrid, smem1)) return arc;
+        Gemv8Args o{};
+        o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
+        o.att_part = dc->att_part; o.d_head = dh; o.n_chunks = dc->n_chunks;
+        if ((rc = launch_gemv8<WT, PRO_ATT, 1, 2>(KT_DEC_GEMV_O, o, E))) return rc;
+        Gemv8Args gu{};
+        gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
+        gu.out = dc->gu_raw; gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
+        if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8>(KT_DEC_GEMV_GATEUP, gu, 2 * F))) return rc;
+        Gemv8Args dn{};
+        dn.step = dc->step; dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw;
+        dn.gate_raw = dc->gu_raw; dn.up_raw = dc->gu_raw + F;
+        rc = wideF ? launch_gemv8<WT, PRO_SILUMUL, 3, 2>(KT_DEC_GEMV_DOWN, dn, E)
+                   : launch_gemv8<WT, PRO_SILUMUL, 1, 2>(KT_DEC_GEMV_DOWN, dn, E);
+        if (rc) return rc;
+    }
+    Gemv8Args hd{};
+    hd.step = dc->step; hd.d_in = E; hd.n_mats = 1; set_mat(hd, 0, d.lm_head, WT, d.n_vocab, E); hd.out = d.logits;
+    hd.res_a = hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
+    if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
+    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)d.logits, d.n_vocab, dc->step, dc->result);
+    return 0;
+}
+
 template <int WT>
 static int enqueue_step(gten_hip_decoder* dc)
 {
@@ -508,8 +1040,7 @@ static int enqueue_step(gten_hip_decoder* dc)
         t.n_chunks = dc->n_chunks; t.n_embd = E;
         const dim3 agrid(d.n_heads, dc->n_chunks);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        GTR_LAUNCH(KT_DEC_ATTN_SCORE, k_dec_attn_score, agrid, dim3(256), smem1, t);
-        GTR_LAUNCH(KT_DEC_ATTN_PV, k_dec_attn_pv, agrid, dim3(256), (size_t)2 * DEC_CHUNK * 4, t);
+        if (int arc = launch_attention(t, agrid, smem1)) return arc;
         // ---- output projection of the attention row
         GemvArgs o{};
         o.step = dc->step; o.adtype = d.adtype; o.d_in = E; o.m[0] = {L.wo, E}; o.n_mats = 1; o.out = dc->proj_raw;
@@ -542,8 +1073,8 @@ static int enqueue(gten_hip_decoder* dc)
 {
     switch (dc->d.wdtype) {
     case GTEN_F16: return enqueue_step<GTEN_F16>(dc);
-    case GTEN_Q8: return enqueue_step<GTEN_Q8>(dc);
-    case GTEN_Q4: return enqueue_step<GTEN_Q4>(dc);
+    case GTEN_Q8: return enqueue_step_q8act<GTEN_Q8>(dc);
+    case GTEN_Q4: return enqueue_step_q8act<GTEN_Q4>(dc);
     }
     return fail(-4, "decoder: bad weight dtype %d", dc->d.wdtype);
 }
@@ -559,7 +1090,7 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
     GTR_REQUIRE(d.n_embd % d.n_heads == 0, "decoder_create: n_embd %% n_heads != 0");
     const int dh = d.n_embd / d.n_heads;
     GTR_REQUIRE(dh == 32 || dh == 64, "decoder_create: fast path supports d_head 32 or 64 (got %d)", dh);
-    GTR_REQUIRE(d.n_embd % 32 == 0 && d.n_ffn % 32 == 0 && d.n_embd <= 8192 && d.n_ffn <= 12288, "decoder_create: unsupported widths");
+    GTR_REQUIRE(d.n_embd % 32 == 0 && d.n_ffn % 32 == 0 && d.n_embd <= 2048 && d.n_ffn <= 6144, "decoder_create: unsupported widths (n_embd <= 2048, n_ffn <= 6144)");
     GTR_REQUIRE(d.max_ctx > 0 && d.max_ctx <= GTEN_ROPE_MAX_POS, "decoder_create: max_ctx %d beyond the RoPE table", d.max_ctx);
     const bool pair_ok = (d.wdtype == GTEN_F16 && d.adtype == GTEN_F16) || ((d.wdtype == GTEN_Q8 || d.wdtype == GTEN_Q4) && d.adtype == GTEN_Q8);
     GTR_REQUIRE(pair_ok, "decoder_create: unsupported dtype pair (%d,%d) (tinyllama.cpp:258-265)", d.wdtype, d.adtype);
@@ -582,8 +1113,9 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
     GTR_CHECK(hipMalloc((void**)&dc->scores, (size_t)d.n_heads * d.max_ctx * 4));
     GTR_CHECK(hipMalloc((void**)&dc->stats, (size_t)d.n_heads * dc->n_chunks * 2 * 4));
     GTR_CHECK(hipMalloc((void**)&dc->att_part, (size_t)d.n_heads * dc->n_chunks * dh * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->xbuf, gten_hip_row_bytes(d.adtype, E)));
-    GTR_CHECK(hipMalloc((void**)&dc->hbuf, gten_hip_row_bytes(d.adtype, E)));
+    // residual rows between kernels: f32 (exact storage values) for Q8 activations, f16 rows otherwise
+    GTR_CHECK(hipMalloc((void**)&dc->xbuf, (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->hbuf, (size_t)E * 4));
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
     *out = dc;
     return 0;

@@ -32,12 +32,43 @@ __device__ __forceinline__ uint16_t f2h(float f)
     return h;
 }
 
+// ---- cross-lane moves on the DPP path (no LDS crossbar round trip) ----
+// CTRL: 0xB1 quad_perm[1,0,3,2] (xor 1) | 0x4E quad_perm[2,3,0,1] (xor 2) |
+//       0x141 row_half_mirror | 0x140 row_mirror | 0x142 row_bcast15 | 0x143 row_bcast31
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_mov_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+// max / sum over the 4 lanes of a quad (every lane gets the result)
+__device__ __forceinline__ float quad_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    return fmaxf(v, dpp_mov<0x4E>(v));
+}
+__device__ __forceinline__ int quad_sum_i(int v)
+{
+    v += dpp_mov_i<0xB1>(v);
+    return v + dpp_mov_i<0x4E>(v);
+}
+
 // ---- wavefront reductions (all 64 lanes end with the same value) ----
+// Sum of the 64 lanes in a fixed tree: quads, 8, 16 (DPP mirrors), then the
+// four 16-lane rows chained through row_bcast15/31; the total lands in lane 63.
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    v += dpp_mov<0x142, 0xA>(v);
+    v += dpp_mov<0x143, 0xC>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
@@ -82,6 +113,20 @@ __device__ __forceinline__ float block_max(float v, float* scratch)
     float t = scratch[0];
     for (int i = 1; i < nw; i++) t = fmaxf(t, scratch[i]);
     return t;
+}
+
+// Per-thread part of sum x^2 over an f32 row in LDS.  Every kernel that needs the
+// RMSNorm statistic uses THIS element->thread mapping and order (thread t owns
+// the 8 consecutive elements of groups t, t+blockDim, ...), so the operator path
+// and the fused decode path round identically.  d % 8 == 0.
+__device__ __forceinline__ float row_sumsq8(const float* row, int d)
+{
+    float ss = 0.f;
+    for (int gi = threadIdx.x; gi * 8 < d; gi += blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) ss += row[gi * 8 + i] * row[gi * 8 + i];
+    }
+    return ss;
 }
 
 // ---- Q8 activation quantizer pieces (gten/quants.h:52-66) ----

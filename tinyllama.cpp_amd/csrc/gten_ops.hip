@@ -154,9 +154,7 @@ __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x,
     const int r = start_pos + blockIdx.x;
     load_row_f32(x + (size_t)r * x_pitch, dtype, d, v);
     __syncthreads();
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < d; i += blockDim.x) ss += v[i] * v[i];
-    ss = block_sum(ss, red);
+    const float ss = block_sum(row_sumsq8(v, d), red);
     const float rms = sqrtf(ss / (float)d);
     for (int i = threadIdx.x; i < d; i += blockDim.x) v[i] = v[i] / (rms + 1e-6f) * h2f(w[i]);
     __syncthreads();
