@@ -20,6 +20,7 @@ AVX/OpenMP build from oracle/_ref when present, else the oracle port; bounded
 sample) objects.
 """
 import argparse
+import importlib
 import json
 import os
 import sys
@@ -182,27 +183,19 @@ def main():
     for i in range(W):
         step(n_of(i, total))
 
-    def barrier():
+    def sync():
         hip.sync()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
 
-    barrier()
-    t0 = time.perf_counter()
-    last = 0
-    for i in range(W, W + K):
-        last = step(n_of(i, total))
-    if fused:
-        last = model.decode_result(n_of(W + K - 1, total))     # waits for the stream
-    hip.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    def run_steps():
+        for i in range(W, W + K):
+            step(n_of(i, total))
+        return K
+
+    # barrier + synchronise on both sides of exactly K steps; MAX elapsed over ranks
+    rep = importlib.import_module(pkg.__name__ + ".replicas")
+    elapsed, total_tokens = rep.timed_region(run_steps, sync, dist=dist, device="cuda" if dist is not None else None)
+    last = model.decode_result(n_of(W + K - 1, total)) if fused else step(n_of(W + K - 1, total))
 
     # ---- roofline of the dominant kernel: HIP events on the library's stream
     roofline = None
@@ -244,7 +237,7 @@ def main():
 
     if rank != 0:
         return
-    tok_s = world * K / elapsed
+    tok_s = total_tokens / elapsed
     ms_step = elapsed / K * 1e3
     n_mid = N_CTX - K // 2 if total <= N_CTX - 1 else N_CTX - window // 2
     whole = algorithmic_bytes(args.mode, n_mid) / (ms_step * 1e-3) / 1e9

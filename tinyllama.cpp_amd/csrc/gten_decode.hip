@@ -71,8 +71,8 @@ __device__ __forceinline__ void finish_stage(ActStage s, int adtype, int d)
 __device__ __forceinline__ void rms_norm_row(ActStage s, const uint16_t* __restrict__ w, int d)
 {
     const float ss = block_sum(row_sumsq8(s.row, d), s.red);
-    const float rms = sqrtf(ss / (float)d);
-    for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = s.row[i] / (rms + 1e-6f) * h2f(w[i]);
+    const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);     // see k_rms_norm
+    for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = s.row[i] * inv * h2f(w[i]);
 }
 
 // x = embedding row of the step's token, in activation dtype (gten/ops.h:514-533)
@@ -126,7 +126,8 @@ __device__ __forceinline__ float dec_dot(const void* w, int rows, int d_in, int 
     return wave_dot_q4(pw, (size_t)r, s.q8);
 }
 
-enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_SILUMUL = 3 };
+enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_SILUMUL = 3, PRO_ACTQ8 = 4 };
+enum { EPI_RAW = 0, EPI_SILUMUL = 1 };
 
 struct GemvArgs {
     const DecStep* step;
@@ -235,6 +236,9 @@ struct Gemv8Args {
     const uint16_t* norm_w;
     const float* att_part; int d_head, n_chunks;                // PRO_ATT
     const float* gate_raw; const float* up_raw;                 // PRO_SILUMUL
+    float* best_val; int* best_idx;                             // lm_head: per-wave running argmax (may be null)
+    // EPI_SILUMUL writes / PRO_ACTQ8 reads the staged FFN activation in HBM (ActQ8 layout)
+    int8_t* act_q; float* act_d; int* act_sum;
 };
 
 // write_row_from_float + read_row_to_float of one Q8 block spread over a quad
@@ -278,8 +282,34 @@ __device__ __forceinline__ void st8(float* p, const float (&v)[8])
     ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-template <int WT, int PRO, int NCH, int R>
-__global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
+// max / integer sum over the 32 lanes of a half wave (lane = element of one Q8 block)
+__device__ __forceinline__ float max32(float v)
+{
+    v = quad_max(v);
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+__device__ __forceinline__ int sum32_i(int v)
+{
+    v = quad_sum_i(v);
+    v += dpp_mov_i<0x141>(v);
+    v += dpp_mov_i<0x140>(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+// one value per lane, the half wave is one Q8 block: v <- q * fp16(delta)
+__device__ __forceinline__ float q8_round32(float v)
+{
+    const Q8Scale s = q8_scale_from_absmax(max32(fabsf(v)));
+    return (float)q8_round(v, s.scale) * s.ddeq;
+}
+
+// EPI_RAW:     4 waves, wave w owns rows [(4*blockIdx.x + w) * R, +R) of the concatenated matrices
+// EPI_SILUMUL: 8 waves, block = one 32-wide slice of the FFN: waves 0-3 its gate rows, waves 4-7
+//              its up rows (R = 8); the slice's silu(gate)*up chain runs ONCE here, in the
+//              epilogue, and is stored quantized for the down projection (PRO_ACTQ8)
+template <int WT, int PRO, int NCH, int R, int EPI>
+__global__ __launch_bounds__(EPI == EPI_SILUMUL ? 512 : 256) void k_dec_gemv8(const Gemv8Args a)
 {
     constexpr int NP = NCH;                       // prologue passes of 2048 elements (d <= NP * 2048)
     const int d = a.d_in, nb = d >> 5;
@@ -326,7 +356,8 @@ __global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
     // ---- 2. request this wave's weight rows; they stay in flight during the prologue
     const int rows0 = a.rows[0], rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
     const int total = rows0 + rows1 + rows2;
-    const int r0 = (blockIdx.x * 4 + wid) * R;
+    const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
+                                        : (blockIdx.x * 4 + wid) * R;
     uint4 wq[R][NCH], wq1[R][NCH];
     uint16_t wd[R][NCH];
 #pragma unroll
@@ -359,6 +390,8 @@ __global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
     __builtin_amdgcn_sched_barrier(0);            // keep every request above ahead of the prologue's arithmetic
 
     // ---- 3. prologue: the element-wise chain of the reference, on chip
+    //         (PRO_ACTQ8: nothing to do, the input was staged in HBM by the producer's epilogue)
+    if (PRO != PRO_ACTQ8) {
     float ss = 0.f;
 #pragma unroll
     for (int p = 0; p < NP; p++) {
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
     if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
         // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
         ss = block_sum(ss, s.red);
-        const float rms = sqrtf(ss / (float)d);
+        const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);  // see k_rms_norm
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int gi = threadIdx.x + p * 256, base = gi * 8;
@@ -433,13 +466,14 @@ __global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const uint16_t hw = (uint16_t)((i & 1) ? (wu[i >> 1] >> 16) : (wu[i >> 1] & 0xffffu));
-                    v[i] = v[i] / (rms + 1e-6f) * h2f(hw);
+                    v[i] = v[i] * inv * h2f(hw);
                 }
                 q8_stage8(v, gi >> 2, gi & 3, s.q8);
             }
         }
     }
     __syncthreads();
+    }
 
     // ---- 4. this lane's activation blocks, then the dot products
     int av[NCH][8], asum[NCH];
@@ -448,13 +482,20 @@ __global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
     for (int c = 0; c < NCH; c++) {
         const int b = c * 64 + lane;
         const bool in = b < nb;
-        const int4* ap = (const int4*)(s.q8.q + (size_t)(in ? b : 0) * 32);
+        const int bs = in ? b : 0;
+        const int8_t* qsrc = (PRO == PRO_ACTQ8) ? a.act_q : s.q8.q;
+        const int4* ap = (const int4*)(qsrc + (size_t)bs * 32);
         const int4 a0 = ap[0], a1 = ap[1];
         av[c][0] = a0.x; av[c][1] = a0.y; av[c][2] = a0.z; av[c][3] = a0.w;
         av[c][4] = a1.x; av[c][5] = a1.y; av[c][6] = a1.z; av[c][7] = a1.w;
-        ad[c] = in ? s.q8.d[b] : 0.f;
-        asum[c] = in ? s.q8.sum[b] : 0;
+        const float dd = (PRO == PRO_ACTQ8) ? a.act_d[bs] : s.q8.d[bs];
+        const int sm = (PRO == PRO_ACTQ8) ? a.act_sum[bs] : s.q8.sum[bs];
+        ad[c] = in ? dd : 0.f;
+        asum[c] = in ? sm : 0;
     }
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    float* res = s.red;                           // EPI_SILUMUL: 64 results over red + the start of row (both dead by now)
 #pragma unroll
     for (int j = 0; j < R; j++) {
         float acc = 0.f;
@@ -465,7 +506,34 @@ __global__ __launch_bounds__(256) void k_dec_gemv8(const Gemv8Args a)
             acc += (float)isum * (ad[c] * h2f(wd[j][c]));
         }
         acc = wave_sum(acc);
-        if (lane == 0 && r0 + j < total) a.out[r0 + j] = acc;
+        if (EPI == EPI_SILUMUL) {
+            if (lane == 0) res[(wid >> 2) * 32 + (wid & 3) * R + j] = acc;
+        } else {
+            if (lane == 0 && r0 + j < total) a.out[r0 + j] = acc;
+            if (a.best_val && r0 + j < total && acc > best) { best = acc; best_i = r0 + j; }   // strict >: first maximum wins
+        }
+    }
+    if (EPI == EPI_RAW && a.best_val && lane == 0) {
+        a.best_val[blockIdx.x * 4 + wid] = best;
+        a.best_idx[blockIdx.x * 4 + wid] = best_i;
+    }
+    if (EPI == EPI_SILUMUL) {
+        // ---- 5. silu(write(gate)) * write(up), written as Q8 (gten/modules.cpp:238-247), once per slice
+        __syncthreads();
+        if (wid == 0) {
+            const int e = lane & 31;
+            float g = q8_round32(res[e]);                    // gate projection written as Q8
+            g = q8_round32(g / (1.0f + expf(-g)));           // silu in place
+            const float u = q8_round32(res[32 + e]);         // up projection written as Q8
+            const float v = g * u;                           // mul in place, then written as Q8:
+            const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
+            const int q = q8_round(v, sc.scale);
+            const int qs = sum32_i(q);
+            if (lane < 32) {
+                a.act_q[(size_t)blockIdx.x * 32 + e] = (int8_t)q;
+                if (e == 0) { a.act_d[blockIdx.x] = sc.ddeq; a.act_sum[blockIdx.x] = qs; }
+            }
+        }
     }
 }
 
@@ -843,6 +911,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a)
     float acc = 0.f;
     if (ADT == GTEN_Q8) {
         const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+#pragma unroll 8
         for (int cl = cg; cl < len; cl += 4) {
             const uint8_t* row = vb + (size_t)cl * 68;
             acc += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
@@ -859,17 +928,20 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a)
     }
 }
 
-// greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424)
-__global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ logits, int n_vocab, DecStep* step,
-                                                     int32_t* __restrict__ result)
+// greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424).
+// Works on (value, index) candidates: either the logits themselves (idx == null)
+// or the per-wave winners the lm_head kernel left behind.
+__global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ vals, const int* __restrict__ idxs, int count,
+                                                     DecStep* step, int32_t* __restrict__ result)
 {
     __shared__ float bv[16];
     __shared__ int bi[16];
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < n_vocab; i += blockDim.x) {
-        const float v = logits[i];
-        if (v > best) { best = v; idx = i; }
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const float v = vals[i];
+        const int vi = idxs ? idxs[i] : i;
+        if (v > best || (v == best && vi < idx)) { best = v; idx = vi; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -886,7 +958,7 @@ __global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ l
         if (idx == 0x7fffffff) idx = 0;
         const int n = step->n;
         result[n] = idx;                       // argmax of the step that computed row n-1
-        if (step->advance) step->n = n + 1;
+        if (step->advance) step->n = n + 1;    // free-running replay: the next launch decodes row n
     }
 }
 
@@ -903,6 +975,13 @@ struct gten_hip_decoder {
     float *qkv_raw = nullptr, *proj_raw = nullptr, *gu_raw = nullptr, *down_raw = nullptr;
     float *scores = nullptr, *stats = nullptr, *att_part = nullptr;
     uint8_t *xbuf = nullptr, *hbuf = nullptr;
+    int8_t* act_q = nullptr;       // FFN activation staged by the gate/up epilogue (ActQ8 layout)
+    float* act_d = nullptr;
+    int* act_sum = nullptr;
+    float* best_val = nullptr;     // lm_head per-wave winners
+    int* best_idx = nullptr;
+    int n_best = 0;
+    int dev_n = -1;                // value of step->n on the device after the queued work (-1: unknown)
     int n_chunks = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -941,7 +1020,16 @@ template <int WT, int PRO, int NCH, int R>
 static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const dim3 grid((total_rows + 4 * R - 1) / (4 * R)), block(256);
-    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R>), grid, block, stage_bytes(a.d_in), a);
+    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW>), grid, block, stage_bytes(a.d_in), a);
+    return 0;
+}
+
+// gate + up projections with the silu*up chain in the epilogue: one workgroup per 32-wide FFN slice
+template <int WT>
+static int launch_gateup8(const Gemv8Args& a, int n_ffn)
+{
+    const dim3 grid(n_ffn / 32), block(512);
+    GTR_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, 1, 8, EPI_SILUMUL>), grid, block, stage_bytes(a.d_in), a);
     return 0;
 }
 
@@ -992,20 +1080,23 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         if ((rc = launch_gemv8<WT, PRO_ATT, 1, 2>(KT_DEC_GEMV_O, o, E))) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
-        gu.out = dc->gu_raw; gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
-        if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8>(KT_DEC_GEMV_GATEUP, gu, 2 * F))) return rc;
+        gu.out = nullptr; gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
+        gu.act_q = dc->act_q; gu.act_d = dc->act_d; gu.act_sum = dc->act_sum;
+        if ((rc = launch_gateup8<WT>(gu, F))) return rc;
         Gemv8Args dn{};
         dn.step = dc->step; dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw;
-        dn.gate_raw = dc->gu_raw; dn.up_raw = dc->gu_raw + F;
-        rc = wideF ? launch_gemv8<WT, PRO_SILUMUL, 3, 2>(KT_DEC_GEMV_DOWN, dn, E)
-                   : launch_gemv8<WT, PRO_SILUMUL, 1, 2>(KT_DEC_GEMV_DOWN, dn, E);
+        dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum;
+        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, 3, 2>(KT_DEC_GEMV_DOWN, dn, E)
+                   : launch_gemv8<WT, PRO_ACTQ8, 1, 2>(KT_DEC_GEMV_DOWN, dn, E);
         if (rc) return rc;
     }
     Gemv8Args hd{};
     hd.step = dc->step; hd.d_in = E; hd.n_mats = 1; set_mat(hd, 0, d.lm_head, WT, d.n_vocab, E); hd.out = d.logits;
     hd.res_a = hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
+    hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
     if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
-    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)d.logits, d.n_vocab, dc->step, dc->result);
+    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
+               dc->n_best, dc->step, dc->result);
     return 0;
 }
 
@@ -1065,7 +1156,8 @@ static int enqueue_step(gten_hip_decoder* dc)
     hd.res_a = dc->hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
     hd.rows_per_wave = 8;
     if (int rc = launch_gemv<WT, PRO_RESID>(KT_DEC_GEMV_HEAD, hd, d.n_vocab)) return rc;
-    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)d.logits, d.n_vocab, dc->step, dc->result);
+    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)d.logits, (const int*)nullptr, d.n_vocab,
+               dc->step, dc->result);
     return 0;
 }
 
@@ -1116,6 +1208,12 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
     // residual rows between kernels: f32 (exact storage values) for Q8 activations, f16 rows otherwise
     GTR_CHECK(hipMalloc((void**)&dc->xbuf, (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->hbuf, (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->act_q, (size_t)F));
+    GTR_CHECK(hipMalloc((void**)&dc->act_d, (size_t)(F / 32) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->act_sum, (size_t)(F / 32) * 4));
+    dc->n_best = ((d.n_vocab + 31) / 32) * 4;      // lm_head launch: 4 waves x 8 rows per workgroup
+    GTR_CHECK(hipMalloc((void**)&dc->best_val, (size_t)dc->n_best * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->best_idx, (size_t)dc->n_best * 4));
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
     *out = dc;
     return 0;
@@ -1129,7 +1227,8 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     if (dc->exec) hipGraphExecDestroy(dc->exec);
     if (dc->graph) hipGraphDestroy(dc->graph);
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->gu_raw, dc->down_raw,
-                    dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf};
+                    dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
+                    dc->act_q, dc->act_d, dc->act_sum};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;
@@ -1148,7 +1247,14 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && n >= 1 && n <= dc->d.max_ctx, "decoder_step: n=%d outside [1, %d]", n, dc ? dc->d.max_ctx : 0);
-    GTR_CHECK(hipMemsetD32Async((hipDeviceptr_t)&dc->step->n, n, 1, stream()));
+    // The step's position lives on the device and the argmax kernel advances it,
+    // so consecutive steps need no host-side update at all.
+    if (dc->dev_n != n) {
+        const DecStep st{n, 1};
+        GTR_CHECK(hipMemcpyAsync(dc->step, &st, sizeof(st), hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));    // `st` is on this stack frame
+    }
+    dc->dev_n = n + 1;
     if (!use_graph || prof_on()) return enqueue(dc);    // event pairs cannot be recorded into a capture
     if (!dc->exec) {
         GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));

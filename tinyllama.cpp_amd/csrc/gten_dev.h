@@ -146,9 +146,16 @@ __device__ __forceinline__ Q8Scale q8_scale_from_absmax(float amax)
     s.scale = (delta != 0.0f) ? 1.0f / delta : 0.0f;
     return s;
 }
+// roundf (half away from zero), exactly: x - trunc(x) is exact for |x| < 2^23
+__device__ __forceinline__ float round_half_away(float x)
+{
+    const float r = truncf(x);
+    const float f = x - r;
+    return (fabsf(f) >= 0.5f) ? r + copysignf(1.0f, x) : r;
+}
 __device__ __forceinline__ int q8_round(float x, float scale)
 {
-    return (int)(int8_t)roundf(x * scale);
+    return (int)(int8_t)(int)round_half_away(x * scale);
 }
 
 // ---- storage rows -> f32 in LDS ----

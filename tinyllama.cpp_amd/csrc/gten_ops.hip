@@ -155,8 +155,11 @@ __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x,
     load_row_f32(x + (size_t)r * x_pitch, dtype, d, v);
     __syncthreads();
     const float ss = block_sum(row_sumsq8(v, d), red);
-    const float rms = sqrtf(ss / (float)d);
-    for (int i = threadIdx.x; i < d; i += blockDim.x) v[i] = v[i] / (rms + 1e-6f) * h2f(w[i]);
+    // x / (rms + eps) * w evaluated as x * (1 / (rms + eps)) * w: one correctly
+    // rounded reciprocal per row instead of a division per element (<= 1 ulp
+    // apart before the row is rounded to the activation dtype)
+    const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);
+    for (int i = threadIdx.x; i < d; i += blockDim.x) v[i] = v[i] * inv * h2f(w[i]);
     __syncthreads();
     store_row(v, dtype, d, out + (size_t)r * out_pitch);
 }
