@@ -79,7 +79,9 @@ def compare_rows(got, want, dtype, d, what="", min_exact=0.97, steps=1.0, atol=0
     `steps` quantization steps (Q8: delta of the block; f16: one ulp), and at
     least `min_exact` of the stored bytes must be identical.  `atol` covers f32
     accumulation error of long dot products whose result cancels to near zero
-    (there the error is absolute, ~K*2^-24*|partial sums|, not relative).
+    (there the error is absolute, ~K*2^-24*|partial sums|, not relative); for attention
+    it also covers a flipped rounding of one PROBABILITY (1 ulp of p ~ 1.5e-5 at p ~ 1/32)
+    times |v|, which is absolute in the output however small the output is.
     """
     got = np.ascontiguousarray(got).view(np.uint8)
     want = np.ascontiguousarray(want).view(np.uint8)

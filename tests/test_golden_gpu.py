@@ -60,7 +60,7 @@ def test_ops_against_reference_golden(hip):
             want = g[key + ".out.avx"]
             out = hip.upload(np.zeros_like(want))
             hip.qkv_attn(hip.upload(g[key + ".q"]), hip.upload(g[key + ".k"]), hip.upload(g[key + ".v"]), out, ad, n_att, 8, 2, 64, sp)
-            compare_rows(out.download(shape=want.shape)[sp:], want[sp:], ad, 512, key, min_exact=0.90, steps=2.0, atol=8e-6)
+            compare_rows(out.download(shape=want.shape)[sp:], want[sp:], ad, 512, key, min_exact=0.90, steps=2.0, atol=2e-4)
 
 
 def band(name, d, std):

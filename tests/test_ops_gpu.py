@@ -169,7 +169,7 @@ def test_qkv_attn(hip, oracle, ad, n, sp, H, G, dh):
     got = out.download(shape=want.shape)
     assert not got[:sp].any()
     # two chained roundings (probabilities, then the output row): allow 2 steps
-    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0, atol=8e-6)
+    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0, atol=2e-4)
 
 
 def test_errors_are_reported_not_swallowed(hip):
