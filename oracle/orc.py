@@ -283,3 +283,48 @@ def load_ref(kind="avx"):
         path = os.path.join(HERE, "_ref", f"libref_{kind}.so")
         _cache[key] = CpuLib(path, "ref_") if os.path.exists(path) else None
     return _cache[key]
+
+
+class DropinLib:
+    """oracle/_ref/libdropin.so: the reference's UNMODIFIED tinyllama.cpp (TinyLlama class,
+    .gten loader, module wiring) compiled against this repository's HBM-backed gten API
+    and linked with libgten_hip.so (oracle/Makefile, target `dropin`).  Needs a GPU to run."""
+
+    def __init__(self, path):
+        self.lib = L = C.CDLL(path)
+        vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+
+        def sig(name, res, args):
+            f = getattr(L, "ref_" + name)
+            f.restype = res
+            f.argtypes = args
+            return f
+
+        self._mcreate = sig("model_create", vp, [C.POINTER(Config)])
+        self._mfree = sig("model_free", None, [vp])
+        self._mnw = sig("model_n_weights", ci, [vp])
+        self._mwb = sig("model_weight_bytes", sz, [vp, ci])
+        self._msetw = sig("model_set_weight", None, [vp, ci, vp, sz])
+        self._mlogits = sig("model_logits", None, [vp, vp, ci, ci, vp])
+        self._tl_create = sig("tl_create", vp, [ci, ci, ci])
+        self._tl_free = sig("tl_free", None, [vp])
+        self._tl_load = sig("tl_load", ci, [vp, C.c_char_p])
+        self._tl_logits = sig("tl_logits", None, [vp, vp, ci, ci, vp])
+        self.prefix = "ref_"
+
+    def model(self, cfg):
+        return CpuModel(self, cfg)
+
+    def tinyllama(self, n_ctx, wdtype, adtype):
+        return RefTinyLlama(self, n_ctx, wdtype, adtype)
+
+
+def build_dropin():
+    subprocess.run(["make", "-s", "-C", HERE, "dropin"], check=True)
+
+
+def load_dropin():
+    if "dropin" not in _cache:
+        path = os.path.join(HERE, "_ref", "libdropin.so")
+        _cache["dropin"] = DropinLib(path) if os.path.exists(path) else None
+    return _cache["dropin"]

@@ -1,5 +1,12 @@
 // ref_harness.cpp -- thin extern "C" shim around the REAL reference sources.
 //
+// Built a second time with -DGTEN_DROPIN (oracle/Makefile, target `dropin`): the
+// reference's UNMODIFIED tinyllama.cpp (its TinyLlama class, .gten loader and
+// module wiring) is then compiled against THIS repository's HBM-backed gten
+// headers instead of its own gten/ directory and linked with libgten_hip.so --
+// the drop-in boundary exercised by the reference's own caller code
+// (tests/test_dropin_gpu.py).  Only the model-level exports exist in that build.
+//
 // TEST INFRASTRUCTURE ONLY.  This translation unit is compiled only where
 // /root/reference exists (oracle/Makefile, target `ref`); it textually includes
 // the reference's single translation unit from there (never copied into this
@@ -64,6 +71,8 @@ Tensor view2(const void* p, int rows, int cols, int dtype) { return Tensor(p, {r
 } // namespace
 
 extern "C" {
+
+#ifndef GTEN_DROPIN   // ---- operator-level wrappers: need the reference's own gten/ops.h internals
 
 int ref_built_with_avx(void)
 {
@@ -183,6 +192,8 @@ void ref_qkv_attn(const void* q, const void* k, const void* v, void* out, int dt
     qk.resize({n_heads, n, n});
     gten::ops::qkv_attn(qt, kt, vt, qk, ot, max_ctx, start_pos);
 }
+
+#endif // !GTEN_DROPIN
 
 // ---- model assembled from the reference's own modules with arbitrary dims
 // (TinyLLamaParams is hard-coded, tinyllama.cpp:12-20; the wiring below is the
