@@ -167,6 +167,29 @@ def summarize(lg):
     return top, lg[top].astype(np.float32), np.array([lg.mean(), lg.std()], np.float32), probes
 
 
+def add_long_probe(host, refs, out):
+    """long-context probe (q4): teacher-forced ids, single-token steps from n=1 (single-row decode never
+    triggers the reference's probability-scratch stride quirk).  Both reference builds, so that the
+    fixture carries the reference's OWN spread at long context next to the expected values."""
+    toks = host.synthetic_tokens(2048, seed=12345)
+    ns = (257, 1024, 2047, 2048)
+    for kind in ("avx", "scalar"):
+        m = refs[kind].tinyllama(2048, Q4, Q8)
+        m.load("/tmp/gten_golden_q4.gten")
+        t0 = time.time()
+        for n in range(1, 2049):
+            lg = m.logits(toks[:n], n - 1)
+            if n in ns:
+                t, v, s, p = summarize(lg)
+                suffix = "" if kind == "avx" else ".scalar"
+                out[f"long.q4.n{n}.top_ids{suffix}"] = t; out[f"long.q4.n{n}.top_logits{suffix}"] = v
+                out[f"long.q4.n{n}.stats{suffix}"] = s; out[f"long.q4.n{n}.probes{suffix}"] = p
+            if n % 256 == 0:
+                print(f"  long probe {kind} n={n} {time.time() - t0:.0f}s", flush=True)
+        m.close()
+    out["long.q4.ns"] = np.array(ns, np.int32)
+
+
 def make_full_model_golden(pkg, host, refs, skip_long):
     probe_ids = np.concatenate([PROBE_IDS, np.arange(0, 32003, 32, dtype=np.int32)])
     out = {"probe_ids": probe_ids, "seed": np.array([1234]), "token_seed": np.array([12345])}
@@ -202,25 +225,7 @@ def make_full_model_golden(pkg, host, refs, skip_long):
             out[f"{name}.{kind}.probes"] = np.stack(probes)
             print(f"full {name}/{kind}: {time.time() - t0:.0f}s, greedy {toks[15:23]}")
     if not skip_long:
-        # long-context probe (q4): teacher-forced ids, single-token steps from n=1 (single-row
-        # decode never triggers the reference's probability-scratch stride quirk)
-        wd, ad = Q4, Q8
-        m = refs["avx"].tinyllama(2048, wd, ad)
-        m.load("/tmp/gten_golden_q4.gten")
-        toks = host.synthetic_tokens(2048, seed=12345)
-        t0 = time.time()
-        keep = {}
-        for n in range(1, 2049):
-            lg = m.logits(toks[:n], n - 1)
-            if n in (257, 1024, 2047, 2048):
-                keep[n] = summarize(lg)
-            if n % 256 == 0:
-                print(f"  long probe n={n} {time.time() - t0:.0f}s", flush=True)
-        m.close()
-        out["long.q4.ns"] = np.array(sorted(keep), np.int32)
-        for n, (t, v, s, p) in keep.items():
-            out[f"long.q4.n{n}.top_ids"] = t; out[f"long.q4.n{n}.top_logits"] = v
-            out[f"long.q4.n{n}.stats"] = s; out[f"long.q4.n{n}.probes"] = p
+        add_long_probe(host, refs, out)
     np.savez_compressed(os.path.join(HERE, "full_model_golden.npz"), **out)
     print("full_model_golden.npz")
 
@@ -230,6 +235,7 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--skip-long", action="store_true")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--only-long", action="store_true", help="re-run just the long-context probe into the existing fixture")
     args = ap.parse_args()
     assert os.path.isdir(REFERENCE), "run this in the build container (needs /root/reference)"
     orc.build(ref=True)
@@ -238,6 +244,14 @@ def main():
     pkg = load_package()
     pkg.build.build_all()
     host = pkg.load_host()
+    if args.only_long:
+        path = os.path.join(HERE, "full_model_golden.npz")
+        out = dict(np.load(path))
+        if not os.path.exists("/tmp/gten_golden_q4.gten"):
+            host.write_gten(host.default_config(Q4, Q8), 1234, "/tmp/gten_golden_q4.gten")
+        add_long_probe(host, refs, out)
+        np.savez_compressed(path, **out)
+        return
     if not args.only_full:
         make_converter_pins()
         make_ops_golden(oracle, refs)

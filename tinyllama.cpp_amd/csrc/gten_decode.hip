@@ -70,7 +70,7 @@ __device__ __forceinline__ void finish_stage(ActStage s, int adtype, int d)
 // RMSNorm of s.row in place (gten/ops.h:762-778)
 __device__ __forceinline__ void rms_norm_row(ActStage s, const uint16_t* __restrict__ w, int d)
 {
-    const float ss = block_sum(row_sumsq8(s.row, d), s.red);
+    const float ss = block_sum_tree(row_sumsq8(s.row, d), s.red);
     const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);     // see k_rms_norm
     for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = s.row[i] * inv * h2f(w[i]);
 }
@@ -241,45 +241,82 @@ struct Gemv8Args {
     int8_t* act_q; float* act_d; int* act_sum;
 };
 
-// write_row_from_float + read_row_to_float of one Q8 block spread over a quad
-// (8 elements per lane): v <- q * fp16(delta)   (gten/quants.h:52-76)
-__device__ __forceinline__ void q8_round8(float (&v)[8])
+// ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
+// Q8 block is a group of 32/EPT (4 or 8) adjacent lanes and its absmax / sum are DPP steps.
+template <int EPT> __device__ __forceinline__ float grp_max(float v)
 {
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(v[i]));
-    const Q8Scale s = q8_scale_from_absmax(quad_max(amax));
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (float)q8_round(v[i], s.scale) * s.ddeq;
+    v = quad_max(v);
+    if (EPT == 4) v = fmaxf(v, dpp_mov<0x141>(v));      // + row_half_mirror: 8 lanes
+    return v;
+}
+template <int EPT> __device__ __forceinline__ int grp_sum_i(int v)
+{
+    v = quad_sum_i(v);
+    if (EPT == 4) v += dpp_mov_i<0x141>(v);
+    return v;
+}
+template <int EPT> __device__ __forceinline__ float grp_sum(float v)   // balanced tree, natural order
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    if (EPT == 4) v += dpp_mov<0x141>(v);
+    return v;
 }
 
-// quantize the quad's block and stage it for the dot products
-__device__ __forceinline__ void q8_stage8(const float (&v)[8], int b, int sub, ActQ8 a)
+// write_row_from_float + read_row_to_float of one Q8 block spread over its lane group:
+// v <- q * fp16(delta)   (gten/quants.h:52-76)
+template <int EPT> __device__ __forceinline__ void q8_roundN(float (&v)[EPT])
 {
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(v[i]));
-    const Q8Scale s = q8_scale_from_absmax(quad_max(amax));
-    int q[8], sum = 0;
+    for (int i = 0; i < EPT; i++) amax = fmaxf(amax, fabsf(v[i]));
+    const Q8Scale s = q8_scale_from_absmax(grp_max<EPT>(amax));
 #pragma unroll
-    for (int i = 0; i < 8; i++) { q[i] = q8_round(v[i], s.scale); sum += q[i]; }
-    int2 pk;
-    pk.x = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
-    pk.y = (q[4] & 0xff) | ((q[5] & 0xff) << 8) | ((q[6] & 0xff) << 16) | ((q[7] & 0xff) << 24);
-    *(int2*)(a.q + (size_t)b * 32 + sub * 8) = pk;
-    sum = quad_sum_i(sum);
+    for (int i = 0; i < EPT; i++) v[i] = (float)q8_round(v[i], s.scale) * s.ddeq;
+}
+
+// quantize the group's block and stage it for the dot products
+template <int EPT> __device__ __forceinline__ void q8_stageN(const float (&v)[EPT], int b, int sub, ActQ8 a)
+{
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) amax = fmaxf(amax, fabsf(v[i]));
+    const Q8Scale s = q8_scale_from_absmax(grp_max<EPT>(amax));
+    int q[EPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { q[i] = q8_round(v[i], s.scale); sum += q[i]; }
+    const int lo = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
+    if (EPT == 8) {
+        int2 pk;
+        pk.x = lo;
+        pk.y = (q[EPT - 4] & 0xff) | ((q[EPT - 3] & 0xff) << 8) | ((q[EPT - 2] & 0xff) << 16) | ((q[EPT - 1] & 0xff) << 24);
+        *(int2*)(a.q + (size_t)b * 32 + sub * 8) = pk;
+    } else {
+        *(int*)(a.q + (size_t)b * 32 + sub * 4) = lo;
+    }
+    sum = grp_sum_i<EPT>(sum);
     if (sub == 0) { a.d[b] = s.ddeq; a.sum[b] = sum; }
 }
 
-__device__ __forceinline__ void ld8(const float* p, float (&v)[8])
+template <int EPT> __device__ __forceinline__ void ldN(const float* p, float (&v)[EPT])
 {
-    const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    const float4 a = ((const float4*)p)[0];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    if (EPT == 8) {
+        const float4 b = ((const float4*)p)[1];
+        v[EPT - 4] = b.x; v[EPT - 3] = b.y; v[EPT - 2] = b.z; v[EPT - 1] = b.w;
+    }
 }
-__device__ __forceinline__ void st8(float* p, const float (&v)[8])
+template <int EPT> __device__ __forceinline__ void stN(float* p, const float (&v)[EPT])
 {
     ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
-    ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    if (EPT == 8) ((float4*)p)[1] = make_float4(v[EPT - 4], v[EPT - 3], v[EPT - 2], v[EPT - 1]);
+}
+template <int EPT> __device__ __forceinline__ float sumsq_treeN(const float (&v)[EPT])
+{
+    float s = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (EPT == 8) s = s + ((v[EPT - 4] * v[EPT - 4] + v[EPT - 3] * v[EPT - 3]) + (v[EPT - 2] * v[EPT - 2] + v[EPT - 1] * v[EPT - 1]));
+    return s;
 }
 
 // max / integer sum over the 32 lanes of a half wave (lane = element of one Q8 block)
@@ -304,60 +341,65 @@ __device__ __forceinline__ float q8_round32(float v)
     return (float)q8_round(v, s.scale) * s.ddeq;
 }
 
-// EPI_RAW:     4 waves, wave w owns rows [(4*blockIdx.x + w) * R, +R) of the concatenated matrices
+// NT threads (256 or 512): the prologue row (<= 2048 elements) is spread over all of them,
+// EPT = 2048/NT elements each, so a 512-thread workgroup puts two waves on every SIMD and
+// its prologue issues at twice the rate of a 256-thread one.
+// EPI_RAW:     wave w owns rows [(NW*blockIdx.x + w) * R, +R) of the concatenated matrices
 // EPI_SILUMUL: 8 waves, block = one 32-wide slice of the FFN: waves 0-3 its gate rows, waves 4-7
 //              its up rows (R = 8); the slice's silu(gate)*up chain runs ONCE here, in the
 //              epilogue, and is stored quantized for the down projection (PRO_ACTQ8)
-template <int WT, int PRO, int NCH, int R, int EPI>
-__global__ __launch_bounds__(EPI == EPI_SILUMUL ? 512 : 256) void k_dec_gemv8(const Gemv8Args a)
+template <int WT, int PRO, int NCH, int R, int EPI, int NT>
+__global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
 {
-    constexpr int NP = NCH;                       // prologue passes of 2048 elements (d <= NP * 2048)
+    constexpr int EPT = 2048 / NT;                // prologue elements per thread (d <= 2048 unless PRO_ACTQ8)
+    constexpr int LPB = 32 / EPT;                 // lanes per Q8 block
+    constexpr int NW = NT / 64;
+    static_assert(NT == 256 || NT == 512, "256 or 512 threads");
+    static_assert(EPI != EPI_SILUMUL || NT == 512, "the FFN slice epilogue wants 8 waves");
     const int d = a.d_in, nb = d >> 5;
-    ActStage s = carve_stage(d);
+    ActStage s = carve_stage(PRO == PRO_ACTQ8 ? 32 : d);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = a.step->n;
+    const int gi = threadIdx.x, base = gi * EPT, blk = gi / LPB, sub = gi % LPB;
+    const bool on = base < d;                     // lanes past the row re-read group 0 (never used):
+    const int sbase = on ? base : 0;              // an unconditional load has no select on its result
 
     // ---- 1. request the prologue's inputs (they come back first: vmcnt is in order)
-    float pin0[NP][8], pin1[NP][8];
+    float pin0[EPT], pin1[EPT];
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
-        // lanes past the end re-read group 0 (never used): an unconditional load has
-        // no select on its result, so nothing has to wait for it here
-        const int gi = threadIdx.x + p * 256, base = (gi * 8 < d) ? gi * 8 : 0;
-        if (PRO == PRO_RESID) { ld8(a.res_raw + base, pin0[p]); ld8(a.res_a + base, pin1[p]); }
-        else if (PRO == PRO_SILUMUL) { ld8(a.gate_raw + base, pin0[p]); ld8(a.up_raw + base, pin1[p]); }
-        else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) { pin0[p][i] = 0.f; pin1[p][i] = 0.f; }
-        }
+    for (int i = 0; i < EPT; i++) { pin0[i] = 0.f; pin1[i] = 0.f; }
+    if (PRO == PRO_RESID) { ldN<EPT>(a.res_raw + sbase, pin0); ldN<EPT>(a.res_a + sbase, pin1); }
+    unsigned nw[4] = {0, 0, 0, 0};
+    if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
+        if (EPT == 8) { const uint4 t = *(const uint4*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; nw[2] = t.z; nw[3] = t.w; }
+        else { const uint2 t = *(const uint2*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; }
     }
-    uint4 nw8[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        const int gi = threadIdx.x + p * 256, base = (gi * 8 < d) ? gi * 8 : 0;
-        nw8[p] = make_uint4(0, 0, 0, 0);
-        if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) nw8[p] = *(const uint4*)(a.norm_w + base);
-    }
-    uint2 emb_bytes = make_uint2(0, 0);
+    unsigned emb[2] = {0, 0};
     float emb_delta = 0.f;
     if (PRO == PRO_EMBED) {
         const int tok = a.tokens[n - 1];
-        const int gsafe = (threadIdx.x * 8 < d) ? threadIdx.x : 0;
-        const int b = gsafe >> 2, sub = gsafe & 3;
+        const int sb = on ? blk : 0, ssub = on ? sub : 0;
+        // high nibbles are elements 0..15, low nibbles 16..31 (gten/quants.h:78-90); Q8 planes hold 16 bytes each
+        const int byte0 = (ssub * EPT) & 15;      // first source byte inside the 16-byte half
+        const uint8_t* src;
+        const uint16_t* dsp;
         if (WT == GTEN_Q4) {
-            emb_bytes = *(const uint2*)((const uint8_t*)a.table + ((size_t)tok * nb + b) * 16 + (sub & 1) * 8);
-            emb_delta = h2f(((const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 16))[(size_t)tok * nb + b]);
+            src = (const uint8_t*)a.table + ((size_t)tok * nb + sb) * 16 + byte0;
+            dsp = (const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 16);
         } else {
-            emb_bytes = *(const uint2*)((const uint8_t*)a.table + (size_t)tok * nb * 32 + (size_t)(sub >> 1) * nb * 16 + (size_t)b * 16 + (sub & 1) * 8);
-            emb_delta = h2f(((const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 32))[(size_t)tok * nb + b]);
+            src = (const uint8_t*)a.table + (size_t)tok * nb * 32 + (size_t)((ssub * EPT) >> 4) * nb * 16 + (size_t)sb * 16 + byte0;
+            dsp = (const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 32);
         }
+        emb[0] = *(const unsigned*)src;
+        if (EPT == 8) emb[1] = *(const unsigned*)(src + 4);
+        emb_delta = h2f(dsp[(size_t)tok * nb + sb]);
     }
 
     // ---- 2. request this wave's weight rows; they stay in flight during the prologue
     const int rows0 = a.rows[0], rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
     const int total = rows0 + rows1 + rows2;
     const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
-                                        : (blockIdx.x * 4 + wid) * R;
+                                        : (blockIdx.x * NW + wid) * R;
     uint4 wq[R][NCH], wq1[R][NCH];
     uint16_t wd[R][NCH];
 #pragma unroll
@@ -392,87 +434,53 @@ __global__ __launch_bounds__(EPI == EPI_SILUMUL ? 512 : 256) void k_dec_gemv8(co
     // ---- 3. prologue: the element-wise chain of the reference, on chip
     //         (PRO_ACTQ8: nothing to do, the input was staged in HBM by the producer's epilogue)
     if (PRO != PRO_ACTQ8) {
-    float ss = 0.f;
+        float v[EPT];
+        float ss = 0.f;
+        if (PRO == PRO_EMBED) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
-        const int gi = threadIdx.x + p * 256, base = gi * 8, b = gi >> 2, sub = gi & 3;
-        if (base < d) {
-            float v[8];
-            if (PRO == PRO_EMBED) {
-                // high nibbles are elements 0..15, low nibbles 16..31 (gten/quants.h:78-90)
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const unsigned w = (i < 4) ? emb_bytes.x : emb_bytes.y;
-                    const unsigned byte = (w >> ((i & 3) * 8)) & 0xffu;
-                    if (WT == GTEN_Q4) v[i] = (float)(((sub < 2) ? (int)(byte >> 4) : (int)(byte & 0x0fu)) - 7) * emb_delta;
-                    else v[i] = (float)(int)(int8_t)byte * emb_delta;      // block copied verbatim (gten/ops.h:519-521)
-                }
-                if (WT == GTEN_Q4) q8_round8(v);          // Q4 row is re-quantized to Q8 (gten/ops.h:522-528)
-            } else if (PRO == PRO_RESID) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = pin0[p][i];
-                q8_round8(v);                             // Linear output written as Q8
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = pin1[p][i] + v[i];
-                q8_round8(v);                             // Residual output written as Q8
-            } else if (PRO == PRO_ATT) {
-                const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-                const int h = base / a.d_head, e = base % a.d_head;
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = 0.f;
-                for (int j = 0; j < nch; j++) {
-                    float t[8];
-                    ld8(a.att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) v[i] += t[i];
-                }
-            } else {
-                float u[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) { v[i] = pin0[p][i]; u[i] = pin1[p][i]; }
-                q8_round8(v);                             // gate written as Q8
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = v[i] / (1.0f + expf(-v[i]));
-                q8_round8(v);                             // silu in place, written as Q8
-                q8_round8(u);                             // up written as Q8
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = v[i] * u[i];
+            for (int i = 0; i < EPT; i++) {
+                const unsigned byte = (emb[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+                if (WT == GTEN_Q4) v[i] = (float)((((sub * EPT) < 16) ? (int)(byte >> 4) : (int)(byte & 0x0fu)) - 7) * emb_delta;
+                else v[i] = (float)(int)(int8_t)byte * emb_delta;      // block copied verbatim (gten/ops.h:519-521)
             }
-            if (PRO == PRO_EMBED || PRO == PRO_RESID) {
-                if (a.x_out && blockIdx.x == 0) st8(a.x_out + base, v);
-                if (a.norm_w) {
+            if (WT == GTEN_Q4) q8_roundN<EPT>(v);         // Q4 row is re-quantized to Q8 (gten/ops.h:522-528)
+        } else if (PRO == PRO_RESID) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) ss += v[i] * v[i];
-                    st8(s.row + base, v);
-                } else {
-                    q8_stage8(v, b, sub, s.q8);
-                }
-            } else {
-                q8_stage8(v, b, sub, s.q8);
+            for (int i = 0; i < EPT; i++) v[i] = pin0[i];
+            q8_roundN<EPT>(v);                            // Linear output written as Q8
+#pragma unroll
+            for (int i = 0; i < EPT; i++) v[i] = pin1[i] + v[i];
+            q8_roundN<EPT>(v);                            // Residual output written as Q8
+        } else {                                          // PRO_ATT: sum of the per-chunk partials, fixed order
+            const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+            const int h = sbase / a.d_head, e = sbase % a.d_head;
+#pragma unroll
+            for (int i = 0; i < EPT; i++) v[i] = 0.f;
+            for (int j = 0; j < nch; j++) {
+                float t[EPT];
+                ldN<EPT>(a.att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
+#pragma unroll
+                for (int i = 0; i < EPT; i++) v[i] += t[i];
             }
         }
-    }
-    if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
-        // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
-        ss = block_sum(ss, s.red);
-        const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);  // see k_rms_norm
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            const int gi = threadIdx.x + p * 256, base = gi * 8;
-            if (base < d) {
-                float v[8];
-                ld8(s.row + base, v);
-                const unsigned wu[4] = {nw8[p].x, nw8[p].y, nw8[p].z, nw8[p].w};
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint16_t hw = (uint16_t)((i & 1) ? (wu[i >> 1] >> 16) : (wu[i >> 1] & 0xffffu));
-                    v[i] = v[i] * inv * h2f(hw);
-                }
-                q8_stage8(v, gi >> 2, gi & 3, s.q8);
+        if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
+            if (on) {
+                if (a.x_out && blockIdx.x == 0) stN<EPT>(a.x_out + base, v);
+                ss = sumsq_treeN<EPT>(v);
             }
+            // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
+            ss = block_sum_tree(ss, s.red);
+            const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);  // see k_rms_norm
+#pragma unroll
+            for (int i = 0; i < EPT; i++) {
+                const uint16_t hw = (uint16_t)((i & 1) ? (nw[i >> 1] >> 16) : (nw[i >> 1] & 0xffffu));
+                v[i] = v[i] * inv * h2f(hw);
+            }
+        } else if (PRO == PRO_EMBED || PRO == PRO_RESID) {
+            if (on && a.x_out && blockIdx.x == 0) stN<EPT>(a.x_out + base, v);
         }
-    }
-    __syncthreads();
+        if (on) q8_stageN<EPT>(v, blk, sub, s.q8);
+        __syncthreads();
     }
 
     // ---- 4. this lane's activation blocks, then the dot products
@@ -514,8 +522,8 @@ __global__ __launch_bounds__(EPI == EPI_SILUMUL ? 512 : 256) void k_dec_gemv8(co
         }
     }
     if (EPI == EPI_RAW && a.best_val && lane == 0) {
-        a.best_val[blockIdx.x * 4 + wid] = best;
-        a.best_idx[blockIdx.x * 4 + wid] = best_i;
+        a.best_val[blockIdx.x * NW + wid] = best;
+        a.best_idx[blockIdx.x * NW + wid] = best_i;
     }
     if (EPI == EPI_SILUMUL) {
         // ---- 5. silu(write(gate)) * write(up), written as Q8 (gten/modules.cpp:238-247), once per slice
@@ -558,7 +566,7 @@ struct AttnArgs {
 __device__ __forceinline__ float head_prep(float raw, bool act, bool do_rope, int pos, int d_head, int adtype,
                                            const float2* __restrict__ rope, int8_t* qi8, float* qd, uint16_t* qd16)
 {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 63;
     float v = act ? raw : 0.f;
     // Linear output written in the activation dtype
     if (adtype == GTEN_Q8) {
@@ -785,32 +793,32 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a)
 
     const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
     const bool writer = has_new && (h % grp == 0);
-    if (threadIdx.x < 64) {
-        const int t = threadIdx.x;
-        float v = head_prep(a.qkv_raw[h * dh + t], true, true, pos, dh, ADT, a.rope, qi8, qd, d16);
-        qf[t] = v;
-        if (has_new) {
-            v = head_prep(a.qkv_raw[a.n_embd + g * dh + t], true, true, pos, dh, ADT, a.rope, ki8, kd, d16 + 4);
-            kf[t] = v;
-            if (writer) {
-                uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
-                if (ADT == GTEN_Q8) {
-                    uint8_t* blk = krow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-                    blk[2 + (t & 31)] = (uint8_t)ki8[t];
-                    if ((t & 31) == 0) *(uint16_t*)blk = d16[4 + (t >> 5)];
-                } else {
-                    ((uint16_t*)krow)[t] = f2h(v);
-                }
-                v = head_prep(a.qkv_raw[a.n_embd + kv_dim + g * dh + t], true, false, pos, dh, ADT, a.rope, vi8, kd + 4, d16 + 8);
-                uint8_t* vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
-                if (ADT == GTEN_Q8) {
-                    uint8_t* blk = vrow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-                    blk[2 + (t & 31)] = (uint8_t)vi8[t];
-                    if ((t & 31) == 0) *(uint16_t*)blk = d16[8 + (t >> 5)];
-                } else {
-                    ((uint16_t*)vrow)[t] = f2h(v);
-                }
+    // the three new head vectors are independent: one wave each (q | new k row | new v row)
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    if (pw == 0) {
+        qf[t] = head_prep(a.qkv_raw[h * dh + t], true, true, pos, dh, ADT, a.rope, qi8, qd, d16);
+    } else if (pw == 1 && has_new) {
+        const float v = head_prep(a.qkv_raw[a.n_embd + g * dh + t], true, true, pos, dh, ADT, a.rope, ki8, kd, d16 + 4);
+        kf[t] = v;
+        if (writer) {
+            uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+            if (ADT == GTEN_Q8) {
+                uint8_t* blk = krow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                blk[2 + (t & 31)] = (uint8_t)ki8[t];
+                if ((t & 31) == 0) *(uint16_t*)blk = d16[4 + (t >> 5)];
+            } else {
+                ((uint16_t*)krow)[t] = f2h(v);
             }
+        }
+    } else if (pw == 2 && writer) {
+        const float v = head_prep(a.qkv_raw[a.n_embd + kv_dim + g * dh + t], true, false, pos, dh, ADT, a.rope, vi8, kd + 4, d16 + 8);
+        uint8_t* vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+        if (ADT == GTEN_Q8) {
+            uint8_t* blk = vrow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+            blk[2 + (t & 31)] = (uint8_t)vi8[t];
+            if ((t & 31) == 0) *(uint16_t*)blk = d16[8 + (t >> 5)];
+        } else {
+            ((uint16_t*)vrow)[t] = f2h(v);
         }
     }
     __syncthreads();
@@ -1016,11 +1024,12 @@ static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
     return 0;
 }
 
-template <int WT, int PRO, int NCH, int R>
+template <int WT, int PRO, int NCH, int R, int NT>
 static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
-    const dim3 grid((total_rows + 4 * R - 1) / (4 * R)), block(256);
-    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW>), grid, block, stage_bytes(a.d_in), a);
+    const int rows_per_wg = (NT / 64) * R;
+    const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
+    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes(PRO == PRO_ACTQ8 ? 32 : a.d_in), a);
     return 0;
 }
 
@@ -1029,7 +1038,7 @@ template <int WT>
 static int launch_gateup8(const Gemv8Args& a, int n_ffn)
 {
     const dim3 grid(n_ffn / 32), block(512);
-    GTR_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, 1, 8, EPI_SILUMUL>), grid, block, stage_bytes(a.d_in), a);
+    GTR_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, 1, 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), a);
     return 0;
 }
 
@@ -1060,10 +1069,10 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = xbuf;
         if (l == 0) {
             a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
-            rc = launch_gemv8<WT, PRO_EMBED, 1, 2>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
+            rc = launch_gemv8<WT, PRO_EMBED, 1, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
         } else {
             a.res_a = hbuf; a.res_raw = dc->down_raw;
-            rc = launch_gemv8<WT, PRO_RESID, 1, 2>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
+            rc = launch_gemv8<WT, PRO_RESID, 1, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
         }
         if (rc) return rc;
         AttnArgs t{};
@@ -1077,7 +1086,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         Gemv8Args o{};
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
         o.att_part = dc->att_part; o.d_head = dh; o.n_chunks = dc->n_chunks;
-        if ((rc = launch_gemv8<WT, PRO_ATT, 1, 2>(KT_DEC_GEMV_O, o, E))) return rc;
+        if ((rc = launch_gemv8<WT, PRO_ATT, 1, 2, 512>(KT_DEC_GEMV_O, o, E))) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
         gu.out = nullptr; gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
@@ -1086,15 +1095,15 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         Gemv8Args dn{};
         dn.step = dc->step; dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw;
         dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum;
-        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, 3, 2>(KT_DEC_GEMV_DOWN, dn, E)
-                   : launch_gemv8<WT, PRO_ACTQ8, 1, 2>(KT_DEC_GEMV_DOWN, dn, E);
+        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, 3, 2, 256>(KT_DEC_GEMV_DOWN, dn, E)
+                   : launch_gemv8<WT, PRO_ACTQ8, 1, 2, 256>(KT_DEC_GEMV_DOWN, dn, E);
         if (rc) return rc;
     }
     Gemv8Args hd{};
     hd.step = dc->step; hd.d_in = E; hd.n_mats = 1; set_mat(hd, 0, d.lm_head, WT, d.n_vocab, E); hd.out = d.logits;
     hd.res_a = hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
-    if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
+    if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8, 512>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
     GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
                dc->n_best, dc->step, dc->result);
     return 0;
@@ -1211,7 +1220,7 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
     GTR_CHECK(hipMalloc((void**)&dc->act_q, (size_t)F));
     GTR_CHECK(hipMalloc((void**)&dc->act_d, (size_t)(F / 32) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->act_sum, (size_t)(F / 32) * 4));
-    dc->n_best = ((d.n_vocab + 31) / 32) * 4;      // lm_head launch: 4 waves x 8 rows per workgroup
+    dc->n_best = ((d.n_vocab + 63) / 64) * 8;      // lm_head launch: 8 waves x 8 rows per workgroup
     GTR_CHECK(hipMalloc((void**)&dc->best_val, (size_t)dc->n_best * 4));
     GTR_CHECK(hipMalloc((void**)&dc->best_idx, (size_t)dc->n_best * 4));
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }

@@ -91,6 +91,27 @@ __device__ __forceinline__ float group_max(float v)
     return v;
 }
 
+// Block-wide sum as a perfectly balanced binary tree over the threads in natural
+// order (wave tree above, then waves pairwise): with power-of-two thread counts
+// the result does not depend on how the same elements are split over 256 or 512
+// threads, which is what lets kernels with different geometries agree bit for bit.
+__device__ __forceinline__ float block_sum_tree(float v, float* scratch)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = (i < nw) ? scratch[i] : 0.f;
+#pragma unroll
+    for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2 * w) t[i] = t[i] + t[i + w];
+    return t[0];
+}
+
 // block-wide sum through LDS scratch (>= 16 floats); every thread gets the result
 __device__ __forceinline__ float block_sum(float v, float* scratch)
 {
@@ -119,12 +140,23 @@ __device__ __forceinline__ float block_max(float v, float* scratch)
 // RMSNorm statistic uses THIS element->thread mapping and order (thread t owns
 // the 8 consecutive elements of groups t, t+blockDim, ...), so the operator path
 // and the fused decode path round identically.  d % 8 == 0.
+__device__ __forceinline__ float sumsq_tree8(const float (&v)[8])
+{
+    return ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+}
+__device__ __forceinline__ float sumsq_tree4(const float (&v)[4])
+{
+    return (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+}
+// (combine with block_sum_tree; rows longer than 8 * blockDim add further passes sequentially)
 __device__ __forceinline__ float row_sumsq8(const float* row, int d)
 {
     float ss = 0.f;
     for (int gi = threadIdx.x; gi * 8 < d; gi += blockDim.x) {
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) ss += row[gi * 8 + i] * row[gi * 8 + i];
+        for (int i = 0; i < 8; i++) v[i] = row[gi * 8 + i];
+        ss += sumsq_tree8(v);
     }
     return ss;
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x,
     const int r = start_pos + blockIdx.x;
     load_row_f32(x + (size_t)r * x_pitch, dtype, d, v);
     __syncthreads();
-    const float ss = block_sum(row_sumsq8(v, d), red);
+    const float ss = block_sum_tree(row_sumsq8(v, d), red);
     // x / (rms + eps) * w evaluated as x * (1 / (rms + eps)) * w: one correctly
     // rounded reciprocal per row instead of a division per element (<= 1 ulp
     // apart before the row is rounded to the activation dtype)
