@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
     return ap.parse_args()
 
 
@@ -135,6 +137,7 @@ def main():
 
     from __graft_entry__ import load_package
     pkg = load_package()
+    rep_seed = importlib.import_module(pkg.__name__ + ".replicas").prompt_seed
     hip = pkg.hipabi.load(local_rank)
     host = pkg.load_host()
 
@@ -146,7 +149,10 @@ def main():
     load_s = time.time() - t0
 
     K, W = args.steps, args.warmup
-    toks = host.synthetic_tokens(N_CTX, seed=12345 + rank)
+    global N_CTX
+    N_CTX = args.ctx
+    use_graph = not args.no_graph
+    toks = host.synthetic_tokens(N_CTX, seed=rep_seed(12345, rank))
     fused = hasattr(model, "decode_step") and args.path in ("auto", "fused")
     if args.path == "fused" and not fused:
         raise SystemExit("fused decode path requested but not built")
@@ -164,7 +170,7 @@ def main():
 
     def step(n):
         if fused:
-            model.decode_step(n, True)           # asynchronous graph replay; argmax stays on the device
+            model.decode_step(n, use_graph)      # asynchronous graph replay; argmax stays on the device
             return None
         lg = model.logits(toks[:n], n - 1)       # logits reach the host; greedy argmax there
         return int(np.argmax(lg))
@@ -175,7 +181,7 @@ def main():
     t_fill = time.time()
     for n in range(1, first):
         if fused:
-            model.decode_step(n, True)
+            model.decode_step(n, use_graph)
         else:
             model.logits(toks[:n], n - 1, want=False)
     hip.sync()
@@ -250,7 +256,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"TinyLlama-1.1B {args.mode} greedy single-token decode, batch 1 per GPU, steps end at n=2048 "
                                f"(BASELINE.json configs[{ {'f16': 1, 'q8': 2, 'q4': 3}[args.mode] }])",
-                   "ctx": N_CTX, "kv_cache": "f16" if args.mode == "f16" else "q8 blocks (reference layout)",
+                   "ctx": N_CTX, "graph": use_graph, "kv_cache": "f16" if args.mode == "f16" else "q8 blocks (reference layout)",
                    "path": "fused" if fused else "ops", "argmax": "device" if fused else "host (128 KB logits D2H per step)",
                    "parallelism": f"replicas x{world}", "last_token": int(last)},
         "whole_step_hbm": {"achieved": round(whole, 1), "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBPS, 4),
