@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
     return ap.parse_args()
@@ -264,6 +265,23 @@ def main():
         "roofline": roofline,
         "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1)},
     }
+    # secondary: prompt processing on the matrix cores (not part of `value`)
+    if world == 1 and args.prefill > 0:
+        P = min(args.prefill, N_CTX)
+        model.set_fast_decode(False)
+        model.logits(toks[:P], 0, want=False)
+        hip.sync()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model.logits(toks[:P], 0, want=False)
+        hip.sync()
+        dt = (time.perf_counter() - t0) / reps
+        flops = 2.0 * 1_034_426_368 * P
+        out["prefill"] = {"prompt_tokens": P, "ms": round(dt * 1e3, 3), "tok_s": round(P / dt, 1),
+                          "linear_tflops": round(flops / dt / 1e12, 2),
+                          "note": "W.x on v_mfma_f32_16x16x32_f16 (one MFMA = one exact 32-wide quant block), "
+                                  "attention and element-wise ops on the operator kernels"}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(host, cfg, args.mode, args.seed, args.cpu_steps)

@@ -104,7 +104,7 @@ def compare_rows(got, want, dtype, d, what="", min_exact=0.97, steps=1.0, atol=0
     else:
         vg = got.view(np.float32)
         vw = want.view(np.float32)
-        np.testing.assert_allclose(vg, vw, rtol=2e-5, atol=2e-6, err_msg=what)
+        np.testing.assert_allclose(vg, vw, rtol=2e-5, atol=max(atol, 2e-6), err_msg=what)
         return 1.0
     exact = float((got == want).mean())
     assert exact >= min_exact, (what, f"only {exact:.4f} of the bytes are identical")

@@ -84,3 +84,23 @@ def test_greedy_loop_matches_oracle_f16(hip, oracle):
         lg = om.logits(toks, 0 if i == 0 else len(toks) - 1)
         toks.append(int(np.argmax(lg)))
     assert got.tolist() == toks
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_long_prompt_prefill_uses_matrix_cores(hip, oracle, name, wd, ad):
+    """a 40-id prompt: every W.x of the prefill runs on the MFMA kernel; then 3 fused decode steps"""
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(wd, ad, n_heads=4, n_kv_heads=2)
+    cfg = host_cfg(ocfg)
+    gm, om = host.model(cfg), oracle.model(ocfg)
+    for i in range(gm.n_weights()):
+        w = host.synth_weight(cfg, 777, i)
+        gm.set_weight(i, w); om.set_weight(i, w)
+    toks = list(host.synthetic_tokens(40, seed=11, n_vocab=cfg.n_vocab))
+    for step in range(4):
+        sp = 0 if step == 0 else len(toks) - 1
+        want, got = om.logits(toks, sp), gm.logits(toks, sp)
+        check_logits(name, got, want, float(want.std()))
+        toks.append(int(np.argmax(want)))
+    gm.close(); om.close()

@@ -180,3 +180,31 @@ def test_errors_are_reported_not_swallowed(hip):
         hip.matmul_2d(a, F16, a, Q4, a, F16, 1, 256, 32)       # dtype pair the reference does not dispatch
     with pytest.raises(pkg.GtenHipError):
         hip.add(a, a, a, Q8, 2, 256, start_pos=2)             # no rows to compute
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+@pytest.mark.parametrize("n,d_in,d_out,sp", [(40, 256, 96, 0), (100, 2048, 256, 3), (64, 5632, 128, 0), (17, 256, 64, 1)])
+def test_matmul_2d_prefill_on_matrix_cores(hip, oracle, name, wd, ad, n, d_in, d_out, sp):
+    """>= 16 new rows take the MFMA kernel (gten_mfma.hip).  For quantized dtypes one MFMA is one exact
+    integer block dot and the blocks are accumulated in the reference's scalar-build order, so f32
+    outputs equal the oracle in scalar order BIT FOR BIT; f16 accumulates inside the MFMA (tolerance)."""
+    r = rng(n * 131 + d_in + d_out)
+    x, _ = act_rows(oracle, r, n, d_in, ad)
+    w, _ = weight_rows(oracle, r, d_out, d_in, wd)
+    xd, wdv = hip.upload(x), up_weight(hip, w, wd, d_out, d_in)
+    for od in (ad, F32):
+        want = np.full((n, row_bytes(od, d_out)), 0xAB, np.uint8)
+        oracle.matmul_2d(x, ad, w, wd, want, od, n, d_in, d_out, sp)
+        od_dev = hip.upload(np.full_like(want, 0xAB))
+        hip.matmul_2d(xd, ad, wdv, wd, od_dev, od, n, d_in, d_out, sp)
+        got = od_dev.download(shape=want.shape)
+        assert np.array_equal(got[:sp], want[:sp]), "rows below start_pos must be untouched"
+        compare_rows(got[sp:], want[sp:], od, d_out, f"mfma matmul {name}->{od}", atol=8e-6)
+        if wd != F16:
+            oracle.set_simd(False)
+            try:
+                exact = np.full_like(want, 0xAB)
+                oracle.matmul_2d(x, ad, w, wd, exact, od, n, d_in, d_out, sp)
+            finally:
+                oracle.set_simd(True)
+            assert np.array_equal(got[sp:], exact[sp:]), f"{name}->{od}: MFMA path must reproduce the scalar-order oracle exactly"

@@ -9,6 +9,8 @@
 #include "gten_dev.h"
 #include "gten_rt.h"
 
+#include <cstdlib>
+
 using namespace gtd;
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
@@ -370,6 +372,11 @@ int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch, const void* w
     GTR_REQUIRE(x_pitch >= gten_hip_row_bytes(x_dtype, d_in), "matmul_2d: input pitch too small");
     GTR_REQUIRE(out_pitch >= gten_hip_row_bytes(out_dtype, d_out), "matmul_2d: output pitch too small");
     GTR_REQUIRE(n - start_pos <= 65535, "matmul_2d: too many new rows");
+    // prefill-sized calls go to the matrix cores (gten_mfma.hip); the row-per-workgroup
+    // kernel below streams the weights once per row and is meant for a handful of rows
+    static const bool no_mfma = [] { const char* e = std::getenv("GTEN_HIP_NO_MFMA"); return e && e[0] == '1'; }();
+    if (n - start_pos >= GTEN_MFMA_MIN_ROWS && !no_mfma)
+        return gten_launch_matmul_mfma(x, x_dtype, x_pitch, w, w_dtype, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
     const dim3 grid((d_out + 31) / 32, n - start_pos), block(256);
     const size_t act = (w_dtype == GTEN_F16) ? (size_t)d_in * 4 : (size_t)(d_in / 32) * 40;
     const size_t smem = 128 + act;
