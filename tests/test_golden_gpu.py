@@ -165,6 +165,15 @@ def test_long_context_probe_q4(hip, full_golden):
         ref_vals = np.concatenate([g[f"long.q4.n{n}.top_logits"], g[f"long.q4.n{n}.probes"]])
         got_vals = np.concatenate([lg[ids], lg[probe]])
         std = float(g[f"long.q4.n{n}.stats"][1])
-        rms, mx = band("q4", got_vals - ref_vals, std)
-        print(f"n={n}: rms {rms:.4f} max {mx:.4f} (std {std:.3f}) top1 {int(np.argmax(lg))} ref {int(ids[0])}")
+        # yardstick at THIS context length: the reference's own AVX build vs its own scalar build on
+        # the same ids (rms 0.074 at n=257 growing to 0.100 at n=2047; at n=2048 their top-1 differ).
+        # The K/V history of every implementation carries its own rounding noise, so the spread grows
+        # with n; the GPU must stay within 1.35x of the reference's self-disagreement, max <= 0.5.
+        own = g[f"long.q4.n{n}.probes"] - g[f"long.q4.n{n}.probes.scalar"]
+        own_rms = float(np.sqrt((own * own).mean()))
+        d = got_vals - ref_vals
+        rms, mx = float(np.sqrt((d * d).mean())), float(np.abs(d).max())
+        print(f"n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} (std {std:.3f}) "
+              f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} scalar {int(g[f'long.q4.n{n}.top_ids.scalar'][0])}")
+        assert rms <= 1.35 * own_rms and mx <= 0.5, (n, rms, own_rms, mx)
     m.close()

@@ -239,6 +239,7 @@ struct Gemv8Args {
     float* best_val; int* best_idx;                             // lm_head: per-wave running argmax (may be null)
     // EPI_SILUMUL writes / PRO_ACTQ8 reads the staged FFN activation in HBM (ActQ8 layout)
     int8_t* act_q; float* act_d; int* act_sum;
+    float* act_f;                                               // same for f16 activations: f32 row of exact f16 values
 };
 
 // ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
@@ -273,6 +274,17 @@ template <int EPT> __device__ __forceinline__ void q8_roundN(float (&v)[EPT])
     const Q8Scale s = q8_scale_from_absmax(grp_max<EPT>(amax));
 #pragma unroll
     for (int i = 0; i < EPT; i++) v[i] = (float)q8_round(v[i], s.scale) * s.ddeq;
+}
+
+// "written in the activation dtype and read back": Q8 block rounding or f16 rounding
+template <int WT, int EPT> __device__ __forceinline__ void act_roundN(float (&v)[EPT])
+{
+    if (WT == GTEN_F16) {
+#pragma unroll
+        for (int i = 0; i < EPT; i++) v[i] = h2f(f2h(v[i]));
+    } else {
+        q8_roundN<EPT>(v);
+    }
 }
 
 // quantize the group's block and stage it for the dot products
@@ -340,6 +352,10 @@ __device__ __forceinline__ float q8_round32(float v)
     const Q8Scale s = q8_scale_from_absmax(max32(fabsf(v)));
     return (float)q8_round(v, s.scale) * s.ddeq;
 }
+__device__ __forceinline__ float act_round32(float v, bool f16)
+{
+    return f16 ? h2f(f2h(v)) : q8_round32(v);
+}
 
 // NT threads (256 or 512): the prologue row (<= 2048 elements) is spread over all of them,
 // EPT = 2048/NT elements each, so a 512-thread workgroup puts two waves on every SIMD and
@@ -356,8 +372,9 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     constexpr int NW = NT / 64;
     static_assert(NT == 256 || NT == 512, "256 or 512 threads");
     static_assert(EPI != EPI_SILUMUL || NT == 512, "the FFN slice epilogue wants 8 waves");
+    constexpr bool F16W = (WT == GTEN_F16);        // f16 weights <=> f16 activations (tinyllama.cpp:258-265)
     const int d = a.d_in, nb = d >> 5;
-    ActStage s = carve_stage(PRO == PRO_ACTQ8 ? 32 : d);
+    ActStage s = carve_stage((PRO == PRO_ACTQ8 && !F16W) ? 32 : d);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = a.step->n;
     const int gi = threadIdx.x, base = gi * EPT, blk = gi / LPB, sub = gi % LPB;
@@ -374,9 +391,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         if (EPT == 8) { const uint4 t = *(const uint4*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; nw[2] = t.z; nw[3] = t.w; }
         else { const uint2 t = *(const uint2*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; }
     }
-    unsigned emb[2] = {0, 0};
+    unsigned emb[4] = {0, 0, 0, 0};
     float emb_delta = 0.f;
-    if (PRO == PRO_EMBED) {
+    if (PRO == PRO_EMBED && F16W) {
+        const uint16_t* src = (const uint16_t*)a.table + (size_t)a.tokens[n - 1] * d + sbase;
+        if (EPT == 8) { const uint4 t = *(const uint4*)src; emb[0] = t.x; emb[1] = t.y; emb[2] = t.z; emb[3] = t.w; }
+        else { const uint2 t = *(const uint2*)src; emb[0] = t.x; emb[1] = t.y; }
+    }
+    if (PRO == PRO_EMBED && !F16W) {
         const int tok = a.tokens[n - 1];
         const int sb = on ? blk : 0, ssub = on ? sub : 0;
         // high nibbles are elements 0..15, low nibbles 16..31 (gten/quants.h:78-90); Q8 planes hold 16 bytes each
@@ -419,6 +441,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
             // out-of-range K blocks read block 0 (finite data) and are zeroed through
             // the activation scale below: no select on loaded data, so nothing waits here
             const int b = (c * 64 + lane < nb) ? c * 64 + lane : 0;
+            if (F16W) {
+                // f16 rows: NCH counts 512-element segments, lane takes 8 halves of each
+                const int e = (c * 512 + lane * 8 < d) ? c * 512 + lane * 8 : 0;
+                wq[j][c] = *(const uint4*)((const uint16_t*)qbase + (size_t)lr * d + e);
+                wq1[j][c] = make_uint4(0, 0, 0, 0);
+                wd[j][c] = 0;
+                continue;
+            }
             if (WT == GTEN_Q4) {
                 wq[j][c] = ((const uint4*)(qbase + (size_t)lr * nb * 16))[b];
             } else {
@@ -439,18 +469,22 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         if (PRO == PRO_EMBED) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
-                const unsigned byte = (emb[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-                if (WT == GTEN_Q4) v[i] = (float)((((sub * EPT) < 16) ? (int)(byte >> 4) : (int)(byte & 0x0fu)) - 7) * emb_delta;
-                else v[i] = (float)(int)(int8_t)byte * emb_delta;      // block copied verbatim (gten/ops.h:519-521)
+                if (F16W) {
+                    v[i] = h2f((uint16_t)((i & 1) ? (emb[i >> 1] >> 16) : (emb[i >> 1] & 0xffffu)));   // row copied verbatim
+                } else {
+                    const unsigned byte = (emb[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+                    if (WT == GTEN_Q4) v[i] = (float)((((sub * EPT) < 16) ? (int)(byte >> 4) : (int)(byte & 0x0fu)) - 7) * emb_delta;
+                    else v[i] = (float)(int)(int8_t)byte * emb_delta;  // block copied verbatim (gten/ops.h:519-521)
+                }
             }
             if (WT == GTEN_Q4) q8_roundN<EPT>(v);         // Q4 row is re-quantized to Q8 (gten/ops.h:522-528)
         } else if (PRO == PRO_RESID) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = pin0[i];
-            q8_roundN<EPT>(v);                            // Linear output written as Q8
+            act_roundN<WT, EPT>(v);                       // Linear output written in the activation dtype
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = pin1[i] + v[i];
-            q8_roundN<EPT>(v);                            // Residual output written as Q8
+            act_roundN<WT, EPT>(v);                       // Residual output written in the activation dtype
         } else {                                          // PRO_ATT: sum of the per-chunk partials, fixed order
             const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
             const int h = sbase / a.d_head, e = sbase % a.d_head;
@@ -479,7 +513,16 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         } else if (PRO == PRO_EMBED || PRO == PRO_RESID) {
             if (on && a.x_out && blockIdx.x == 0) stN<EPT>(a.x_out + base, v);
         }
-        if (on) q8_stageN<EPT>(v, blk, sub, s.q8);
+        if (F16W) {
+            act_roundN<WT, EPT>(v);
+            if (on) stN<EPT>(s.row + base, v);            // staged as f32 (exact f16 values)
+        } else if (on) {
+            q8_stageN<EPT>(v, blk, sub, s.q8);
+        }
+        __syncthreads();
+    } else if (F16W) {
+        // the FFN activation row was stored by the gate/up epilogue: bring it on chip
+        for (int i = threadIdx.x * 4; i < d; i += NT * 4) *(float4*)(s.row + i) = *(const float4*)(a.act_f + i);
         __syncthreads();
     }
 
@@ -488,6 +531,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     float ad[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
+        if (F16W) { asum[c] = 0; ad[c] = 0.f; continue; }
         const int b = c * 64 + lane;
         const bool in = b < nb;
         const int bs = in ? b : 0;
@@ -503,12 +547,29 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     }
     float best = -INFINITY;
     int best_i = 0x7fffffff;
-    float* res = s.red;                           // EPI_SILUMUL: 64 results over red + the start of row (both dead by now)
+    // EPI_SILUMUL: 64 results in LDS that nobody reads any more: red + the start of the row for
+    // Q8 activations (the staged vector lives in the Q8 area), the Q8 area for f16 (it lives in the row)
+    float* res = F16W ? (float*)((uint8_t*)s.row + (size_t)d * 4) : s.red;
 #pragma unroll
     for (int j = 0; j < R; j++) {
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+            if (F16W) {
+                // same element order as wave_dot_f16 (gten_dev.h): segments ascending, 8 halves each
+                const int e = c * 512 + lane * 8;
+                if (e < d) {
+                    const float4 a0 = *(const float4*)(s.row + e), a1 = *(const float4*)(s.row + e + 4);
+                    const float fa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const unsigned u[4] = {wq[j][c].x, wq[j][c].y, wq[j][c].z, wq[j][c].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        acc += h2f((uint16_t)(u[i] & 0xffffu)) * fa[2 * i];
+                        acc += h2f((uint16_t)(u[i] >> 16)) * fa[2 * i + 1];
+                    }
+                }
+                continue;
+            }
             const int isum = (WT == GTEN_Q4) ? dot_q8_q4_block(av[c], asum[c], wq[j][c])
                                              : dot_q8_q8_block(av[c], wq[j][c], wq1[j][c]);
             acc += (float)isum * (ad[c] * h2f(wd[j][c]));
@@ -530,10 +591,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         __syncthreads();
         if (wid == 0) {
             const int e = lane & 31;
-            float g = q8_round32(res[e]);                    // gate projection written as Q8
-            g = q8_round32(g / (1.0f + expf(-g)));           // silu in place
-            const float u = q8_round32(res[32 + e]);         // up projection written as Q8
-            const float v = g * u;                           // mul in place, then written as Q8:
+            float g = act_round32(res[e], F16W);                    // gate projection written in the activation dtype
+            g = act_round32(g / (1.0f + expf(-g)), F16W);           // silu in place
+            const float u = act_round32(res[32 + e], F16W);         // up projection written
+            const float v = g * u;                                  // mul in place, then written:
+            if (F16W) {
+                if (lane < 32) a.act_f[(size_t)blockIdx.x * 32 + e] = h2f(f2h(v));
+                return;
+            }
             const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
             const int q = q8_round(v, sc.scale);
             const int qs = sum32_i(q);
@@ -983,6 +1048,7 @@ struct gten_hip_decoder {
     float *qkv_raw = nullptr, *proj_raw = nullptr, *gu_raw = nullptr, *down_raw = nullptr;
     float *scores = nullptr, *stats = nullptr, *att_part = nullptr;
     uint8_t *xbuf = nullptr, *hbuf = nullptr;
+    float* act_f = nullptr;        // FFN activation staged by the gate/up epilogue, f16 configurations
     int8_t* act_q = nullptr;       // FFN activation staged by the gate/up epilogue (ActQ8 layout)
     float* act_d = nullptr;
     int* act_sum = nullptr;
@@ -1029,7 +1095,7 @@ static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
     const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
-    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes(PRO == PRO_ACTQ8 ? 32 : a.d_in), a);
+    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), a);
     return 0;
 }
 
@@ -1038,7 +1104,7 @@ template <int WT>
 static int launch_gateup8(const Gemv8Args& a, int n_ffn)
 {
     const dim3 grid(n_ffn / 32), block(512);
-    GTR_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, 1, 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), a);
+    GTR_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), a);
     return 0;
 }
 
@@ -1046,18 +1112,23 @@ static void set_mat(Gemv8Args& a, int k, const void* w, int wdtype, int rows, in
 {
     const size_t nb = (size_t)cols / 32;
     a.qs[k] = (const uint8_t*)w;
-    a.ds[k] = (const uint16_t*)((const uint8_t*)w + (size_t)rows * nb * (wdtype == GTEN_Q4 ? 16 : 32));
+    a.ds[k] = (wdtype == GTEN_F16) ? nullptr
+                                   : (const uint16_t*)((const uint8_t*)w + (size_t)rows * nb * (wdtype == GTEN_Q4 ? 16 : 32));
     a.rows[k] = rows;
 }
 
-// Q8-activation configurations (q8, q4): the register-prologue kernels
+// The register-prologue kernels, all three configurations.  NCH = lane passes over a weight
+// row: 64 quant blocks (2048 elements) per pass for Q8/Q4, one 512-element segment per pass for f16.
 template <int WT>
 static int enqueue_step_q8act(gten_hip_decoder* dc)
 {
     const gten_hip_decoder_desc& d = dc->d;
     const int E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads;
     const size_t kv_pitch = gten_hip_row_bytes(d.adtype, KV);
-    const bool wideF = F > 2048;                  // blocks per row beyond one wave's 64 lanes
+    constexpr bool F16W = (WT == GTEN_F16);
+    constexpr int NE = F16W ? 4 : 1;              // passes over an n_embd-wide row (<= 2048)
+    constexpr int NF = F16W ? 11 : 3;             // passes over an n_ffn-wide row (<= 5632 / 6144)
+    const bool wideF = F16W ? (F > 2048) : (F > 2048);
     float* xbuf = (float*)dc->xbuf;
     float* hbuf = (float*)dc->hbuf;
     int rc;
@@ -1069,10 +1140,10 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = xbuf;
         if (l == 0) {
             a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
-            rc = launch_gemv8<WT, PRO_EMBED, 1, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
+            rc = launch_gemv8<WT, PRO_EMBED, NE, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
         } else {
             a.res_a = hbuf; a.res_raw = dc->down_raw;
-            rc = launch_gemv8<WT, PRO_RESID, 1, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
+            rc = launch_gemv8<WT, PRO_RESID, NE, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
         }
         if (rc) return rc;
         AttnArgs t{};
@@ -1086,24 +1157,25 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         Gemv8Args o{};
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
         o.att_part = dc->att_part; o.d_head = dh; o.n_chunks = dc->n_chunks;
-        if ((rc = launch_gemv8<WT, PRO_ATT, 1, 2, 512>(KT_DEC_GEMV_O, o, E))) return rc;
+        if ((rc = launch_gemv8<WT, PRO_ATT, NE, 2, 512>(KT_DEC_GEMV_O, o, E))) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
         gu.out = nullptr; gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
-        gu.act_q = dc->act_q; gu.act_d = dc->act_d; gu.act_sum = dc->act_sum;
+        gu.act_q = dc->act_q; gu.act_d = dc->act_d; gu.act_sum = dc->act_sum; gu.act_f = dc->act_f;
         if ((rc = launch_gateup8<WT>(gu, F))) return rc;
         Gemv8Args dn{};
         dn.step = dc->step; dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw;
         dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum;
-        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, 3, 2, 256>(KT_DEC_GEMV_DOWN, dn, E)
-                   : launch_gemv8<WT, PRO_ACTQ8, 1, 2, 256>(KT_DEC_GEMV_DOWN, dn, E);
+        dn.act_f = dc->act_f;
+        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, NF, 2, 256>(KT_DEC_GEMV_DOWN, dn, E)
+                   : launch_gemv8<WT, PRO_ACTQ8, NE, 2, 256>(KT_DEC_GEMV_DOWN, dn, E);
         if (rc) return rc;
     }
     Gemv8Args hd{};
     hd.step = dc->step; hd.d_in = E; hd.n_mats = 1; set_mat(hd, 0, d.lm_head, WT, d.n_vocab, E); hd.out = d.logits;
     hd.res_a = hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
-    if ((rc = launch_gemv8<WT, PRO_RESID, 1, 8, 512>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
+    if ((rc = launch_gemv8<WT, PRO_RESID, NE, F16W ? 4 : 8, 512>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
     GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
                dc->n_best, dc->step, dc->result);
     return 0;
@@ -1122,7 +1194,7 @@ static int enqueue_step(gten_hip_decoder* dc)
         a.step = dc->step; a.adtype = d.adtype; a.d_in = E;
         a.m[0] = {L.wq, E}; a.m[1] = {L.wk, KV}; a.m[2] = {L.wv, KV}; a.n_mats = 3;
         a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = dc->xbuf;
-        a.rows_per_wave = 2;
+        a.rows_per_wave = 1;
         int rc;
         if (l == 0) {
             a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
@@ -1144,26 +1216,26 @@ static int enqueue_step(gten_hip_decoder* dc)
         // ---- output projection of the attention row
         GemvArgs o{};
         o.step = dc->step; o.adtype = d.adtype; o.d_in = E; o.m[0] = {L.wo, E}; o.n_mats = 1; o.out = dc->proj_raw;
-        o.att_part = dc->att_part; o.n_heads = d.n_heads; o.d_head = dh; o.n_chunks = dc->n_chunks; o.rows_per_wave = 2;
+        o.att_part = dc->att_part; o.n_heads = d.n_heads; o.d_head = dh; o.n_chunks = dc->n_chunks; o.rows_per_wave = 1;
         if ((rc = launch_gemv<WT, PRO_ATT>(KT_DEC_GEMV_O, o, E))) return rc;
         // ---- h = x + proj ; gate, up of norm(h)
         GemvArgs gu{};
         gu.step = dc->step; gu.adtype = d.adtype; gu.d_in = E;
         gu.m[0] = {L.wgate, F}; gu.m[1] = {L.wup, F}; gu.n_mats = 2; gu.out = dc->gu_raw;
         gu.res_a = dc->xbuf; gu.res_raw = dc->proj_raw; gu.x_out = dc->hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
-        gu.rows_per_wave = 4;
+        gu.rows_per_wave = 1;
         if ((rc = launch_gemv<WT, PRO_RESID>(KT_DEC_GEMV_GATEUP, gu, 2 * F))) return rc;
         // ---- down( silu(gate) * up )
         GemvArgs dn{};
         dn.step = dc->step; dn.adtype = d.adtype; dn.d_in = F; dn.m[0] = {L.wdown, E}; dn.n_mats = 1; dn.out = dc->down_raw;
-        dn.gate_raw = dc->gu_raw; dn.up_raw = dc->gu_raw + F; dn.rows_per_wave = 2;
+        dn.gate_raw = dc->gu_raw; dn.up_raw = dc->gu_raw + F; dn.rows_per_wave = 1;
         if ((rc = launch_gemv<WT, PRO_SILUMUL>(KT_DEC_GEMV_DOWN, dn, E))) return rc;
     }
     // ---- x = h + down ; logits = lm_head(norm(x))
     GemvArgs hd{};
     hd.step = dc->step; hd.adtype = d.adtype; hd.d_in = E; hd.m[0] = {d.lm_head, d.n_vocab}; hd.n_mats = 1; hd.out = d.logits;
     hd.res_a = dc->hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
-    hd.rows_per_wave = 8;
+    hd.rows_per_wave = 2;
     if (int rc = launch_gemv<WT, PRO_RESID>(KT_DEC_GEMV_HEAD, hd, d.n_vocab)) return rc;
     GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)d.logits, (const int*)nullptr, d.n_vocab,
                dc->step, dc->result);
@@ -1173,7 +1245,7 @@ static int enqueue_step(gten_hip_decoder* dc)
 static int enqueue(gten_hip_decoder* dc)
 {
     switch (dc->d.wdtype) {
-    case GTEN_F16: return enqueue_step<GTEN_F16>(dc);
+    case GTEN_F16: return enqueue_step_q8act<GTEN_F16>(dc);
     case GTEN_Q8: return enqueue_step_q8act<GTEN_Q8>(dc);
     case GTEN_Q4: return enqueue_step_q8act<GTEN_Q4>(dc);
     }
@@ -1220,7 +1292,11 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
     GTR_CHECK(hipMalloc((void**)&dc->act_q, (size_t)F));
     GTR_CHECK(hipMalloc((void**)&dc->act_d, (size_t)(F / 32) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->act_sum, (size_t)(F / 32) * 4));
-    dc->n_best = ((d.n_vocab + 63) / 64) * 8;      // lm_head launch: 8 waves x 8 rows per workgroup
+    GTR_CHECK(hipMalloc((void**)&dc->act_f, (size_t)F * 4));
+    {
+        const int head_rows_per_wg = 8 * (d.wdtype == GTEN_F16 ? 4 : 8);   // lm_head launch: 8 waves x R rows
+        dc->n_best = ((d.n_vocab + head_rows_per_wg - 1) / head_rows_per_wg) * 8;
+    }
     GTR_CHECK(hipMalloc((void**)&dc->best_val, (size_t)dc->n_best * 4));
     GTR_CHECK(hipMalloc((void**)&dc->best_idx, (size_t)dc->n_best * 4));
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
@@ -1237,7 +1313,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     if (dc->graph) hipGraphDestroy(dc->graph);
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->gu_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
-                    dc->act_q, dc->act_d, dc->act_sum};
+                    dc->act_q, dc->act_d, dc->act_sum, dc->act_f};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;

@@ -401,18 +401,34 @@ __device__ __forceinline__ float wave_dot_q8(const PackedW w, size_t row, const 
     return wave_sum(acc);
 }
 // f16 weights x f16 activations (activations staged as f32 in LDS, exact).
-// Lane L takes elements [8L, 8L+8) of every 512-element segment.
+// Lane L takes elements [8L, 8L+8) of every 512-element segment; four segments'
+// worth of weights are requested together so a row costs one memory latency per
+// 2048 elements instead of one per 512.
 __device__ __forceinline__ float wave_dot_f16(const uint16_t* wrow, const float* act, int d)
 {
     const int lane = threadIdx.x & 63;
     float acc = 0.f;
-    for (int e = lane * 8; e < d; e += 512) {
-        const uint4 wv = *(const uint4*)(wrow + e);
-        const unsigned u[4] = {wv.x, wv.y, wv.z, wv.w};
+    for (int e0 = lane * 8; e0 < d; e0 += 2048) {
+        uint4 wv[4];
+        bool ok[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            acc += h2f((uint16_t)(u[j] & 0xffffu)) * act[e + 2 * j];
-            acc += h2f((uint16_t)(u[j] >> 16)) * act[e + 2 * j + 1];
+        for (int k = 0; k < 4; k++) {
+            const int e = e0 + 512 * k;
+            ok[k] = e < d;
+            wv[k] = *(const uint4*)(wrow + (ok[k] ? e : e0));      // clamped: no select on loaded data
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!ok[k]) continue;
+            const int e = e0 + 512 * k;
+            const unsigned u[4] = {wv[k].x, wv[k].y, wv[k].z, wv[k].w};
+            const float4 a0 = *(const float4*)(act + e), a1 = *(const float4*)(act + e + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc += h2f((uint16_t)(u[j] & 0xffffu)) * av[2 * j];
+                acc += h2f((uint16_t)(u[j] >> 16)) * av[2 * j + 1];
+            }
         }
     }
     return wave_sum(acc);
