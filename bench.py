@@ -228,13 +228,19 @@ def main():
         per_launch = None
         if fam in per_family_bytes:
             per_launch = per_family_bytes[fam] / (launches / P)
-        avg_us = ms * 1e3 / launches
+        # a bracket = kernel + the two event packets; the latter is calibrated on an empty kernel
+        # bracketed the same way, so that avg_kernel_us is comparable with rocprofv3's AverageNs
+        bracket_us = ms * 1e3 / launches
+        overhead_us = hip.prof_event_overhead_us()
+        avg_us = max(bracket_us - overhead_us, 1e-3)
         achieved = (per_launch / (avg_us * 1e-6) / 1e9) if per_launch else None
         roofline = {"bound": "hbm", "kernel": fam, "achieved": round(achieved, 1) if achieved else None,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
-                    "traffic": None, "avg_launch_us": round(avg_us, 3), "launches_per_step": launches // P,
+                    "traffic": None, "avg_launch_us": round(avg_us, 3), "event_bracket_us": round(bracket_us, 3),
+                    "event_overhead_us": round(overhead_us, 3), "launches_per_step": launches // P,
                     "algorithmic_bytes_per_launch": int(per_launch) if per_launch else None,
-                    "kernel_time_share_of_step": {k: round(v[1] / P / (elapsed / K * 1e3), 3) for k, v in prof.items()}}
+                    "kernel_time_share_of_step": {k: round(max(v[1] - v[0] * overhead_us * 1e-3, 0.0) / P / (elapsed / K * 1e3), 3)
+                                                  for k, v in prof.items()}}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
