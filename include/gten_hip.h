@@ -163,6 +163,10 @@ int gten_hip_decoder_set_tokens(gten_hip_decoder* dec, const int32_t* tokens_hos
 /* asynchronous: computes row n-1, logits and their argmax.  use_graph != 0
  * replays the captured hipGraph (captured on first use). */
 int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
+/* HIP-event timing of one kernel family of the step (family index as in gten_hip_prof_family_name):
+ * `reps` replays of a graph holding only that family's launches at context length n, bracketed by
+ * two events on the library's stream; *avg_us = elapsed / (reps * launches per replay). */
+int gten_hip_decoder_time_family(gten_hip_decoder* dec, int family, int n, int reps, double* avg_us, int* launches_per_replay);
 /* waits for the stream and returns the argmax produced by step n */
 int gten_hip_decoder_result(gten_hip_decoder* dec, int n, int32_t* argmax_host);
 

@@ -65,6 +65,9 @@ int gten_host_model_decode_begin(gten_host_model* m, const int32_t* tokens, int 
 int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph);          /* asynchronous */
 int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out);  /* waits */
 
+/* HIP-event timing of one kernel family of the decode step (see gten_hip_decoder_time_family) */
+int gten_host_model_time_family(gten_host_model* m, int family, int n, int reps, double* avg_us, int* launches);
+
 /* synthetic weight tensor `idx` of a model with config `cfg`, in storage layout */
 int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes);
 /* the same weights as a .gten file (tinyllama_to_gten.py:94-201 layout) */

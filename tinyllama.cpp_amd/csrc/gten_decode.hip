@@ -9,8 +9,10 @@
 //   * every W.x kernel writes its raw f32 dot products; the element-wise chain
 //     that follows in the reference (write in activation dtype -> residual add
 //     -> RMSNorm -> write ...) is recomputed by each workgroup of the NEXT
-//     kernel in its prologue, entirely on chip (it is 2048..5632 elements), so
-//     no kernel waits on a 1-workgroup element-wise launch;
+//     kernel in its prologue, entirely on chip (2048 elements, in registers),
+//     so no kernel waits on a 1-workgroup element-wise launch; the one long
+//     chain (silu(gate)*up over 5632 elements) runs once per 32-wide slice in
+//     the gate/up kernel's EPILOGUE and is handed to the down projection staged;
 //   * the step's position n comes from device memory, so one captured
 //     hipGraph replays for every n (no per-step host work beyond one launch);
 //   * attention is split over (head, 256-position chunk); probabilities are
@@ -31,17 +33,22 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
 
 #define DEC_CHUNK 256            // attention positions per workgroup
 
+// launches of a decode step can be restricted to one kernel family (gten_hip_decoder_time_family)
+static int g_only_family = -1;
+#define DEC_LAUNCH(tag, kernel, grid, block, smem, ...)                                        \
+    do {                                                                                       \
+        if (g_only_family < 0 || g_only_family == (tag)) GTR_LAUNCH(tag, kernel, grid, block, smem, __VA_ARGS__); \
+    } while (0)
+
 struct DecStep {
     int n;                        // context length of this step; the new row is n-1
     int advance;                  // argmax kernel bumps n afterwards (free-running replay)
 };
 
-// ---------------------------------------------------------------- prologues
+// ---------------------------------------------------------------- LDS stage
 //
-// All prologues leave the W.x input vector staged in LDS: ActQ8 form for Q8
+// Every prologue leaves the W.x input vector staged in LDS: ActQ8 form for Q8
 // activations, an f32 row (of exact fp16 values) for f16 activations.
-// `row` is an f32 LDS scratch row of length d.  Thread t owns elements
-// t, t+256, ... in every element-wise step, so only reductions need barriers.
 
 struct ActStage {
     float* row;                   // d floats
@@ -59,161 +66,12 @@ __device__ __forceinline__ ActStage carve_stage(int d)
 }
 static size_t stage_bytes(int d) { return 64 + (size_t)d * 4 + (size_t)(d >> 5) * 40; }
 
-// final step of every prologue: the (unrounded) f32 row becomes the staged input
-__device__ __forceinline__ void finish_stage(ActStage s, int adtype, int d)
-{
-    if (adtype == GTEN_Q8) quantize_to_actq8(s.row, d >> 5, s.q8);
-    else round_row_inplace(s.row, GTEN_F16, d);
-    __syncthreads();
-}
-
-// RMSNorm of s.row in place (gten/ops.h:762-778)
-__device__ __forceinline__ void rms_norm_row(ActStage s, const uint16_t* __restrict__ w, int d)
-{
-    const float ss = block_sum_tree(row_sumsq8(s.row, d), s.red);
-    const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);     // see k_rms_norm
-    for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = s.row[i] * inv * h2f(w[i]);
-}
-
-// x = embedding row of the step's token, in activation dtype (gten/ops.h:514-533)
-template <int WT>
-__device__ __forceinline__ void pro_embed(ActStage s, const void* table, int n_vocab, int tok, int adtype, int d)
-{
-    const int nb = d >> 5;
-    if (WT == GTEN_F16) {
-        const uint16_t* src = (const uint16_t*)table + (size_t)tok * d;
-        for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = h2f(src[i]);
-    } else if (WT == GTEN_Q8) {
-        const PackedW p = packed_view(table, GTEN_Q8, n_vocab, d);
-        const uint8_t* q0 = p.qs + (size_t)tok * nb * 32;
-        for (int i = threadIdx.x; i < d; i += blockDim.x) {
-            const int b = i >> 5, e = i & 31;
-            const int qv = (int)(int8_t)q0[(size_t)(e >> 4) * nb * 16 + (size_t)b * 16 + (e & 15)];
-            s.row[i] = (float)qv * h2f(p.ds[(size_t)tok * nb + b]);      // copied blocks dequantize to this
-        }
-    } else {
-        const PackedW p = packed_view(table, GTEN_Q4, n_vocab, d);
-        const uint8_t* q = p.qs + (size_t)tok * nb * 16;
-        for (int i = threadIdx.x; i < d; i += blockDim.x) {
-            const int b = i >> 5, e = i & 31;
-            const uint8_t byte = q[(size_t)b * 16 + (e & 15)];
-            const int nib = (e < 16) ? (byte >> 4) : (byte & 0x0f);
-            s.row[i] = (float)(nib - 7) * h2f(p.ds[(size_t)tok * nb + b]);
-        }
-        round_row_inplace(s.row, adtype, d);     // Q4 row is re-quantized to Q8 (gten/ops.h:522-528)
-    }
-}
-
-// x = write(add(a, write(raw)))  i.e. Linear output in activation dtype, then
-// the residual add, then stored (gten/modules.cpp:33-43, 52-63)
-__device__ __forceinline__ void pro_residual(ActStage s, const uint8_t* __restrict__ a, const float* __restrict__ raw, int adtype, int d)
-{
-    for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = raw[i];
-    round_row_inplace(s.row, adtype, d);
-    for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = load_elem(a, adtype, i) + s.row[i];
-}
-
-// ------------------------------------------------------------ GEMV kernels
-
-struct GemvMat { const void* w; int rows; };
-
-template <int WT>
-__device__ __forceinline__ float dec_dot(const void* w, int rows, int d_in, int r, const ActStage& s)
-{
-    if (WT == GTEN_F16) return wave_dot_f16((const uint16_t*)w + (size_t)r * d_in, s.row, d_in);
-    const PackedW pw = packed_view(w, WT, rows, d_in);
-    if (WT == GTEN_Q8) return wave_dot_q8(pw, (size_t)r, s.q8);
-    return wave_dot_q4(pw, (size_t)r, s.q8);
-}
-
-enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_SILUMUL = 3, PRO_ACTQ8 = 4 };
+enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_ACTQ8 = 4 };
 enum { EPI_RAW = 0, EPI_SILUMUL = 1 };
 
-struct GemvArgs {
-    const DecStep* step;
-    // matrices computed by this launch, outputs are concatenated in `out`
-    GemvMat m[3];
-    int n_mats;
-    int d_in;
-    float* out;                   // raw f32 dot products
-    int adtype;
-    // prologue inputs
-    const void* table; int n_vocab; const int32_t* tokens;     // PRO_EMBED
-    const uint8_t* res_a; const float* res_raw;                 // PRO_RESID
-    uint8_t* x_out;                                             // PRO_EMBED/PRO_RESID: the new residual row (storage dtype)
-    const uint16_t* norm_w;                                     // PRO_EMBED/PRO_RESID
-    const float* att_part; int n_heads, d_head, n_chunks;       // PRO_ATT
-    const float* gate_raw; const float* up_raw;                 // PRO_SILUMUL
-    int rows_per_wave;
-};
-
-template <int WT, int PRO>
-__global__ __launch_bounds__(256) void k_dec_gemv(const GemvArgs a)
-{
-    const int d = a.d_in;
-    ActStage s = carve_stage(d);
-    const int n = a.step->n;
-
-    if (PRO == PRO_EMBED || PRO == PRO_RESID) {
-        if (PRO == PRO_EMBED) pro_embed<WT>(s, a.table, a.n_vocab, a.tokens[n - 1], a.adtype, d);
-        else pro_residual(s, a.res_a, a.res_raw, a.adtype, d);
-        // the residual stream row is stored once, by workgroup 0, for the later add
-        if (a.x_out && blockIdx.x == 0) store_row(s.row, a.adtype, d, a.x_out);
-        round_row_inplace(s.row, a.adtype, d);
-        if (a.norm_w) {
-            rms_norm_row(s, a.norm_w, d);
-        }
-    } else if (PRO == PRO_ATT) {
-        // attention output row = sum of the per-chunk partials (fixed order)
-        const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-        for (int i = threadIdx.x; i < d; i += blockDim.x) {
-            const int h = i / a.d_head, e = i % a.d_head;
-            float v = 0.f;
-            for (int j = 0; j < nch; j++) v += a.att_part[((size_t)h * a.n_chunks + j) * a.d_head + e];
-            s.row[i] = v;
-        }
-    } else {
-        // silu(write(gate)) then * write(up), each written in the activation dtype
-        // (gten/modules.cpp:238-247: silu and mul are in place on the gate buffer)
-        for (int i = threadIdx.x; i < d; i += blockDim.x) s.row[i] = a.gate_raw[i];
-        round_row_inplace(s.row, a.adtype, d);
-        for (int i = threadIdx.x; i < d; i += blockDim.x) { const float x = s.row[i]; s.row[i] = x / (1.0f + expf(-x)); }
-        round_row_inplace(s.row, a.adtype, d);
-        // up: round in registers with the same 32-lane grouping
-        const int padded = d;   // d % 32 == 0
-        for (int i = threadIdx.x; i < padded; i += blockDim.x) {
-            float u = a.up_raw[i];
-            if (a.adtype == GTEN_Q8) {
-                const float amax = group_max<32>(fabsf(u));
-                const Q8Scale sc = q8_scale_from_absmax(amax);
-                u = (float)q8_round(u, sc.scale) * sc.ddeq;
-            } else {
-                u = h2f(f2h(u));
-            }
-            s.row[i] = s.row[i] * u;
-        }
-    }
-    finish_stage(s, a.adtype, d);
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int rpw = a.rows_per_wave;
-    const int r0 = (blockIdx.x * 4 + wid) * rpw;
-    int total = 0;
-    for (int k = 0; k < a.n_mats; k++) total += a.m[k].rows;
-    for (int j = 0; j < rpw; j++) {
-        const int r = r0 + j;
-        if (r >= total) break;
-        int lr = r, k = 0;
-        while (lr >= a.m[k].rows) { lr -= a.m[k].rows; k++; }
-        const float v = dec_dot<WT>(a.m[k].w, a.m[k].rows, d, lr, s);
-        if (lane == 0) a.out[r] = v;
-    }
-}
-
-// -------------------------------------------- GEMV kernels, Q8 activations
+// ------------------------------------------------------------ W.x kernels
 //
-// The q8/q4 configurations' W.x kernel.  Differences from k_dec_gemv above are
-// organisational only (same values, same rounding points):
+// One kernel template for every W.x launch of the step, all three configurations:
 //   * the wave's weight rows are requested from HBM FIRST, then the prologue
 //     runs while they are in flight (hipcc's __syncthreads() here is
 //     lgkmcnt(0)+s_barrier, so the loads stay outstanding across it);
@@ -1056,20 +914,12 @@ struct gten_hip_decoder {
     int* best_idx = nullptr;
     int n_best = 0;
     int dev_n = -1;                // value of step->n on the device after the queued work (-1: unknown)
+    int only_family = -1;          // >= 0: enqueue only the launches of this kernel family (timing replays)
     int n_chunks = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const float2* rope = nullptr;
 };
-
-template <int WT, int PRO>
-static int launch_gemv(int tag, const GemvArgs& a, int total_rows)
-{
-    const int rows_per_wg = 4 * a.rows_per_wave;
-    const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(256);
-    GTR_LAUNCH(tag, (k_dec_gemv<WT, PRO>), grid, block, stage_bytes(a.d_in), a);
-    return 0;
-}
 
 static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
 {
@@ -1077,16 +927,16 @@ static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
         const size_t nw = (t.adtype == GTEN_Q8) ? 17 : 32;
         const size_t smem2 = (size_t)2 * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * nw * 4;
         if (t.adtype == GTEN_Q8) {
-            GTR_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_Q8>), agrid, dim3(256), smem1, t);
-            GTR_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_Q8>), agrid, dim3(256), smem2, t);
+            DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_Q8>), agrid, dim3(256), smem1, t);
+            DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_Q8>), agrid, dim3(256), smem2, t);
         } else {
-            GTR_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_F16>), agrid, dim3(256), smem1, t);
-            GTR_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_F16>), agrid, dim3(256), smem2, t);
+            DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_F16>), agrid, dim3(256), smem1, t);
+            DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_F16>), agrid, dim3(256), smem2, t);
         }
         return 0;
     }
-    GTR_LAUNCH(KT_DEC_ATTN_SCORE, k_dec_attn_score, agrid, dim3(256), smem1, t);
-    GTR_LAUNCH(KT_DEC_ATTN_PV, k_dec_attn_pv, agrid, dim3(256), (size_t)2 * DEC_CHUNK * 4, t);
+    DEC_LAUNCH(KT_DEC_ATTN_SCORE, k_dec_attn_score, agrid, dim3(256), smem1, t);
+    DEC_LAUNCH(KT_DEC_ATTN_PV, k_dec_attn_pv, agrid, dim3(256), (size_t)2 * DEC_CHUNK * 4, t);
     return 0;
 }
 
@@ -1095,7 +945,7 @@ static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
     const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
-    GTR_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), a);
+    DEC_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), a);
     return 0;
 }
 
@@ -1104,7 +954,7 @@ template <int WT>
 static int launch_gateup8(const Gemv8Args& a, int n_ffn)
 {
     const dim3 grid(n_ffn / 32), block(512);
-    GTR_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), a);
+    DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), a);
     return 0;
 }
 
@@ -1176,69 +1026,8 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
     hd.res_a = hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
     if ((rc = launch_gemv8<WT, PRO_RESID, NE, F16W ? 4 : 8, 512>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
-    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
+    DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
                dc->n_best, dc->step, dc->result);
-    return 0;
-}
-
-template <int WT>
-static int enqueue_step(gten_hip_decoder* dc)
-{
-    const gten_hip_decoder_desc& d = dc->d;
-    const int E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads;
-    const size_t kv_pitch = gten_hip_row_bytes(d.adtype, KV);
-    for (int l = 0; l < d.n_layers; l++) {
-        const gten_hip_layer_ptrs& L = dc->layers[l];
-        // ---- q,k,v projections of norm(x)
-        GemvArgs a{};
-        a.step = dc->step; a.adtype = d.adtype; a.d_in = E;
-        a.m[0] = {L.wq, E}; a.m[1] = {L.wk, KV}; a.m[2] = {L.wv, KV}; a.n_mats = 3;
-        a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = dc->xbuf;
-        a.rows_per_wave = 1;
-        int rc;
-        if (l == 0) {
-            a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
-            rc = launch_gemv<WT, PRO_EMBED>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
-        } else {
-            a.res_a = dc->hbuf; a.res_raw = dc->down_raw;
-            rc = launch_gemv<WT, PRO_RESID>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
-        }
-        if (rc) return rc;
-        // ---- attention over the caches
-        AttnArgs t{};
-        t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kcache = (uint8_t*)L.kcache; t.vcache = (uint8_t*)L.vcache;
-        t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats; t.att_part = dc->att_part; t.rope = dc->rope;
-        t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
-        t.n_chunks = dc->n_chunks; t.n_embd = E;
-        const dim3 agrid(d.n_heads, dc->n_chunks);
-        const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        if (int arc = launch_attention(t, agrid, smem1)) return arc;
-        // ---- output projection of the attention row
-        GemvArgs o{};
-        o.step = dc->step; o.adtype = d.adtype; o.d_in = E; o.m[0] = {L.wo, E}; o.n_mats = 1; o.out = dc->proj_raw;
-        o.att_part = dc->att_part; o.n_heads = d.n_heads; o.d_head = dh; o.n_chunks = dc->n_chunks; o.rows_per_wave = 1;
-        if ((rc = launch_gemv<WT, PRO_ATT>(KT_DEC_GEMV_O, o, E))) return rc;
-        // ---- h = x + proj ; gate, up of norm(h)
-        GemvArgs gu{};
-        gu.step = dc->step; gu.adtype = d.adtype; gu.d_in = E;
-        gu.m[0] = {L.wgate, F}; gu.m[1] = {L.wup, F}; gu.n_mats = 2; gu.out = dc->gu_raw;
-        gu.res_a = dc->xbuf; gu.res_raw = dc->proj_raw; gu.x_out = dc->hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
-        gu.rows_per_wave = 1;
-        if ((rc = launch_gemv<WT, PRO_RESID>(KT_DEC_GEMV_GATEUP, gu, 2 * F))) return rc;
-        // ---- down( silu(gate) * up )
-        GemvArgs dn{};
-        dn.step = dc->step; dn.adtype = d.adtype; dn.d_in = F; dn.m[0] = {L.wdown, E}; dn.n_mats = 1; dn.out = dc->down_raw;
-        dn.gate_raw = dc->gu_raw; dn.up_raw = dc->gu_raw + F; dn.rows_per_wave = 1;
-        if ((rc = launch_gemv<WT, PRO_SILUMUL>(KT_DEC_GEMV_DOWN, dn, E))) return rc;
-    }
-    // ---- x = h + down ; logits = lm_head(norm(x))
-    GemvArgs hd{};
-    hd.step = dc->step; hd.adtype = d.adtype; hd.d_in = E; hd.m[0] = {d.lm_head, d.n_vocab}; hd.n_mats = 1; hd.out = d.logits;
-    hd.res_a = dc->hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
-    hd.rows_per_wave = 2;
-    if (int rc = launch_gemv<WT, PRO_RESID>(KT_DEC_GEMV_HEAD, hd, d.n_vocab)) return rc;
-    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)d.logits, (const int*)nullptr, d.n_vocab,
-               dc->step, dc->result);
     return 0;
 }
 
@@ -1352,6 +1141,49 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
         GTR_CHECK(hipGraphInstantiate(&dc->exec, dc->graph, nullptr, nullptr, 0));
     }
     GTR_CHECK(hipGraphLaunch(dc->exec, stream()));
+    return 0;
+}
+
+// Average duration of ONE kernel family of the decode step, timed with two HIP events on the
+// library's stream around `reps` replays of a graph that contains only that family's launches
+// (22 per replay for a per-block kernel).  The kernels run on whatever the last step left in the
+// scratch buffers: their timing does not depend on the values.
+int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int reps, double* avg_us, int* launches_per_replay)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && avg_us && reps > 0 && n >= 1 && n <= dc->d.max_ctx, "decoder_time_family: bad arguments");
+    GTR_REQUIRE(!prof_on(), "decoder_time_family: switch the per-launch profiler off first");
+    const DecStep st{n, 0};
+    GTR_CHECK(hipMemcpyAsync(dc->step, &st, sizeof(st), hipMemcpyHostToDevice, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    dc->dev_n = -1;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    g_only_family = family;
+    GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue(dc);
+    const hipError_t e = hipStreamEndCapture(stream(), &g);
+    g_only_family = -1;
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    GTR_CHECK(e);
+    size_t n_nodes = 0;
+    GTR_CHECK(hipGraphGetNodes(g, nullptr, &n_nodes));
+    GTR_REQUIRE(n_nodes > 0, "decoder_time_family: family %d has no launch in a decode step", family);
+    GTR_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t a, b;
+    GTR_CHECK(hipEventCreate(&a));
+    GTR_CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) GTR_CHECK(hipGraphLaunch(ge, stream()));
+    GTR_CHECK(hipEventRecord(a, stream()));
+    for (int i = 0; i < reps; i++) GTR_CHECK(hipGraphLaunch(ge, stream()));
+    GTR_CHECK(hipEventRecord(b, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    float ms = 0.f;
+    GTR_CHECK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    *avg_us = (double)ms * 1e3 / ((double)reps * (double)n_nodes);
+    if (launches_per_replay) *launches_per_replay = (int)n_nodes;
     return 0;
 }
 

@@ -83,7 +83,7 @@ class GtenHip:
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
         # the export check covers the whole header
         "gten_hip_decoder_create", "gten_hip_decoder_destroy", "gten_hip_decoder_set_tokens",
-        "gten_hip_decoder_step", "gten_hip_decoder_result",
+        "gten_hip_decoder_step", "gten_hip_decoder_result", "gten_hip_decoder_time_family",
     ]
 
     def __init__(self, path=None):
@@ -149,6 +149,16 @@ class GtenHip:
         us = C.c_double(0.0)
         self._check(self._prof_ovh(C.byref(us)))
         return us.value
+
+    def prof_family_index(self, wanted):
+        fam = 0
+        while True:
+            name = self._prof_name(fam)
+            if name is None:
+                raise KeyError(wanted)
+            if name.decode() == wanted:
+                return fam
+            fam += 1
 
     def prof_read(self):
         """{family name: (launches, total_ms)} for every family with at least one launch."""

@@ -125,6 +125,13 @@ int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph)
     return 0;
 }
 
+int gten_host_model_time_family(gten_host_model* m, int family, int n, int reps, double* avg_us, int* launches)
+{
+    if (!avg_us) return -1;
+    *avg_us = m->model->decode_time_family(family, n, reps, launches);
+    return 0;
+}
+
 int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out)
 {
     if (!argmax_out) return -1;

@@ -88,6 +88,14 @@ public:
         ensure_decoder();
         GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
     }
+    // HIP-event timed replay of one kernel family of the decode step (bench.py roofline)
+    double decode_time_family(int family, int n, int reps, int* launches)
+    {
+        ensure_decoder();
+        double us = 0.0;
+        GTEN_HIP_OK(gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches));
+        return us;
+    }
     int decode_result(int n)
     {
         ensure_decoder();

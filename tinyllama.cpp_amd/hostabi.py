@@ -36,7 +36,7 @@ class GtenHost:
         "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy",
         "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
-        "gten_host_model_decode_result",
+        "gten_host_model_decode_result", "gten_host_model_time_family",
     ]
 
     def __init__(self, path=None):
@@ -61,6 +61,7 @@ class GtenHost:
         self._dbegin = _sig(L, "gten_host_model_decode_begin", ci, [vp, vp, ci])
         self._dstep = _sig(L, "gten_host_model_decode_step", ci, [vp, ci, ci])
         self._dresult = _sig(L, "gten_host_model_decode_result", ci, [vp, ci, C.POINTER(C.c_int32)])
+        self._timefam = _sig(L, "gten_host_model_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
         self._synthw = _sig(L, "gten_host_synth_weight", ci, [cfgp, C.c_uint64, ci, vp, sz])
         self._writeg = _sig(L, "gten_host_write_gten", ci, [cfgp, C.c_uint64, C.c_char_p])
         self._stoks = _sig(L, "gten_host_synthetic_tokens", None, [vp, ci, C.c_uint32, ci])
@@ -153,6 +154,14 @@ class HostModel:
         if rc:
             raise GtenHipError(f"decode_result({n}) rc={rc}")
         return out.value
+
+    def time_family(self, family, n, reps=20):
+        """(average us per launch, launches per replay) of one kernel family, HIP-event timed"""
+        us, cnt = C.c_double(0.0), C.c_int(0)
+        rc = self.host._timefam(self.h, family, n, reps, C.byref(us), C.byref(cnt))
+        if rc:
+            raise GtenHipError(f"time_family rc={rc}")
+        return us.value, cnt.value
 
     def greedy(self, prompt, max_tokens, eos=-1):
         buf = np.zeros(max_tokens, np.int32)
