@@ -155,11 +155,22 @@ typedef struct {
 
 typedef struct gten_hip_decoder gten_hip_decoder;
 
+/* K/V caches of one (sequence, layer) for multi-sequence decode */
+typedef struct { void* kcache; void* vcache; } gten_hip_kv_ptrs;
+
 int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, gten_hip_decoder** out);
+/* Multi-sequence decode: n_seq in {2, 4, 8} independent sequences, each with
+ * its own K/V caches (kv[seq * n_layers + layer]) and token ids, advance by one token per step and
+ * SHARE every weight pass (weights are streamed once per step, not once per sequence).  Per sequence
+ * the results are bit-identical to the single-sequence decoder.  desc->logits is ignored: read a
+ * sequence's logits with gten_hip_decoder_logits_seq.  All sequences are at the same position n. */
+int gten_hip_decoder_create_multi(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers,
+                                  const gten_hip_kv_ptrs* kv, int n_seq, gten_hip_decoder** out);
 int gten_hip_decoder_destroy(gten_hip_decoder* dec);
 /* token ids (host) for positions [first, first+count): the step for context
  * length n embeds token[n-1]. */
 int gten_hip_decoder_set_tokens(gten_hip_decoder* dec, const int32_t* tokens_host, int first, int count);
+int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dec, int seq, const int32_t* tokens_host, int first, int count);
 /* asynchronous: computes row n-1, logits and their argmax.  use_graph != 0
  * replays the captured hipGraph (captured on first use). */
 int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
@@ -169,6 +180,9 @@ int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
 int gten_hip_decoder_time_family(gten_hip_decoder* dec, int family, int n, int reps, double* avg_us, int* launches_per_replay);
 /* waits for the stream and returns the argmax produced by step n */
 int gten_hip_decoder_result(gten_hip_decoder* dec, int n, int32_t* argmax_host);
+int gten_hip_decoder_result_seq(gten_hip_decoder* dec, int seq, int n, int32_t* argmax_host);
+/* waits for the stream and copies the f32 logits of the last step of `seq` to the host */
+int gten_hip_decoder_logits_seq(gten_hip_decoder* dec, int seq, float* logits_host);
 
 #ifdef __cplusplus
 }

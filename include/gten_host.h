@@ -65,6 +65,24 @@ int gten_host_model_decode_begin(gten_host_model* m, const int32_t* tokens, int 
 int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph);          /* asynchronous */
 int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out);  /* waits */
 
+/* ---- several sequences on one GPU sharing one copy of the weights.
+ * n_seq in {2, 4, 8}.  Every sequence is a full model object of the gten API with its own K/V
+ * caches; their weight tensors alias sequence 0's storage.  One decode step advances ALL sequences
+ * by one token and streams every weight once.  Per sequence the results are bit-identical to
+ * gten_host_model_decode_* on a model of its own. */
+typedef struct gten_host_batch gten_host_batch;
+gten_host_batch* gten_host_batch_create(const gten_host_config* cfg, int n_seq);
+void gten_host_batch_free(gten_host_batch* b);
+int  gten_host_batch_load_synthetic(gten_host_batch* b, uint64_t seed);
+int  gten_host_batch_set_weight(gten_host_batch* b, int idx, const void* bytes, size_t nbytes);  /* idx ascending */
+/* prompt of sequence `seq` through the operator path (fills its caches); logits_out may be NULL */
+int  gten_host_batch_prefill(gten_host_batch* b, int seq, const int32_t* tokens, int n, float* logits_out);
+int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
+int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
+int  gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out); /* waits */
+int  gten_host_batch_logits(gten_host_batch* b, int seq, float* logits_out);                /* waits; f32[n_vocab] */
+int  gten_host_batch_time_family(gten_host_batch* b, int family, int n, int reps, double* avg_us, int* launches);
+
 /* HIP-event timing of one kernel family of the decode step (see gten_hip_decoder_time_family) */
 int gten_host_model_time_family(gten_host_model* m, int family, int n, int reps, double* avg_us, int* launches);
 

@@ -1,0 +1,70 @@
+"""-m gpu: multi-sequence decode (several sequences share every weight pass) against the
+single-sequence decoder: per sequence the logits must be BIT-IDENTICAL (same arithmetic in the same
+order; only the weights are streamed once instead of once per sequence)."""
+import numpy as np
+import pytest
+
+from gpu_common import hip  # noqa: F401
+from __graft_entry__ import load_package
+from helpers import MODES, tiny_config
+from test_model_gpu import host_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+@pytest.mark.parametrize("n_seq", [2, 4, 8])
+def test_each_sequence_matches_its_own_single_sequence_decode(hip, name, wd, ad, n_seq):
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    batch = host.batch(cfg, n_seq)
+    singles = [host.model(cfg) for _ in range(n_seq)]
+    for i in range(len(cfg.weight_shapes())):
+        w = host.synth_weight(cfg, 555, i)
+        batch.set_weight(i, w)
+        for m in singles:
+            m.set_weight(i, w)
+    P, N = 7, 270                                   # crosses the 256-position attention chunk boundary
+    streams = [host.synthetic_tokens(N, seed=100 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
+    for q in range(n_seq):
+        a = batch.prefill(q, streams[q][:P])        # operator path, sequence q's own caches
+        b = singles[q].logits(streams[q][:P], 0)
+        assert np.array_equal(a, b), (name, q, "prefill")
+        batch.decode_begin(q, streams[q])
+        singles[q].decode_begin(streams[q])
+    checks = (P + 1, P + 2, 40, 255, 256, 257, N)
+    for n in range(P + 1, N + 1):
+        batch.decode_step(n, True)
+        for m in singles:
+            m.decode_step(n, True)
+        if n in checks:
+            for q in range(n_seq):
+                assert batch.decode_result(q, n) == singles[q].decode_result(n), (name, n_seq, q, n)
+                got = batch.logits(q)
+                want = singles[q].logits(streams[q][:n], n - 1)      # recomputes row n-1 (same bytes) and copies logits
+                assert np.array_equal(got, want), (name, n_seq, q, n, float(np.abs(got - want).max()))
+    # sequences really are independent: different streams gave different logits
+    assert not np.array_equal(batch.logits(0), batch.logits(1))
+    batch.close()
+    for m in singles:
+        m.close()
+
+
+def test_multiseq_graph_replay_equals_eager(hip):
+    from helpers import Q4, Q8
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=64, n_layers=2))
+    res = []
+    for use_graph in (True, False):
+        b = host.batch(cfg, 4)
+        for i in range(len(cfg.weight_shapes())):
+            b.set_weight(i, host.synth_weight(cfg, 9, i))
+        for q in range(4):
+            b.decode_begin(q, host.synthetic_tokens(40, seed=q + 1, n_vocab=cfg.n_vocab))
+        for n in range(1, 41):
+            b.decode_step(n, use_graph)
+        res.append([[b.decode_result(q, n) for n in (1, 2, 17, 40)] for q in range(4)])
+        b.close()
+    assert res[0] == res[1]

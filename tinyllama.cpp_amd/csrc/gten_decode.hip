@@ -67,7 +67,7 @@ __device__ __forceinline__ ActStage carve_stage(int d)
 static size_t stage_bytes(int d) { return 64 + (size_t)d * 4 + (size_t)(d >> 5) * 40; }
 
 enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_ACTQ8 = 4 };
-enum { EPI_RAW = 0, EPI_SILUMUL = 1 };
+enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2 };
 
 // ------------------------------------------------------------ W.x kernels
 //
@@ -98,6 +98,13 @@ struct Gemv8Args {
     // EPI_SILUMUL writes / PRO_ACTQ8 reads the staged FFN activation in HBM (ActQ8 layout)
     int8_t* act_q; float* act_d; int* act_sum;
     float* act_f;                                               // same for f16 activations: f32 row of exact f16 values
+    // multi-sequence decode (EPI_STAGE / k_dec_gemvm): element strides between consecutive sequences
+    int raw_stride;               // res_raw / out rows
+    int tok_stride;               // token id rows
+    int part_stride;              // att_part
+    int best_stride;              // best_val / best_idx
+    // k_dec_gemvm + EPI_SILUMUL: where the FFN activation is staged (its INPUT stage is act_*)
+    int8_t* out_q; float* out_d; int* out_sum; float* out_f;
 };
 
 // ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
@@ -234,7 +241,22 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     const int d = a.d_in, nb = d >> 5;
     ActStage s = carve_stage((PRO == PRO_ACTQ8 && !F16W) ? 32 : d);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n = a.step->n;
+    // EPI_STAGE: one workgroup per SEQUENCE runs only the prologue and leaves the staged vector in
+    // HBM for the multi-sequence W.x kernel (k_dec_gemvm), which then needs no prologue of its own
+    const int seq = (EPI == EPI_STAGE) ? blockIdx.x : 0;
+    const int n = a.step[seq].n;
+    const float* res_raw = a.res_raw + (size_t)seq * a.raw_stride;
+    const float* res_a = a.res_a + (size_t)seq * d;
+    float* x_out = a.x_out ? a.x_out + (size_t)seq * d : nullptr;
+    const int32_t* tokens = a.tokens + (size_t)seq * a.tok_stride;
+    const float* att_part = a.att_part + (size_t)seq * a.part_stride;
+    if (EPI == EPI_STAGE) {
+        s.q8.q = a.act_q + (size_t)seq * d;
+        s.q8.d = a.act_d + (size_t)seq * nb;
+        s.q8.sum = a.act_sum + (size_t)seq * nb;
+        if (F16W) s.row = a.act_f + (size_t)seq * d;
+    }
+    const bool stores_x = (EPI == EPI_STAGE) || blockIdx.x == 0;
     const int gi = threadIdx.x, base = gi * EPT, blk = gi / LPB, sub = gi % LPB;
     const bool on = base < d;                     // lanes past the row re-read group 0 (never used):
     const int sbase = on ? base : 0;              // an unconditional load has no select on its result
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     float pin0[EPT], pin1[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; i++) { pin0[i] = 0.f; pin1[i] = 0.f; }
-    if (PRO == PRO_RESID) { ldN<EPT>(a.res_raw + sbase, pin0); ldN<EPT>(a.res_a + sbase, pin1); }
+    if (PRO == PRO_RESID) { ldN<EPT>(res_raw + sbase, pin0); ldN<EPT>(res_a + sbase, pin1); }
     unsigned nw[4] = {0, 0, 0, 0};
     if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
         if (EPT == 8) { const uint4 t = *(const uint4*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; nw[2] = t.z; nw[3] = t.w; }
@@ -252,12 +274,12 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     unsigned emb[4] = {0, 0, 0, 0};
     float emb_delta = 0.f;
     if (PRO == PRO_EMBED && F16W) {
-        const uint16_t* src = (const uint16_t*)a.table + (size_t)a.tokens[n - 1] * d + sbase;
+        const uint16_t* src = (const uint16_t*)a.table + (size_t)tokens[n - 1] * d + sbase;
         if (EPT == 8) { const uint4 t = *(const uint4*)src; emb[0] = t.x; emb[1] = t.y; emb[2] = t.z; emb[3] = t.w; }
         else { const uint2 t = *(const uint2*)src; emb[0] = t.x; emb[1] = t.y; }
     }
     if (PRO == PRO_EMBED && !F16W) {
-        const int tok = a.tokens[n - 1];
+        const int tok = tokens[n - 1];
         const int sb = on ? blk : 0, ssub = on ? sub : 0;
         // high nibbles are elements 0..15, low nibbles 16..31 (gten/quants.h:78-90); Q8 planes hold 16 bytes each
         const int byte0 = (ssub * EPT) & 15;      // first source byte inside the 16-byte half
@@ -284,6 +306,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     uint16_t wd[R][NCH];
 #pragma unroll
     for (int j = 0; j < R; j++) {
+        if (EPI == EPI_STAGE) break;              // no W.x in a staging launch
         int lr = r0 + j;
         const bool ok = lr < total;
         const uint8_t* qbase = a.qs[0];
@@ -350,14 +373,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
             for (int i = 0; i < EPT; i++) v[i] = 0.f;
             for (int j = 0; j < nch; j++) {
                 float t[EPT];
-                ldN<EPT>(a.att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
+                ldN<EPT>(att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
 #pragma unroll
                 for (int i = 0; i < EPT; i++) v[i] += t[i];
             }
         }
         if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
             if (on) {
-                if (a.x_out && blockIdx.x == 0) stN<EPT>(a.x_out + base, v);
+                if (x_out && stores_x) stN<EPT>(x_out + base, v);
                 ss = sumsq_treeN<EPT>(v);
             }
             // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
@@ -369,7 +392,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
                 v[i] = v[i] * inv * h2f(hw);
             }
         } else if (PRO == PRO_EMBED || PRO == PRO_RESID) {
-            if (on && a.x_out && blockIdx.x == 0) stN<EPT>(a.x_out + base, v);
+            if (on && x_out && stores_x) stN<EPT>(x_out + base, v);
         }
         if (F16W) {
             act_roundN<WT, EPT>(v);
@@ -383,6 +406,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         for (int i = threadIdx.x * 4; i < d; i += NT * 4) *(float4*)(s.row + i) = *(const float4*)(a.act_f + i);
         __syncthreads();
     }
+
+    if (EPI == EPI_STAGE) return;
 
     // ---- 4. this lane's activation blocks, then the dot products
     int av[NCH][8], asum[NCH];
@@ -468,6 +493,158 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     }
 }
 
+// ------------------------------------------- W.x kernel, several sequences
+//
+// Multi-sequence decode: S independent sequences advance by one token per
+// step and SHARE every weight pass -- the weights are streamed once and each row is dotted with
+// S staged activation vectors (left in HBM by the EPI_STAGE launches above, ActQ8 layout per
+// sequence, or an f32 row for f16).  Per sequence the arithmetic, its order and therefore the
+// result are exactly those of the single-sequence kernel (tested bit for bit).
+template <int WT, int NCH, int R, int S, int EPI, int NT>
+__global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
+{
+    constexpr int NW = NT / 64;
+    constexpr bool F16W = (WT == GTEN_F16);
+    static_assert(EPI != EPI_SILUMUL || (NT == 512 && S <= 8), "FFN slice epilogue: 8 waves, one per sequence");
+    const int d = a.d_in, nb = d >> 5;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float* res = (float*)g_smem;                  // EPI_SILUMUL: [S][64]
+
+    const int rows0 = a.rows[0], rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
+    const int total = rows0 + rows1 + rows2;
+    const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
+                                        : (blockIdx.x * NW + wid) * R;
+    uint4 wq[R][NCH], wq1[R][NCH];
+    uint16_t wd[R][NCH];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        int lr = r0 + j;
+        const bool ok = lr < total;
+        const uint8_t* qbase = a.qs[0];
+        const uint16_t* dbase = a.ds[0];
+        if (lr >= rows0 && rows1 > 0) {
+            lr -= rows0; qbase = a.qs[1]; dbase = a.ds[1];
+            if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; }
+        }
+        if (!ok) lr = 0;
+        const uint16_t* drow = dbase + (size_t)lr * nb;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int b = (c * 64 + lane < nb) ? c * 64 + lane : 0;
+            if (F16W) {
+                const int e = (c * 512 + lane * 8 < d) ? c * 512 + lane * 8 : 0;
+                wq[j][c] = *(const uint4*)((const uint16_t*)qbase + (size_t)lr * d + e);
+                wq1[j][c] = make_uint4(0, 0, 0, 0);
+                wd[j][c] = 0;
+                continue;
+            }
+            if (WT == GTEN_Q4) {
+                wq[j][c] = ((const uint4*)(qbase + (size_t)lr * nb * 16))[b];
+            } else {
+                const uint4* q0 = (const uint4*)(qbase + (size_t)lr * nb * 32);
+                wq[j][c] = q0[b];
+                wq1[j][c] = q0[nb + b];
+            }
+            wd[j][c] = drow[b];
+        }
+    }
+
+    float acc[R][S];
+#pragma unroll
+    for (int j = 0; j < R; j++)
+#pragma unroll
+        for (int q = 0; q < S; q++) acc[j][q] = 0.f;
+
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if (F16W) {
+            const int e = c * 512 + lane * 8;
+            if (e < d) {
+#pragma unroll
+                for (int q = 0; q < S; q++) {
+                    const float* row = a.act_f + (size_t)q * d + e;
+                    const float4 a0 = *(const float4*)row, a1 = *(const float4*)(row + 4);
+                    const float fa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        const unsigned u[4] = {wq[j][c].x, wq[j][c].y, wq[j][c].z, wq[j][c].w};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            acc[j][q] += h2f((uint16_t)(u[i] & 0xffffu)) * fa[2 * i];
+                            acc[j][q] += h2f((uint16_t)(u[i] >> 16)) * fa[2 * i + 1];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+        const int b = c * 64 + lane;
+        const bool in = b < nb;
+        const int bs = in ? b : 0;
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            const int4* ap = (const int4*)(a.act_q + (size_t)q * d + (size_t)bs * 32);
+            const int4 a0 = ap[0], a1 = ap[1];
+            const int av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float ad = in ? a.act_d[(size_t)q * nb + bs] : 0.f;
+            const int asum = in ? a.act_sum[(size_t)q * nb + bs] : 0;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int isum = (WT == GTEN_Q4) ? dot_q8_q4_block(av, asum, wq[j][c]) : dot_q8_q8_block(av, wq[j][c], wq1[j][c]);
+                acc[j][q] += (float)isum * (ad * h2f(wd[j][c]));
+            }
+        }
+    }
+
+    float best[S];
+    int best_i[S];
+#pragma unroll
+    for (int q = 0; q < S; q++) { best[q] = -INFINITY; best_i[q] = 0x7fffffff; }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            const float v = wave_sum(acc[j][q]);
+            if (EPI == EPI_SILUMUL) {
+                if (lane == 0) res[q * 64 + (wid >> 2) * 32 + (wid & 3) * R + j] = v;
+            } else {
+                if (lane == 0 && r0 + j < total) a.out[(size_t)q * a.raw_stride + r0 + j] = v;
+                if (a.best_val && r0 + j < total && v > best[q]) { best[q] = v; best_i[q] = r0 + j; }
+            }
+        }
+    }
+    if (EPI == EPI_RAW && a.best_val && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            a.best_val[(size_t)q * a.best_stride + blockIdx.x * NW + wid] = best[q];
+            a.best_idx[(size_t)q * a.best_stride + blockIdx.x * NW + wid] = best_i[q];
+        }
+    }
+    if (EPI == EPI_SILUMUL) {
+        // silu(write(gate)) * write(up), written in the activation dtype, one wave per sequence
+        __syncthreads();
+        if (wid < S) {
+            const int q = wid, e = lane & 31;
+            const int nbf = rows0 >> 5;
+            float g = act_round32(res[q * 64 + e], F16W);
+            g = act_round32(g / (1.0f + expf(-g)), F16W);
+            const float u = act_round32(res[q * 64 + 32 + e], F16W);
+            const float v = g * u;
+            if (F16W) {
+                if (lane < 32) a.out_f[(size_t)q * rows0 + (size_t)blockIdx.x * 32 + e] = h2f(f2h(v));
+            } else {
+                const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
+                const int qv = q8_round(v, sc.scale);
+                const int qs = sum32_i(qv);
+                if (lane < 32) {
+                    a.out_q[(size_t)q * rows0 + (size_t)blockIdx.x * 32 + e] = (int8_t)qv;
+                    if (e == 0) { a.out_d[(size_t)q * nbf + blockIdx.x] = sc.ddeq; a.out_sum[(size_t)q * nbf + blockIdx.x] = qs; }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------- attention
 
 struct AttnArgs {
@@ -479,7 +656,27 @@ struct AttnArgs {
     float* att_part;              // [n_heads][n_chunks][d_head]
     const float2* rope;
     int adtype, n_heads, n_kv, d_head, max_ctx, n_chunks, n_embd;
+    // multi-sequence decode: blockIdx.z = sequence; its caches come from a device table
+    // [seq][layer][k|v], its scratch rows lie `*_stride` elements apart
+    const void* const* kv_tab; int layer, n_layers;
+    int qkv_stride, scores_stride, stats_stride, part_stride;
 };
+
+// per-sequence view of the arguments (identity for single-sequence launches)
+__device__ __forceinline__ AttnArgs attn_for_seq(const AttnArgs& a, int seq)
+{
+    AttnArgs t = a;
+    t.step = a.step + seq;
+    t.qkv_raw = a.qkv_raw + (size_t)seq * a.qkv_stride;
+    t.scores = a.scores + (size_t)seq * a.scores_stride;
+    t.stats = a.stats + (size_t)seq * a.stats_stride;
+    t.att_part = a.att_part + (size_t)seq * a.part_stride;
+    if (a.kv_tab) {
+        t.kcache = (uint8_t*)a.kv_tab[((size_t)seq * a.n_layers + a.layer) * 2];
+        t.vcache = (uint8_t*)a.kv_tab[((size_t)seq * a.n_layers + a.layer) * 2 + 1];
+    }
+    return t;
+}
 
 // write(raw) -> rope -> write, for one head vector of d_head (32 or 64) elements
 // held by lanes [0, d_head) of wave 0; returns the final f32 value (exact storage
@@ -684,8 +881,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv(const AttnArgs a)
 // instead of one per cached row.
 
 template <int ADT>
-__global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a)
+__global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
 {
+    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
     constexpr int dh = 64, nblk = 2;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
     const int n = a.step->n, pos = n - 1;
@@ -796,8 +994,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a)
 }
 
 template <int ADT>
-__global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a)
+__global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a0)
 {
+    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
     constexpr int dh = 64;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
     const int n = a.step->n;
@@ -862,9 +1061,14 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a)
 // greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424).
 // Works on (value, index) candidates: either the logits themselves (idx == null)
 // or the per-wave winners the lm_head kernel left behind.
-__global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ vals, const int* __restrict__ idxs, int count,
-                                                     DecStep* step, int32_t* __restrict__ result)
+__global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ vals0, const int* __restrict__ idxs0, int count,
+                                                     DecStep* step0, int32_t* __restrict__ result0, int cand_stride, int result_stride)
 {
+    // one workgroup per sequence
+    const float* vals = vals0 + (size_t)blockIdx.x * cand_stride;
+    const int* idxs = idxs0 ? idxs0 + (size_t)blockIdx.x * cand_stride : nullptr;
+    DecStep* step = step0 + blockIdx.x;
+    int32_t* result = result0 + (size_t)blockIdx.x * result_stride;
     __shared__ float bv[16];
     __shared__ int bi[16];
     float best = -INFINITY;
@@ -915,6 +1119,14 @@ struct gten_hip_decoder {
     int n_best = 0;
     int dev_n = -1;                // value of step->n on the device after the queued work (-1: unknown)
     int only_family = -1;          // >= 0: enqueue only the launches of this kernel family (timing replays)
+    // ---- multi-sequence decode (n_seq > 1): per-sequence rows of every scratch buffer above, plus
+    int n_seq = 1;
+    const void** kv_tab = nullptr; // device: [n_seq][n_layers][k|v]
+    int8_t* stg_q = nullptr;       // staged n_embd-wide input of the next W.x: [n_seq] ActQ8 / f32 rows
+    float* stg_d = nullptr;
+    int* stg_sum = nullptr;
+    float* stg_f = nullptr;
+    float* logits_m = nullptr;     // [n_seq][n_vocab]
     int n_chunks = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -1027,12 +1239,135 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
     if ((rc = launch_gemv8<WT, PRO_RESID, NE, F16W ? 4 : 8, 512>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
     DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
-               dc->n_best, dc->step, dc->result);
+               dc->n_best, dc->step, dc->result, 0, 0);
     return 0;
+}
+
+// ---- one decode step of n_seq sequences that share every weight pass
+template <int WT, int PRO>
+static int launch_stage(int tag, Gemv8Args a, int n_seq)
+{
+    DEC_LAUNCH(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), a);
+    return 0;
+}
+
+template <int WT, int NCH, int R, int S, int NT>
+static int launch_gemvm(int tag, const Gemv8Args& a, int total_rows)
+{
+    const int rows_per_wg = (NT / 64) * R;
+    DEC_LAUNCH(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT), 0, a);
+    return 0;
+}
+
+template <int WT, int S>
+static int enqueue_step_multi(gten_hip_decoder* dc)
+{
+    const gten_hip_decoder_desc& d = dc->d;
+    const int E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads, V = d.n_vocab;
+    const size_t kv_pitch = gten_hip_row_bytes(d.adtype, KV);
+    constexpr bool F16W = (WT == GTEN_F16);
+    constexpr int NE = F16W ? 4 : 1, NF = F16W ? 11 : 3;
+    constexpr int RH = F16W ? 2 : 4;              // lm_head rows per wave
+    const bool wideF = F > 2048;
+    float* xbuf = (float*)dc->xbuf;
+    float* hbuf = (float*)dc->hbuf;
+    int rc;
+    // stage descriptors shared by every launch
+    Gemv8Args base{};
+    base.step = dc->step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
+    base.best_stride = dc->n_best;
+    for (int l = 0; l < d.n_layers; l++) {
+        const gten_hip_layer_ptrs& L = dc->layers[l];
+        // x (and its RMSNorm) per sequence -> stage
+        Gemv8Args st = base;
+        st.d_in = E; st.norm_w = (const uint16_t*)L.attn_norm; st.x_out = xbuf;
+        st.act_q = dc->stg_q; st.act_d = dc->stg_d; st.act_sum = dc->stg_sum; st.act_f = dc->stg_f;
+        if (l == 0) {
+            st.table = d.embed; st.n_vocab = V; st.tokens = dc->tokens;
+            rc = launch_stage<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
+        } else {
+            st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E;
+            rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
+        }
+        if (rc) return rc;
+        Gemv8Args a = base;
+        a.d_in = E; a.n_mats = 3;
+        set_mat(a, 0, L.wq, WT, E, E); set_mat(a, 1, L.wk, WT, KV, E); set_mat(a, 2, L.wv, WT, KV, E);
+        a.out = dc->qkv_raw; a.raw_stride = E + 2 * KV;
+        a.act_q = dc->stg_q; a.act_d = dc->stg_d; a.act_sum = dc->stg_sum; a.act_f = dc->stg_f;
+        if ((rc = launch_gemvm<WT, NE, 2, S, 256>(KT_DEC_GEMV_QKV, a, E + 2 * KV))) return rc;
+        // attention, one grid plane per sequence
+        AttnArgs t{};
+        t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
+        t.att_part = dc->att_part; t.rope = dc->rope;
+        t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
+        t.n_chunks = dc->n_chunks; t.n_embd = E;
+        t.kv_tab = (const void* const*)dc->kv_tab; t.layer = l; t.n_layers = d.n_layers;
+        t.qkv_stride = E + 2 * KV; t.scores_stride = d.n_heads * d.max_ctx; t.stats_stride = d.n_heads * dc->n_chunks * 2;
+        t.part_stride = d.n_heads * dc->n_chunks * dh;
+        const dim3 agrid(d.n_heads, dc->n_chunks, S);
+        const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
+        if ((rc = launch_attention(t, agrid, smem1))) return rc;
+        // attention rows -> stage -> o projection
+        Gemv8Args sa = base;
+        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.n_chunks = dc->n_chunks;
+        sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
+        if ((rc = launch_stage<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
+        Gemv8Args o = base;
+        o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw; o.raw_stride = E;
+        o.act_q = dc->stg_q; o.act_d = dc->stg_d; o.act_sum = dc->stg_sum; o.act_f = dc->stg_f;
+        if ((rc = launch_gemvm<WT, NE, 2, S, 256>(KT_DEC_GEMV_O, o, E))) return rc;
+        // h = x + proj (and its RMSNorm) -> stage -> gate/up with the silu*up chain in the epilogue
+        Gemv8Args sh = base;
+        sh.d_in = E; sh.res_a = xbuf; sh.res_raw = dc->proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
+        sh.norm_w = (const uint16_t*)L.ffn_norm;
+        sh.act_q = dc->stg_q; sh.act_d = dc->stg_d; sh.act_sum = dc->stg_sum; sh.act_f = dc->stg_f;
+        if ((rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
+        Gemv8Args gu = base;
+        gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
+        gu.act_q = dc->stg_q; gu.act_d = dc->stg_d; gu.act_sum = dc->stg_sum; gu.act_f = dc->stg_f;
+        gu.out_q = dc->act_q; gu.out_d = dc->act_d; gu.out_sum = dc->act_sum; gu.out_f = dc->act_f;
+        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), (size_t)S * 64 * 4, gu);
+        Gemv8Args dn = base;
+        dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw; dn.raw_stride = E;
+        dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum; dn.act_f = dc->act_f;
+        rc = wideF ? launch_gemvm<WT, NF, 2, S, 256>(KT_DEC_GEMV_DOWN, dn, E) : launch_gemvm<WT, NE, 2, S, 256>(KT_DEC_GEMV_DOWN, dn, E);
+        if (rc) return rc;
+    }
+    Gemv8Args sf = base;
+    sf.d_in = E; sf.res_a = hbuf; sf.res_raw = dc->down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
+    sf.act_q = dc->stg_q; sf.act_d = dc->stg_d; sf.act_sum = dc->stg_sum; sf.act_f = dc->stg_f;
+    if ((rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
+    Gemv8Args hd = base;
+    hd.d_in = E; hd.n_mats = 1; set_mat(hd, 0, d.lm_head, WT, V, E); hd.out = dc->logits_m; hd.raw_stride = V;
+    hd.act_q = dc->stg_q; hd.act_d = dc->stg_d; hd.act_sum = dc->stg_sum; hd.act_f = dc->stg_f;
+    hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
+    if ((rc = launch_gemvm<WT, NE, RH, S, 512>(KT_DEC_GEMV_HEAD, hd, V))) return rc;
+    DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
+               dc->n_best, dc->step, dc->result, dc->n_best, d.max_ctx + 2);
+    return 0;
+}
+
+template <int WT>
+static int enqueue_multi(gten_hip_decoder* dc)
+{
+    switch (dc->n_seq) {
+    case 2: return enqueue_step_multi<WT, 2>(dc);
+    case 4: return enqueue_step_multi<WT, 4>(dc);
+    case 8: return enqueue_step_multi<WT, 8>(dc);
+    }
+    return fail(-4, "decoder: n_seq %d not in {1, 2, 4, 8}", dc->n_seq);
 }
 
 static int enqueue(gten_hip_decoder* dc)
 {
+    if (dc->n_seq > 1) {
+        switch (dc->d.wdtype) {
+        case GTEN_F16: return enqueue_multi<GTEN_F16>(dc);
+        case GTEN_Q8: return enqueue_multi<GTEN_Q8>(dc);
+        case GTEN_Q4: return enqueue_multi<GTEN_Q4>(dc);
+        }
+    }
     switch (dc->d.wdtype) {
     case GTEN_F16: return enqueue_step_q8act<GTEN_F16>(dc);
     case GTEN_Q8: return enqueue_step_q8act<GTEN_Q8>(dc);
@@ -1041,9 +1376,8 @@ static int enqueue(gten_hip_decoder* dc)
     return fail(-4, "decoder: bad weight dtype %d", dc->d.wdtype);
 }
 
-extern "C" {
-
-int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, gten_hip_decoder** out)
+static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers,
+                                 const gten_hip_kv_ptrs* kv, int n_seq, gten_hip_decoder** out)
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(desc && layers && out, "decoder_create: null argument");
@@ -1056,41 +1390,77 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
     GTR_REQUIRE(d.max_ctx > 0 && d.max_ctx <= GTEN_ROPE_MAX_POS, "decoder_create: max_ctx %d beyond the RoPE table", d.max_ctx);
     const bool pair_ok = (d.wdtype == GTEN_F16 && d.adtype == GTEN_F16) || ((d.wdtype == GTEN_Q8 || d.wdtype == GTEN_Q4) && d.adtype == GTEN_Q8);
     GTR_REQUIRE(pair_ok, "decoder_create: unsupported dtype pair (%d,%d) (tinyllama.cpp:258-265)", d.wdtype, d.adtype);
-    GTR_REQUIRE(d.embed && d.final_norm && d.lm_head && d.logits, "decoder_create: null model pointer");
+    GTR_REQUIRE(d.embed && d.final_norm && d.lm_head, "decoder_create: null model pointer");
+    GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8, "decoder_create: n_seq %d not in {1, 2, 4, 8}", n_seq);
+    GTR_REQUIRE(n_seq == 1 || (kv && dh == 64), "decoder_create: multi-sequence decode needs the cache table and d_head 64");
+    GTR_REQUIRE(n_seq > 1 || d.logits, "decoder_create: null logits pointer");
     auto* dc = new gten_hip_decoder;
     dc->d = d;
+    dc->n_seq = n_seq;
     dc->layers.assign(layers, layers + d.n_layers);
     dc->n_chunks = (d.max_ctx + DEC_CHUNK - 1) / DEC_CHUNK;
     const int E = d.n_embd, F = d.n_ffn, KV = dh * d.n_kv_heads;
-    GTR_CHECK(hipMalloc((void**)&dc->step, sizeof(DecStep)));
-    GTR_CHECK(hipMemset(dc->step, 0, sizeof(DecStep)));
-    GTR_CHECK(hipMalloc((void**)&dc->tokens, (size_t)(d.max_ctx + 1) * 4));
-    GTR_CHECK(hipMemset(dc->tokens, 0, (size_t)(d.max_ctx + 1) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->result, (size_t)(d.max_ctx + 2) * 4));
-    GTR_CHECK(hipMemset(dc->result, 0, (size_t)(d.max_ctx + 2) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, (size_t)(E + 2 * KV) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->proj_raw, (size_t)E * 4));
+    const size_t S = (size_t)n_seq;
+    GTR_CHECK(hipMalloc((void**)&dc->step, S * sizeof(DecStep)));
+    GTR_CHECK(hipMemset(dc->step, 0, S * sizeof(DecStep)));
+    GTR_CHECK(hipMalloc((void**)&dc->tokens, S * (size_t)(d.max_ctx + 1) * 4));
+    GTR_CHECK(hipMemset(dc->tokens, 0, S * (size_t)(d.max_ctx + 1) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->result, S * (size_t)(d.max_ctx + 2) * 4));
+    GTR_CHECK(hipMemset(dc->result, 0, S * (size_t)(d.max_ctx + 2) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, S * (size_t)(E + 2 * KV) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->proj_raw, S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->gu_raw, (size_t)2 * F * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->down_raw, (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->scores, (size_t)d.n_heads * d.max_ctx * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->stats, (size_t)d.n_heads * dc->n_chunks * 2 * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->att_part, (size_t)d.n_heads * dc->n_chunks * dh * 4));
-    // residual rows between kernels: f32 (exact storage values) for Q8 activations, f16 rows otherwise
-    GTR_CHECK(hipMalloc((void**)&dc->xbuf, (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->hbuf, (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->act_q, (size_t)F));
-    GTR_CHECK(hipMalloc((void**)&dc->act_d, (size_t)(F / 32) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->act_sum, (size_t)(F / 32) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->act_f, (size_t)F * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->down_raw, S * (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->scores, S * (size_t)d.n_heads * d.max_ctx * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->stats, S * (size_t)d.n_heads * dc->n_chunks * 2 * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->att_part, S * (size_t)d.n_heads * dc->n_chunks * dh * 4));
+    // residual rows between kernels: f32 rows of exact storage values
+    GTR_CHECK(hipMalloc((void**)&dc->xbuf, S * (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->hbuf, S * (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->act_q, S * (size_t)F));
+    GTR_CHECK(hipMalloc((void**)&dc->act_d, S * (size_t)(F / 32) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->act_sum, S * (size_t)(F / 32) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->act_f, S * (size_t)F * 4));
     {
-        const int head_rows_per_wg = 8 * (d.wdtype == GTEN_F16 ? 4 : 8);   // lm_head launch: 8 waves x R rows
-        dc->n_best = ((d.n_vocab + head_rows_per_wg - 1) / head_rows_per_wg) * 8;
+        // lm_head launch: 8 waves x R rows per workgroup (R: single 8 | 4 for f16; multi 4 | 2)
+        const int r = (n_seq == 1) ? (d.wdtype == GTEN_F16 ? 4 : 8) : (d.wdtype == GTEN_F16 ? 2 : 4);
+        dc->n_best = ((d.n_vocab + 8 * r - 1) / (8 * r)) * 8;
     }
-    GTR_CHECK(hipMalloc((void**)&dc->best_val, (size_t)dc->n_best * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->best_idx, (size_t)dc->n_best * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->best_val, S * (size_t)dc->n_best * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->best_idx, S * (size_t)dc->n_best * 4));
+    if (n_seq > 1) {
+        GTR_CHECK(hipMalloc((void**)&dc->stg_q, S * (size_t)E));
+        GTR_CHECK(hipMalloc((void**)&dc->stg_d, S * (size_t)(E / 32) * 4));
+        GTR_CHECK(hipMalloc((void**)&dc->stg_sum, S * (size_t)(E / 32) * 4));
+        GTR_CHECK(hipMalloc((void**)&dc->stg_f, S * (size_t)E * 4));
+        GTR_CHECK(hipMalloc((void**)&dc->logits_m, S * (size_t)d.n_vocab * 4));
+        std::vector<const void*> tab(S * d.n_layers * 2);
+        for (size_t q = 0; q < S; q++)
+            for (int l = 0; l < d.n_layers; l++) {
+                const gten_hip_kv_ptrs& p = kv[q * d.n_layers + l];
+                GTR_REQUIRE(p.kcache && p.vcache, "decoder_create: null cache pointer (sequence %zu, layer %d)", q, l);
+                tab[(q * d.n_layers + l) * 2] = p.kcache;
+                tab[(q * d.n_layers + l) * 2 + 1] = p.vcache;
+            }
+        GTR_CHECK(hipMalloc((void**)&dc->kv_tab, tab.size() * sizeof(void*)));
+        GTR_CHECK(hipMemcpy(dc->kv_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
+    }
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
     *out = dc;
     return 0;
+}
+
+extern "C" {
+
+int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, gten_hip_decoder** out)
+{
+    return decoder_create_common(desc, layers, nullptr, 1, out);
+}
+
+int gten_hip_decoder_create_multi(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers,
+                                  const gten_hip_kv_ptrs* kv, int n_seq, gten_hip_decoder** out)
+{
+    return decoder_create_common(desc, layers, kv, n_seq, out);
 }
 
 int gten_hip_decoder_destroy(gten_hip_decoder* dc)
@@ -1102,7 +1472,8 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     if (dc->graph) hipGraphDestroy(dc->graph);
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->gu_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
-                    dc->act_q, dc->act_d, dc->act_sum, dc->act_f};
+                    dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
+                    dc->logits_m, (void*)dc->kv_tab};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;
@@ -1110,9 +1481,15 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
 
 int gten_hip_decoder_set_tokens(gten_hip_decoder* dc, const int32_t* tokens_host, int first, int count)
 {
+    return gten_hip_decoder_set_tokens_seq(dc, 0, tokens_host, first, count);
+}
+
+int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t* tokens_host, int first, int count)
+{
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && tokens_host && first >= 0 && count > 0 && first + count <= dc->d.max_ctx + 1, "decoder_set_tokens: bad range");
-    GTR_CHECK(hipMemcpyAsync(dc->tokens + first, tokens_host, (size_t)count * 4, hipMemcpyHostToDevice, stream()));
+    GTR_REQUIRE(seq >= 0 && seq < dc->n_seq, "decoder_set_tokens: sequence %d outside [0, %d)", seq, dc->n_seq);
+    GTR_CHECK(hipMemcpyAsync(dc->tokens + (size_t)seq * (dc->d.max_ctx + 1) + first, tokens_host, (size_t)count * 4, hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     return 0;
 }
@@ -1122,11 +1499,12 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && n >= 1 && n <= dc->d.max_ctx, "decoder_step: n=%d outside [1, %d]", n, dc ? dc->d.max_ctx : 0);
     // The step's position lives on the device and the argmax kernel advances it,
-    // so consecutive steps need no host-side update at all.
+    // so consecutive steps need no host-side update at all.  (All sequences of a
+    // multi-sequence decoder are at the same position.)
     if (dc->dev_n != n) {
-        const DecStep st{n, 1};
-        GTR_CHECK(hipMemcpyAsync(dc->step, &st, sizeof(st), hipMemcpyHostToDevice, stream()));
-        GTR_CHECK(hipStreamSynchronize(stream()));    // `st` is on this stack frame
+        std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n, 1});
+        GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));    // `st` lives on this stack frame
     }
     dc->dev_n = n + 1;
     if (!use_graph || prof_on()) return enqueue(dc);    // event pairs cannot be recorded into a capture
@@ -1153,8 +1531,8 @@ int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int re
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && avg_us && reps > 0 && n >= 1 && n <= dc->d.max_ctx, "decoder_time_family: bad arguments");
     GTR_REQUIRE(!prof_on(), "decoder_time_family: switch the per-launch profiler off first");
-    const DecStep st{n, 0};
-    GTR_CHECK(hipMemcpyAsync(dc->step, &st, sizeof(st), hipMemcpyHostToDevice, stream()));
+    std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n, 0});
+    GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     hipGraph_t g = nullptr;
@@ -1189,9 +1567,25 @@ int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int re
 
 int gten_hip_decoder_result(gten_hip_decoder* dc, int n, int32_t* argmax_host)
 {
+    return gten_hip_decoder_result_seq(dc, 0, n, argmax_host);
+}
+
+int gten_hip_decoder_result_seq(gten_hip_decoder* dc, int seq, int n, int32_t* argmax_host)
+{
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && argmax_host && n >= 1 && n <= dc->d.max_ctx, "decoder_result: bad arguments");
-    GTR_CHECK(hipMemcpyAsync(argmax_host, dc->result + n, 4, hipMemcpyDeviceToHost, stream()));
+    GTR_REQUIRE(seq >= 0 && seq < dc->n_seq, "decoder_result: sequence %d outside [0, %d)", seq, dc->n_seq);
+    GTR_CHECK(hipMemcpyAsync(argmax_host, dc->result + (size_t)seq * (dc->d.max_ctx + 2) + n, 4, hipMemcpyDeviceToHost, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int gten_hip_decoder_logits_seq(gten_hip_decoder* dc, int seq, float* logits_host)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && logits_host && seq >= 0 && seq < dc->n_seq, "decoder_logits: bad arguments");
+    const float* src = dc->n_seq > 1 ? dc->logits_m + (size_t)seq * dc->d.n_vocab : dc->d.logits;
+    GTR_CHECK(hipMemcpyAsync(logits_host, src, (size_t)dc->d.n_vocab * 4, hipMemcpyDeviceToHost, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     return 0;
 }

@@ -139,6 +139,85 @@ int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out
     return 0;
 }
 
+// ---- several sequences sharing one copy of the weights
+struct gten_host_batch {
+    gten_host_config cfg;
+    std::unique_ptr<TinyLlamaBatch> batch;
+};
+
+gten_host_batch* gten_host_batch_create(const gten_host_config* cfg, int n_seq)
+{
+    if (!cfg || !(n_seq == 2 || n_seq == 4 || n_seq == 8)) return nullptr;
+    auto* b = new gten_host_batch;
+    b->cfg = *cfg;
+    b->batch.reset(new TinyLlamaBatch(n_seq, cfg->max_ctx, ModuleDtype{to_dtype(cfg->wdtype), to_dtype(cfg->adtype)}, to_params(*cfg)));
+    return b;
+}
+
+void gten_host_batch_free(gten_host_batch* b) { delete b; }
+
+int gten_host_batch_load_synthetic(gten_host_batch* b, uint64_t seed)
+{
+    b->batch->load_synthetic(seed);
+    return 0;
+}
+
+int gten_host_batch_set_weight(gten_host_batch* b, int idx, const void* bytes, size_t nbytes)
+{
+    TinyLlama& m0 = b->batch->seq(0);
+    if (idx < 0 || idx >= m0.n_weights()) return -1;
+    Tensor& w = m0.weight(idx);
+    if (nbytes != w.nbytes()) return -2;
+    std::memcpy(w.data_ptr<char>(), bytes, nbytes);
+    w.device_weight();
+    if (idx == m0.n_weights() - 1) b->batch->share_weights();     // last tensor in: alias them all
+    return 0;
+}
+
+int gten_host_batch_prefill(gten_host_batch* b, int seq, const int32_t* tokens, int n, float* logits_out)
+{
+    if (seq < 0 || seq >= b->batch->n_seq() || !tokens || n <= 0) return -1;
+    Tensor tk(tokens, {n}, kInt32);
+    const Tensor lg = b->batch->seq(seq).logits(tk, 0);          // operator path on this sequence's own caches
+    if (logits_out) std::memcpy(logits_out, lg.data_ptr<float>(), (size_t)lg.numel() * sizeof(float));
+    return 0;
+}
+
+int gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count)
+{
+    if (seq < 0 || seq >= b->batch->n_seq() || !tokens || count <= 0 || count > b->cfg.max_ctx) return -1;
+    b->batch->decode_set_tokens(seq, tokens, 0, count);
+    return 0;
+}
+
+int gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph)
+{
+    if (n < 1 || n > b->cfg.max_ctx) return -1;
+    b->batch->decode_step(n, use_graph != 0);
+    return 0;
+}
+
+int gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out)
+{
+    if (!argmax_out || seq < 0 || seq >= b->batch->n_seq()) return -1;
+    *argmax_out = b->batch->decode_result(seq, n);
+    return 0;
+}
+
+int gten_host_batch_logits(gten_host_batch* b, int seq, float* logits_out)
+{
+    if (!logits_out || seq < 0 || seq >= b->batch->n_seq()) return -1;
+    b->batch->decode_logits(seq, logits_out);
+    return 0;
+}
+
+int gten_host_batch_time_family(gten_host_batch* b, int family, int n, int reps, double* avg_us, int* launches)
+{
+    if (!avg_us) return -1;
+    *avg_us = b->batch->decode_time_family(family, n, reps, launches);
+    return 0;
+}
+
 int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes)
 {
     std::vector<float> scratch;

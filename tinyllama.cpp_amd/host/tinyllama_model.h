@@ -9,6 +9,7 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,35 @@ public:
         ensure_decoder();
         GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
     }
+    // device pointers of this model's weights / logits buffer for a decoder (shared code with TinyLlamaBatch)
+    void describe(gten_hip_decoder_desc* d, std::vector<gten_hip_layer_ptrs>* L)
+    {
+        *d = gten_hip_decoder_desc{};
+        d->n_vocab = params.n_vocab; d->max_ctx = n_ctx_; d->n_embd = params.n_embd; d->n_ffn = params.n_ffn;
+        d->n_layers = params.n_layers; d->n_heads = params.n_heads; d->n_kv_heads = params.n_query_groups;
+        d->wdtype = dtype_code(dtype_.wdtype); d->adtype = dtype_code(dtype_.adtype);
+        d->embed = tok_emb_.weight.device_weight();
+        d->final_norm = norm_.weight.device_weight();
+        d->lm_head = lm_head_.weight.device_weight();
+        d->logits = static_cast<float*>(lm_head_.acv.device_ptr_mut());
+        L->assign((size_t)params.n_layers, gten_hip_layer_ptrs{});
+        for (int i = 0; i < params.n_layers; i++) {
+            AttentionBlock& b = blocks_[(size_t)i];
+            gten_hip_layer_ptrs& p = (*L)[(size_t)i];
+            p.wq = b.attn.query.weight.device_weight();
+            p.wk = b.attn.key.weight.device_weight();
+            p.wv = b.attn.value.weight.device_weight();
+            p.wo = b.attn.qkv_proj.weight.device_weight();
+            p.wgate = b.ffn_gate_proj.weight.device_weight();
+            p.wup = b.ffn_up_proj.weight.device_weight();
+            p.wdown = b.ffn_down_proj.weight.device_weight();
+            p.attn_norm = b.attn_norm.weight.device_weight();
+            p.ffn_norm = b.ffn_norm.weight.device_weight();
+            p.kcache = b.attn.key.acv.device_ptr_mut();      // the K/V caches ARE these activation tensors
+            p.vcache = b.attn.value.acv.device_ptr_mut();
+        }
+    }
+
     // HIP-event timed replay of one kernel family of the decode step (bench.py roofline)
     double decode_time_family(int family, int n, int reps, int* launches)
     {
@@ -239,36 +269,105 @@ private:
     void ensure_decoder()
     {
         if (dec_) return;
-        gten_hip_decoder_desc d{};
-        d.n_vocab = params.n_vocab; d.max_ctx = n_ctx_; d.n_embd = params.n_embd; d.n_ffn = params.n_ffn;
-        d.n_layers = params.n_layers; d.n_heads = params.n_heads; d.n_kv_heads = params.n_query_groups;
-        d.wdtype = dtype_code(dtype_.wdtype); d.adtype = dtype_code(dtype_.adtype);
-        d.embed = tok_emb_.weight.device_weight();
-        d.final_norm = norm_.weight.device_weight();
-        d.lm_head = lm_head_.weight.device_weight();
-        d.logits = static_cast<float*>(lm_head_.acv.device_ptr_mut());
-        std::vector<gten_hip_layer_ptrs> L((size_t)params.n_layers);
-        for (int i = 0; i < params.n_layers; i++) {
-            AttentionBlock& b = blocks_[(size_t)i];
-            gten_hip_layer_ptrs& p = L[(size_t)i];
-            p.wq = b.attn.query.weight.device_weight();
-            p.wk = b.attn.key.weight.device_weight();
-            p.wv = b.attn.value.weight.device_weight();
-            p.wo = b.attn.qkv_proj.weight.device_weight();
-            p.wgate = b.ffn_gate_proj.weight.device_weight();
-            p.wup = b.ffn_up_proj.weight.device_weight();
-            p.wdown = b.ffn_down_proj.weight.device_weight();
-            p.attn_norm = b.attn_norm.weight.device_weight();
-            p.ffn_norm = b.ffn_norm.weight.device_weight();
-            p.kcache = b.attn.key.acv.device_ptr_mut();
-            p.vcache = b.attn.value.acv.device_ptr_mut();
-        }
+        gten_hip_decoder_desc d;
+        std::vector<gten_hip_layer_ptrs> L;
+        describe(&d, &L);
         GTEN_HIP_OK(gten_hip_decoder_create(&d, L.data(), &dec_));
     }
 
 public:
     int64_t load_time = 0;
     int64_t sample_time = 0;
+};
+
+// S sequences that share ONE copy of the weights.  Each sequence is a full
+// TinyLlama object of the gten API -- its own activation tensors, hence its own K/V caches -- whose
+// weight Tensors are shallow copies of sequence 0's (gten Tensors share storage on copy,
+// gten/tensor.h:24-29), so the weights exist once in HBM.  Prefill goes through each object's
+// operator path; single-token steps of all sequences go through one multi-sequence decoder that
+// streams every weight once per step.
+class TinyLlamaBatch {
+public:
+    TinyLlamaBatch(int n_seq, int n_ctx, ModuleDtype dtype, TinyLLamaParams p = TinyLLamaParams{}) : n_ctx_{n_ctx}
+    {
+        GTEN_ASSERTM(n_seq == 2 || n_seq == 4 || n_seq == 8, "TinyLlamaBatch: n_seq %d not in {2, 4, 8}", n_seq);
+        for (int i = 0; i < n_seq; i++) {
+            seqs_.emplace_back(new TinyLlama(n_ctx, dtype, p));
+            seqs_.back()->set_fast_decode(false);
+        }
+    }
+    ~TinyLlamaBatch()
+    {
+        if (dec_) gten_hip_decoder_destroy(dec_);
+    }
+    TinyLlamaBatch(const TinyLlamaBatch&) = delete;
+    TinyLlamaBatch& operator=(const TinyLlamaBatch&) = delete;
+
+    int n_seq() const { return (int)seqs_.size(); }
+    TinyLlama& seq(int i) { return *seqs_[(size_t)i]; }
+
+    // call after sequence 0's weights are loaded: every other sequence aliases them
+    void share_weights()
+    {
+        for (size_t i = 1; i < seqs_.size(); i++)
+            for (int w = 0; w < seqs_[0]->n_weights(); w++) seqs_[i]->weight(w) = seqs_[0]->weight(w);
+    }
+    void load_synthetic(uint64_t seed)
+    {
+        seqs_[0]->load_synthetic(seed);
+        share_weights();
+    }
+
+    void decode_set_tokens(int seq_i, const int32_t* ids, int first, int count)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_set_tokens_seq(dec_, seq_i, ids, first, count));
+    }
+    // asynchronous: row n-1 of EVERY sequence
+    void decode_step(int n, bool use_graph)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
+    }
+    int decode_result(int seq_i, int n)
+    {
+        ensure_decoder();
+        int32_t tok = -1;
+        GTEN_HIP_OK(gten_hip_decoder_result_seq(dec_, seq_i, n, &tok));
+        return tok;
+    }
+    void decode_logits(int seq_i, float* out)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_logits_seq(dec_, seq_i, out));
+    }
+    double decode_time_family(int family, int n, int reps, int* launches)
+    {
+        ensure_decoder();
+        double us = 0.0;
+        GTEN_HIP_OK(gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches));
+        return us;
+    }
+
+private:
+    std::vector<std::unique_ptr<TinyLlama>> seqs_;
+    gten_hip_decoder* dec_ = nullptr;
+    int n_ctx_;
+
+    void ensure_decoder()
+    {
+        if (dec_) return;
+        gten_hip_decoder_desc d;
+        std::vector<gten_hip_layer_ptrs> L, Li;
+        seqs_[0]->describe(&d, &L);
+        std::vector<gten_hip_kv_ptrs> kv;
+        for (auto& m : seqs_) {
+            gten_hip_decoder_desc di;
+            m->describe(&di, &Li);
+            for (auto& p : Li) kv.push_back(gten_hip_kv_ptrs{p.kcache, p.vcache});
+        }
+        GTEN_HIP_OK(gten_hip_decoder_create_multi(&d, L.data(), kv.data(), (int)seqs_.size(), &dec_));
+    }
 };
 
 // Greedy loop of tinyllama.cpp:395-440 on token ids (no tokenizer): iteration 0

@@ -37,6 +37,9 @@ class GtenHost:
         "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
         "gten_host_model_decode_result", "gten_host_model_time_family",
+        "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
+        "gten_host_batch_prefill", "gten_host_batch_decode_begin", "gten_host_batch_decode_step",
+        "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
     ]
 
     def __init__(self, path=None):
@@ -62,6 +65,16 @@ class GtenHost:
         self._dstep = _sig(L, "gten_host_model_decode_step", ci, [vp, ci, ci])
         self._dresult = _sig(L, "gten_host_model_decode_result", ci, [vp, ci, C.POINTER(C.c_int32)])
         self._timefam = _sig(L, "gten_host_model_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
+        self._bcreate = _sig(L, "gten_host_batch_create", vp, [cfgp, ci])
+        self._bfree = _sig(L, "gten_host_batch_free", None, [vp])
+        self._bloads = _sig(L, "gten_host_batch_load_synthetic", ci, [vp, C.c_uint64])
+        self._bsetw = _sig(L, "gten_host_batch_set_weight", ci, [vp, ci, vp, sz])
+        self._bprefill = _sig(L, "gten_host_batch_prefill", ci, [vp, ci, vp, ci, vp])
+        self._bbegin = _sig(L, "gten_host_batch_decode_begin", ci, [vp, ci, vp, ci])
+        self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
+        self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
+        self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
+        self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
         self._synthw = _sig(L, "gten_host_synth_weight", ci, [cfgp, C.c_uint64, ci, vp, sz])
         self._writeg = _sig(L, "gten_host_write_gten", ci, [cfgp, C.c_uint64, C.c_char_p])
         self._stoks = _sig(L, "gten_host_synthetic_tokens", None, [vp, ci, C.c_uint32, ci])
@@ -91,6 +104,9 @@ class GtenHost:
 
     def model(self, cfg):
         return HostModel(self, cfg)
+
+    def batch(self, cfg, n_seq):
+        return HostBatch(self, cfg, n_seq)
 
 
 class HostModel:
@@ -172,6 +188,69 @@ class HostModel:
     def close(self):
         if self.h:
             self.host._free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostBatch:
+    """n_seq sequences sharing one copy of the weights; one step advances all of them."""
+
+    def __init__(self, host, cfg, n_seq):
+        self.host, self.cfg, self.n_seq = host, cfg, n_seq
+        if host.hip.device_count() < 1:
+            raise GtenHipError("no MI355X visible: the model runs only on the gten_hip path")
+        self.h = host._bcreate(C.byref(cfg), n_seq)
+        if not self.h:
+            raise GtenHipError(f"batch_create(n_seq={n_seq}) failed")
+
+    def _ck(self, rc, what):
+        if rc:
+            raise GtenHipError(f"{what} rc={rc}")
+
+    def load_synthetic(self, seed):
+        self._ck(self.host._bloads(self.h, seed), "batch_load_synthetic")
+
+    def set_weight(self, idx, data):
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        self._ck(self.host._bsetw(self.h, idx, data.ctypes.data_as(C.c_void_p), data.size), f"batch_set_weight({idx})")
+
+    def prefill(self, seq, tokens, want=True):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.zeros(self.cfg.n_vocab, np.float32) if want else None
+        self._ck(self.host._bprefill(self.h, seq, tokens.ctypes.data_as(C.c_void_p), len(tokens),
+                                     out.ctypes.data_as(C.c_void_p) if want else None), "batch_prefill")
+        return out
+
+    def decode_begin(self, seq, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        self._ck(self.host._bbegin(self.h, seq, tokens.ctypes.data_as(C.c_void_p), len(tokens)), "batch_decode_begin")
+
+    def decode_step(self, n, use_graph=True):
+        self._ck(self.host._bstep(self.h, n, 1 if use_graph else 0), f"batch_decode_step({n})")
+
+    def decode_result(self, seq, n):
+        out = C.c_int32(-1)
+        self._ck(self.host._bresult(self.h, seq, n, C.byref(out)), "batch_decode_result")
+        return out.value
+
+    def logits(self, seq):
+        out = np.zeros(self.cfg.n_vocab, np.float32)
+        self._ck(self.host._blogits(self.h, seq, out.ctypes.data_as(C.c_void_p)), "batch_logits")
+        return out
+
+    def time_family(self, family, n, reps=20):
+        us, cnt = C.c_double(0.0), C.c_int(0)
+        self._ck(self.host._btime(self.h, family, n, reps, C.byref(us), C.byref(cnt)), "batch_time_family")
+        return us.value, cnt.value
+
+    def close(self):
+        if self.h:
+            self.host._bfree(self.h)
             self.h = None
 
     def __del__(self):
