@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--streams", type=int, default=8, choices=[0, 2, 4, 8],
+                    help="also measure this many sequences sharing each weight pass on the GPU (0 = skip); "
+                         "reported separately, `value` stays the single-sequence rate")
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
@@ -274,6 +277,38 @@ def main():
         "roofline": roofline,
         "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1)},
     }
+    # secondary: several sequences on this GPU sharing every weight pass (not part of `value`)
+    if world == 1 and fused and args.streams > 1:
+        S = args.streams
+        model.close()
+        batch = host.batch(cfg, S)
+        batch.load_synthetic(args.seed)
+        for q in range(S):
+            batch.decode_begin(q, host.synthetic_tokens(N_CTX, seed=rep_seed(12345, 1000 + q)))
+        for n in range(1, first):
+            batch.decode_step(n, use_graph)
+        for i in range(W):
+            batch.decode_step(n_of(i, total), use_graph)
+        hip.sync()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            batch.decode_step(n_of(i, total), use_graph)
+        hip.sync()
+        dt = time.perf_counter() - t0
+        ms = dt / K * 1e3
+        bytes_step = algorithmic_bytes(args.mode, n_mid) + (S - 1) * (algorithmic_bytes(args.mode, n_mid) - algorithmic_bytes(args.mode, 0))
+        fam_idx = hip.prof_family_index("decode_gemv_gateup")
+        g_us, _ = batch.time_family(fam_idx, N_CTX, 20)
+        out["multi_stream"] = {"streams": S, "tok_s": round(S * K / dt, 1), "ms_per_step": round(ms, 4),
+                               "speedup_vs_single": round(S * K / dt / tok_s, 2),
+                               "hbm": {"achieved": round(bytes_step / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                       "algorithmic_bytes_per_step": int(bytes_step),
+                                       "note": "weights once per step + one K/V history per sequence"},
+                               "gateup_kernel_us": round(g_us, 3), "last_tokens": [batch.decode_result(q, n_of(W + K - 1, total)) for q in range(S)],
+                               "note": "per sequence bit-identical to the single-sequence decoder (tests/test_multiseq_gpu.py)"}
+        batch.close()
+        model = host.model(cfg)
+        model.load_synthetic(args.seed)
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if world == 1 and args.prefill > 0:
         P = min(args.prefill, N_CTX)

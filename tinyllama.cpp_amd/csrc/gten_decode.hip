@@ -32,6 +32,7 @@ using namespace gtd;
 extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
 
 #define DEC_CHUNK 256            // attention positions per workgroup
+#define GEMVM_F16_LDS_LIMIT 61440  // multi-sequence f16 inputs are staged in LDS up to this many bytes (stays under the 64 KiB default)
 
 // launches of a decode step can be restricted to one kernel family (gten_hip_decoder_time_family)
 static int g_only_family = -1;
@@ -549,6 +550,24 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
         }
     }
 
+    // ---- the S staged input vectors: HBM -> LDS once per workgroup (every wave needs all of them)
+    //      layout: [S][d] quants | [S][nb] deltas | [S][nb] sums   (f16: [S][d] f32 values)
+    const bool lds_f = F16W && ((size_t)S * d * 4 <= GEMVM_F16_LDS_LIMIT);
+    int8_t* lq = (int8_t*)(g_smem + (EPI == EPI_SILUMUL ? (size_t)S * 64 * 4 : 0));
+    float* ld_ = (float*)(lq + (size_t)S * d);
+    int* lsum = (int*)(ld_ + (size_t)S * nb);
+    float* lf = (float*)lq;
+    if (F16W) {
+        if (lds_f) {
+            for (int i = threadIdx.x * 4; i < S * d; i += NT * 4) *(float4*)(lf + i) = *(const float4*)(a.act_f + i);
+        }
+    } else {
+        for (int i = threadIdx.x * 16; i < S * d; i += NT * 16) *(uint4*)(lq + i) = *(const uint4*)(a.act_q + i);
+        for (int i = threadIdx.x; i < S * nb; i += NT) { ld_[i] = a.act_d[i]; lsum[i] = a.act_sum[i]; }
+    }
+    __syncthreads();
+    const float* fsrc = lds_f ? lf : a.act_f;
+
     float acc[R][S];
 #pragma unroll
     for (int j = 0; j < R; j++)
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
             if (e < d) {
 #pragma unroll
                 for (int q = 0; q < S; q++) {
-                    const float* row = a.act_f + (size_t)q * d + e;
+                    const float* row = fsrc + (size_t)q * d + e;
                     const float4 a0 = *(const float4*)row, a1 = *(const float4*)(row + 4);
                     const float fa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -581,17 +600,29 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
         const int b = c * 64 + lane;
         const bool in = b < nb;
         const int bs = in ? b : 0;
+        // this lane's block of all S sequences, then every weight row against them: the weight
+        // block's nibbles are split once per row, not once per (row, sequence)
+        int av[S][8], asum[S];
+        float ad[S];
 #pragma unroll
         for (int q = 0; q < S; q++) {
-            const int4* ap = (const int4*)(a.act_q + (size_t)q * d + (size_t)bs * 32);
+            const int4* ap = (const int4*)(lq + (size_t)q * d + (size_t)bs * 32);
             const int4 a0 = ap[0], a1 = ap[1];
-            const int av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const float ad = in ? a.act_d[(size_t)q * nb + bs] : 0.f;
-            const int asum = in ? a.act_sum[(size_t)q * nb + bs] : 0;
+            av[q][0] = a0.x; av[q][1] = a0.y; av[q][2] = a0.z; av[q][3] = a0.w;
+            av[q][4] = a1.x; av[q][5] = a1.y; av[q][6] = a1.z; av[q][7] = a1.w;
+            ad[q] = in ? ld_[q * nb + bs] : 0.f;
+            asum[q] = in ? lsum[q * nb + bs] : 0;
+        }
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                const int isum = (WT == GTEN_Q4) ? dot_q8_q4_block(av, asum, wq[j][c]) : dot_q8_q8_block(av, wq[j][c], wq1[j][c]);
-                acc[j][q] += (float)isum * (ad * h2f(wd[j][c]));
+        for (int j = 0; j < R; j++) {
+            const float dw = h2f(wd[j][c]);
+            if (WT == GTEN_Q4) {
+                const Q4Unpacked u = q4_unpack(wq[j][c]);
+#pragma unroll
+                for (int q = 0; q < S; q++) acc[j][q] += (float)dot_q8_q4_unpacked(av[q], asum[q], u) * (ad[q] * dw);
+            } else {
+#pragma unroll
+                for (int q = 0; q < S; q++) acc[j][q] += (float)dot_q8_q8_block(av[q], wq[j][c], wq1[j][c]) * (ad[q] * dw);
             }
         }
     }
@@ -1251,11 +1282,20 @@ static int launch_stage(int tag, Gemv8Args a, int n_seq)
     return 0;
 }
 
+static size_t gemvm_lds_bytes(int wt, int n_seq, int d, bool silumul)
+{
+    size_t b = silumul ? (size_t)n_seq * 64 * 4 : 0;
+    if (wt == GTEN_F16) b += ((size_t)n_seq * d * 4 <= GEMVM_F16_LDS_LIMIT) ? (size_t)n_seq * d * 4 : 0;
+    else b += (size_t)n_seq * (d + (size_t)(d / 32) * 8);
+    return b + 16;
+}
+
 template <int WT, int NCH, int R, int S, int NT>
 static int launch_gemvm(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
-    DEC_LAUNCH(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT), 0, a);
+    DEC_LAUNCH(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT),
+               gemvm_lds_bytes(WT, S, a.d_in, false), a);
     return 0;
 }
 
@@ -1327,7 +1367,7 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
         gu.act_q = dc->stg_q; gu.act_d = dc->stg_d; gu.act_sum = dc->stg_sum; gu.act_f = dc->stg_f;
         gu.out_q = dc->act_q; gu.out_d = dc->act_d; gu.out_sum = dc->act_sum; gu.out_f = dc->act_f;
-        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), (size_t)S * 64 * 4, gu);
+        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), gemvm_lds_bytes(WT, S, E, true), gu);
         Gemv8Args dn = base;
         dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw; dn.raw_stride = E;
         dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum; dn.act_f = dc->act_f;

@@ -292,6 +292,30 @@ __device__ __forceinline__ int dot_q8_q4_block(const int (&a)[8], int asum, cons
     acc = dot4(a[7], (int)(w.w & m), acc);
     return acc - 7 * asum;
 }
+// The same in two steps, for callers that dot one weight block with several activation
+// blocks: split the nibbles once, then 8 dot4 per activation block.
+struct Q4Unpacked { int hi[4], lo[4]; };
+__device__ __forceinline__ Q4Unpacked q4_unpack(const uint4 w)
+{
+    const unsigned m = 0x0f0f0f0fu;
+    Q4Unpacked u;
+    u.hi[0] = (int)((w.x >> 4) & m); u.hi[1] = (int)((w.y >> 4) & m); u.hi[2] = (int)((w.z >> 4) & m); u.hi[3] = (int)((w.w >> 4) & m);
+    u.lo[0] = (int)(w.x & m); u.lo[1] = (int)(w.y & m); u.lo[2] = (int)(w.z & m); u.lo[3] = (int)(w.w & m);
+    return u;
+}
+__device__ __forceinline__ int dot_q8_q4_unpacked(const int (&a)[8], int asum, const Q4Unpacked& u)
+{
+    int acc = 0;
+    acc = dot4(a[0], u.hi[0], acc);
+    acc = dot4(a[1], u.hi[1], acc);
+    acc = dot4(a[2], u.hi[2], acc);
+    acc = dot4(a[3], u.hi[3], acc);
+    acc = dot4(a[4], u.lo[0], acc);
+    acc = dot4(a[5], u.lo[1], acc);
+    acc = dot4(a[6], u.lo[2], acc);
+    acc = dot4(a[7], u.lo[3], acc);
+    return acc - 7 * asum;
+}
 __device__ __forceinline__ int dot_q8_q8_block(const int (&a)[8], const uint4 w0, const uint4 w1)
 {
     int acc = 0;
