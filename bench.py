@@ -130,11 +130,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("GTEN_HIP_DEVICE", str(local_rank))
+    # weight synthesis is OpenMP code on the host: share the cores between the ranks of this node
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(4, (os.cpu_count() or 8) // max(world, 1))))
 
     import numpy as np
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

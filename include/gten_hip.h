@@ -76,10 +76,6 @@ int gten_hip_memcpy_d2d(void* dst, const void* src, size_t nbytes);
 int         gten_hip_prof_enable(int on);
 int         gten_hip_prof_read(int family, int* launches, double* total_ms);
 const char* gten_hip_prof_family_name(int family);   /* NULL past the last family */
-/* mean bracket time of an EMPTY 256x256 kernel measured the same way: the share of a
- * bracket that is event/launch packets rather than kernel (subtract it to compare a
- * bracketed duration with rocprofv3's kernel duration) */
-int         gten_hip_prof_event_overhead_us(double* us);
 
 /* bytes of one storage row (gten/tensor.h:97-117, gten/tensor.cpp:37-57) */
 size_t gten_hip_row_bytes(int dtype, int cols);

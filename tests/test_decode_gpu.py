@@ -100,3 +100,46 @@ def test_kv_cache_rows_identical_between_paths(hip, oracle):
     b = slow.logits(toks, len(toks) - 1)
     assert np.array_equal(a, b)
     fast.close(); slow.close(); om.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_fused_decode_d_head_32(hip, oracle, name, wd, ad):
+    """d_head = 32 takes the generic attention kernels of the fused path (one Q8 block per head,
+    2-byte aligned head slices): still bit-identical to the operator path, still inside the band"""
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(wd, ad, n_heads=8, n_kv_heads=2)          # n_embd 256 / 8 heads
+    cfg = host_cfg(ocfg)
+    fast, slow, om = host.model(cfg), host.model(cfg), oracle.model(ocfg)
+    slow.set_fast_decode(False)
+    for i in range(fast.n_weights()):
+        w = host.synth_weight(cfg, 321, i)
+        fast.set_weight(i, w); slow.set_weight(i, w); om.set_weight(i, w)
+    toks = list(host.synthetic_tokens(5, seed=4, n_vocab=cfg.n_vocab))
+    for step in range(8):
+        sp = 0 if step == 0 else len(toks) - 1
+        a, b, want = fast.logits(toks, sp), slow.logits(toks, sp), om.logits(toks, sp)
+        assert np.array_equal(a, b), (name, step)
+        check_logits(name, a, want, float(want.std()))
+        toks.append(int(np.argmax(want)))
+    fast.close(); slow.close(); om.close()
+
+
+def test_decode_at_the_last_position(hip, oracle):
+    """n = max_ctx: the step that fills the cache to its last row (RoPE table's last entry, ragged
+    last attention chunk when max_ctx is not a multiple of 256)"""
+    from helpers import Q4, Q8
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=40, n_layers=1)
+    cfg = host_cfg(ocfg)
+    gm, om = host.model(cfg), oracle.model(ocfg)
+    for i in range(gm.n_weights()):
+        w = host.synth_weight(cfg, 5, i)
+        gm.set_weight(i, w); om.set_weight(i, w)
+    toks = host.synthetic_tokens(40, seed=8, n_vocab=cfg.n_vocab)
+    for n in range(1, 41):
+        got = gm.logits(toks[:n], n - 1)
+        want = om.logits(toks[:n], n - 1)
+    check_logits("q4", got, want, float(want.std()))
+    gm.close(); om.close()

@@ -94,7 +94,6 @@ struct Gemv8Args {
     float* x_out;                                               // PRO_EMBED/PRO_RESID: new residual row, f32
     const uint16_t* norm_w;
     const float* att_part; int d_head, n_chunks;                // PRO_ATT
-    const float* gate_raw; const float* up_raw;                 // PRO_SILUMUL
     float* best_val; int* best_idx;                             // lm_head: per-wave running argmax (may be null)
     // EPI_SILUMUL writes / PRO_ACTQ8 reads the staged FFN activation in HBM (ActQ8 layout)
     int8_t* act_q; float* act_d; int* act_sum;
@@ -1138,7 +1137,7 @@ struct gten_hip_decoder {
     DecStep* step = nullptr;
     int32_t* tokens = nullptr;     // [max_ctx + 1] teacher-forcing / prompt ids
     int32_t* result = nullptr;     // [max_ctx + 2] argmax per step, indexed by n
-    float *qkv_raw = nullptr, *proj_raw = nullptr, *gu_raw = nullptr, *down_raw = nullptr;
+    float *qkv_raw = nullptr, *proj_raw = nullptr, *down_raw = nullptr;
     float *scores = nullptr, *stats = nullptr, *att_part = nullptr;
     uint8_t *xbuf = nullptr, *hbuf = nullptr;
     float* act_f = nullptr;        // FFN activation staged by the gate/up epilogue, f16 configurations
@@ -1253,7 +1252,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         if ((rc = launch_gemv8<WT, PRO_ATT, NE, 2, 512>(KT_DEC_GEMV_O, o, E))) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
-        gu.out = nullptr; gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
+        gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
         gu.act_q = dc->act_q; gu.act_d = dc->act_d; gu.act_sum = dc->act_sum; gu.act_f = dc->act_f;
         if ((rc = launch_gateup8<WT>(gu, F))) return rc;
         Gemv8Args dn{};
@@ -1449,7 +1448,6 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     GTR_CHECK(hipMemset(dc->result, 0, S * (size_t)(d.max_ctx + 2) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, S * (size_t)(E + 2 * KV) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->proj_raw, S * (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->gu_raw, (size_t)2 * F * 4));
     GTR_CHECK(hipMalloc((void**)&dc->down_raw, S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->scores, S * (size_t)d.n_heads * d.max_ctx * 4));
     GTR_CHECK(hipMalloc((void**)&dc->stats, S * (size_t)d.n_heads * dc->n_chunks * 2 * 4));
@@ -1510,7 +1508,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     GTR_CHECK(hipStreamSynchronize(stream()));
     if (dc->exec) hipGraphExecDestroy(dc->exec);
     if (dc->graph) hipGraphDestroy(dc->graph);
-    void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->gu_raw, dc->down_raw,
+    void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
                     dc->logits_m, (void*)dc->kv_tab};

@@ -177,36 +177,6 @@ int gten_hip_prof_enable(int on)
     return 0;
 }
 
-// An empty kernel bracketed exactly like every profiled launch: what the two event
-// packets themselves add to a bracket (rocprofv3's kernel durations do not contain it).
-__global__ void k_prof_empty() {}
-
-int gten_hip_prof_event_overhead_us(double* us)
-{
-    GTR_NEED_INIT();
-    GTR_REQUIRE(us, "prof_event_overhead_us: null pointer");
-    GTR_CHECK(hipStreamSynchronize(g_stream));
-    const int reps = 200;
-    std::vector<hipEvent_t> ev(2 * reps);
-    for (auto& e : ev) GTR_CHECK(hipEventCreate(&e));
-    for (int pass = 0; pass < 2; pass++)          // first pass warms up
-        for (int i = 0; i < reps; i++) {
-            GTR_CHECK(hipEventRecord(ev[2 * i], g_stream));
-            hipLaunchKernelGGL(k_prof_empty, dim3(256), dim3(256), 0, g_stream);
-            GTR_CHECK(hipEventRecord(ev[2 * i + 1], g_stream));
-        }
-    GTR_CHECK(hipStreamSynchronize(g_stream));
-    double tot = 0.0;
-    for (int i = 0; i < reps; i++) {
-        float t = 0.f;
-        GTR_CHECK(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
-        tot += t;
-    }
-    for (auto& e : ev) hipEventDestroy(e);
-    *us = tot * 1e3 / reps;
-    return 0;
-}
-
 int gten_hip_prof_read(int family, int* launches, double* total_ms)
 {
     GTR_NEED_INIT();

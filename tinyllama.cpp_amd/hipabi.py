@@ -76,7 +76,6 @@ class GtenHip:
         "gten_hip_device_count", "gten_hip_init", "gten_hip_last_error", "gten_hip_stream", "gten_hip_sync",
         "gten_hip_malloc", "gten_hip_free", "gten_hip_memset", "gten_hip_memcpy_h2d", "gten_hip_memcpy_d2h",
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
-        "gten_hip_prof_event_overhead_us",
         "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
         "gten_hip_add", "gten_hip_qkv_attn",
@@ -110,7 +109,6 @@ class GtenHip:
         self._prof_enable = _sig(L, "gten_hip_prof_enable", ci, [ci])
         self._prof_read = _sig(L, "gten_hip_prof_read", ci, [ci, C.POINTER(ci), C.POINTER(C.c_double)])
         self._prof_name = _sig(L, "gten_hip_prof_family_name", C.c_char_p, [ci])
-        self._prof_ovh = _sig(L, "gten_hip_prof_event_overhead_us", ci, [C.POINTER(C.c_double)])
         self._pack = _sig(L, "gten_hip_pack_weight", ci, [vp, ci, ci, ci, vp])
         self._embed = _sig(L, "gten_hip_token_embed", ci, [vp, ci, ci, vp, vp, ci, sz, ci, ci, ci])
         self._matmul = _sig(L, "gten_hip_matmul_2d", ci, [vp, ci, sz, vp, ci, vp, ci, sz, ci, ci, ci, ci])
@@ -146,11 +144,6 @@ class GtenHip:
 
     def prof_enable(self, on):
         self._check(self._prof_enable(1 if on else 0))
-
-    def prof_event_overhead_us(self):
-        us = C.c_double(0.0)
-        self._check(self._prof_ovh(C.byref(us)))
-        return us.value
 
     def prof_family_index(self, wanted):
         fam = 0
