@@ -143,3 +143,30 @@ def test_decode_at_the_last_position(hip, oracle):
         want = om.logits(toks[:n], n - 1)
     check_logits("q4", got, want, float(want.std()))
     gm.close(); om.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_one_launch_attention_is_bit_identical(hip, oracle, name, wd, ad, monkeypatch):
+    """GTEN_HIP_ATTN_ONE_LAUNCH=1 (scores, softmax statistics exchanged inside the launch, p.V): the same
+    bytes as the default two launches across a chunk boundary -- every argmax and the last logits row"""
+    import os
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2)
+    cfg = host_cfg(ocfg)
+    N = 300
+    toks = host.synthetic_tokens(N, seed=11, n_vocab=cfg.n_vocab)
+    outs = []
+    for one in ("0", "1"):
+        monkeypatch.setenv("GTEN_HIP_ATTN_ONE_LAUNCH", one)
+        gm = host.model(cfg)
+        for i in range(gm.n_weights()):
+            gm.set_weight(i, host.synth_weight(cfg, 77, i))
+        gm.decode_begin(toks)                       # the decoder (and its launch choice) is made here
+        for n in range(1, N + 1):
+            gm.decode_step(n, n % 2 == 0)           # alternate graph replay and eager launches
+        res = [gm.decode_result(n) for n in range(1, N + 1)]
+        outs.append((res, gm.logits(toks[:N], N - 1).copy()))
+        gm.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])

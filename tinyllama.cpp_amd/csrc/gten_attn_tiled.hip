@@ -1,0 +1,321 @@
+// gten_attn_tiled.hip -- ops::qkv_attn for MANY new rows (prompt processing), Q8 activations, d_head 64.
+//
+// Replaces, for that case, the row-at-a-time k_attn of gten_ops.hip (which re-reads the whole K/V
+// prefix once per (head, row): 9 GB of L2 traffic per block at n = 2048).  Reference: gten/ops.h:930-1116
+// (qk scores, causal mask, softmax, probabilities rounded to the activation dtype, p.V).
+//
+// One workgroup = 32 query rows of one head.  The K/V prefix is walked in 256-position tiles, three
+// times: row maxima, sums of exponentials, probabilities.  Scores are recomputed each time instead
+// of kept (32 x 2048 f32 would not fit LDS), which costs almost nothing because a Q8 score IS an
+// int8 matrix product: one v_mfma_i32_16x16x32_i8 is exactly one 32-wide quant block of 16 rows x
+// 16 positions, and the two block sums are scaled by delta_q * delta_k in f32 as the scalar code
+// does.  p.V stays on the VALU (packed f32 mul/add): V's per-position deltas sit inside the sum, so
+// it is not an integer matrix product.
+//
+// BIT-IDENTICAL to k_attn (and therefore to the fused decoder for contexts <= 256): every
+// floating-point reduction is laid out so that it reproduces k_attn's association --
+//   * sum of exponentials: k_attn thread t adds positions t, t+256, ...; here lane (wave w,
+//     column group cg, lane%16) owns position 64w + 16cg + lane%16 of every tile: the same 256
+//     running sums, then the same tree (16-lane DPP rows, (R0+R1)+(R2+R3), waves in order);
+//   * p.V: four accumulators per output for positions = 0,1,2,3 (mod 4), summed in that order.
+#include "gten_rt.h"
+#include "gten_dev.h"
+
+using namespace gtd;
+using namespace gtr;
+
+namespace {
+
+constexpr int AT_ROWS = 32;        // query rows per workgroup
+constexpr int AT_TILE = 256;       // context positions per tile
+constexpr int AT_VSUB = 64;        // positions of V staged at a time
+constexpr int AT_PPITCH = 260;     // floats per probability row in LDS (16-byte aligned rows)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// quant bytes sit at 2-byte aligned offsets inside a 34-byte block: unaligned vector loads (gfx9 global
+// memory takes them)
+struct __attribute__((packed, aligned(2))) U2 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(2))) U4 { uint32_t v[4]; };
+
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    return fmaxf(v, dpp_mov<0x140>(v));
+}
+// the first four steps of wave_sum(): every lane of a 16-lane row ends with the row's sum
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ long as_long(const U2& u)
+{
+    long r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+}
+
+struct QFrag {
+    long a[2][2];          // [row group][quant block]: MFMA A operand, row = lane % 16, k = 8 * (lane / 16) ..
+    float d[2][2][4];      // deltas of the 4 output rows of this lane: [row group][block][i]
+};
+
+// scores of 2 x 16 query rows against the 16 positions of one column group
+__device__ __forceinline__ void tile_scores(const QFrag& q, const uint8_t* __restrict__ kslice, int lq, float (&s)[2][4])
+{
+    const U2 b0 = *(const U2*)(kslice + 2 + 8 * lq);
+    const U2 b1 = *(const U2*)(kslice + 36 + 8 * lq);
+    const float kd0 = h2f(*(const uint16_t*)kslice), kd1 = h2f(*(const uint16_t*)(kslice + 34));
+    const long kb0 = as_long(b0), kb1 = as_long(b1);
+    const v4i z = {0, 0, 0, 0};
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+        const v4i i0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(q.a[rg][0], kb0, z, 0, 0, 0);
+        const v4i i1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(q.a[rg][1], kb1, z, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float acc = 0.f;
+            acc += (float)i0[i] * (q.d[rg][0][i] * kd0);       // gten/ops.h:224-316: block sums scaled by both deltas
+            acc += (float)i1[i] * (q.d[rg][1][i] * kd1);
+            s[rg][i] = acc * 0.125f;                          // 1 / sqrt(64)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_attn_tiled_q8(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
+                                                       const uint8_t* __restrict__ v, uint8_t* __restrict__ out,
+                                                       size_t q_pitch, size_t kv_pitch, size_t out_pitch,
+                                                       int n_heads, int n_kv, int n, int start_pos)
+{
+    __shared__ __attribute__((aligned(16))) float s_p[AT_ROWS * AT_PPITCH];
+    __shared__ __attribute__((aligned(16))) float s_v[AT_VSUB * 64];
+    __shared__ float s_red[4 * AT_ROWS];
+    __shared__ float s_row[AT_ROWS];
+
+    const int h = blockIdx.x;
+    const int rt = gridDim.y - 1 - blockIdx.y;            // long (late) row tiles are scheduled first
+    const int r0 = start_pos + rt * AT_ROWS;
+    const int g = h / (n_heads / n_kv);
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lc = l & 15, lq = l >> 4;
+    const int r_last = min(r0 + AT_ROWS, n) - 1;          // last row of this tile: positions 0..r_last matter
+    const int ntile = r_last / AT_TILE + 1;
+    const uint8_t* kbase = k + (size_t)g * 68;
+    const uint8_t* vbase = v + (size_t)g * 68;
+
+    QFrag qf;
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+        const uint8_t* qs = q + (size_t)min(r0 + 16 * rg + lc, n - 1) * q_pitch + (size_t)h * 68;
+        qf.a[rg][0] = as_long(*(const U2*)(qs + 2 + 8 * lq));
+        qf.a[rg][1] = as_long(*(const U2*)(qs + 36 + 8 * lq));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint8_t* qr = q + (size_t)min(r0 + 16 * rg + 4 * lq + i, n - 1) * q_pitch + (size_t)h * 68;
+            qf.d[rg][0][i] = h2f(*(const uint16_t*)qr);
+            qf.d[rg][1][i] = h2f(*(const uint16_t*)(qr + 34));
+        }
+    }
+    const int row_base = r0 + 4 * lq;                      // this lane's rows: row_base + 16 rg + i
+
+    // ---- pass 0: row maxima
+    float mx[2][4];
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) mx[rg][i] = -INFINITY;
+    for (int t = 0; t < ntile; t++) {
+#pragma unroll
+        for (int cg = 0; cg < 4; cg++) {
+            const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+            if (c - lc > r_last) continue;                 // wave-uniform: nothing of this column group is visible
+            float s[2][4];
+            tile_scores(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (c <= row_base + 16 * rg + i) mx[rg][i] = fmaxf(mx[rg][i], s[rg][i]);   // causal mask, gten/ops.h:957
+        }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            mx[rg][i] = row16_max(mx[rg][i]);
+            if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = mx[rg][i];
+        }
+    __syncthreads();
+    if (threadIdx.x < AT_ROWS)
+        s_row[threadIdx.x] = fmaxf(fmaxf(s_red[threadIdx.x], s_red[AT_ROWS + threadIdx.x]),
+                                   fmaxf(s_red[2 * AT_ROWS + threadIdx.x], s_red[3 * AT_ROWS + threadIdx.x]));
+    __syncthreads();
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) mx[rg][i] = s_row[16 * rg + 4 * lq + i];
+    __syncthreads();
+
+    // ---- pass 1: sums of exponentials, one running sum per (row, position mod 256)
+    float tot[2][4];
+    {
+        float ls[2][4][4];
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) ls[rg][cg][i] = 0.f;
+        for (int t = 0; t < ntile; t++) {
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+                if (c - lc > r_last) continue;
+                float s[2][4];
+                tile_scores(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        ls[rg][cg][i] += (c <= row_base + 16 * rg + i) ? expf(s[rg][i] - mx[rg][i]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float r0s = row16_sum(ls[rg][0][i]), r1s = row16_sum(ls[rg][1][i]);
+                const float r2s = row16_sum(ls[rg][2][i]), r3s = row16_sum(ls[rg][3][i]);
+                const float ws = (r3s + r2s) + (r1s + r0s);          // wave_sum()'s last two steps
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = ws;
+            }
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS) {
+            float t = 0.f;
+            for (int i = 0; i < 4; i++) t += s_red[i * AT_ROWS + threadIdx.x];   // block_sum(): waves in order
+            s_row[threadIdx.x] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) tot[rg][i] = s_row[16 * rg + 4 * lq + i];
+    }
+
+    // ---- pass 2: probabilities in the activation dtype, times V
+    const int ep = threadIdx.x & 31, rq = threadIdx.x >> 5;      // outputs: rows 4 rq .. 4 rq + 3, elements 2 ep, 2 ep + 1
+    v2f acc[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[rr][j] = (v2f){0.f, 0.f};
+
+    for (int t = 0; t < ntile; t++) {
+        float p[2][4][4];
+#pragma unroll
+        for (int cg = 0; cg < 4; cg++) {
+            const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+            if (c - lc > r_last) {
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) p[rg][cg][i] = 0.f;
+                continue;
+            }
+            float s[2][4];
+            tile_scores(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    p[rg][cg][i] = (c <= row_base + 16 * rg + i) ? expf(s[rg][i] - mx[rg][i]) / tot[rg][i] : 0.f;
+        }
+        // the probability row is stored as Q8 blocks along the context (gten/ops.h:996-997): a block = two
+        // column groups x 16 lanes; masked entries are zeros, exactly what the partial tail block sees
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int bp = 0; bp < 2; bp++) {
+                    const float amax = row16_max(fmaxf(fabsf(p[rg][2 * bp][i]), fabsf(p[rg][2 * bp + 1][i])));
+                    const Q8Scale sc = q8_scale_from_absmax(amax);
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const float x = p[rg][2 * bp + u][i];
+                        s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * (2 * bp + u) + lc] = (float)q8_round(x, sc.scale) * sc.ddeq;
+                    }
+                }
+        __syncthreads();
+
+        for (int vs = 0; vs < AT_TILE / AT_VSUB; vs++) {
+            const int c0 = t * AT_TILE + vs * AT_VSUB;
+            if (c0 > r_last) break;
+            {
+                // stage 64 positions of this kv head's V slice as f32: thread = (position, quarter of the 64 elements)
+                const int pos = threadIdx.x >> 2, qtr = threadIdx.x & 3, b = qtr >> 1;
+                const uint8_t* vs_ = vbase + (size_t)min(c0 + pos, n - 1) * kv_pitch;
+                const U4 raw = *(const U4*)(vs_ + 2 + 34 * b + 16 * (qtr & 1));
+                const float d = h2f(*(const uint16_t*)(vs_ + 34 * b));
+                float* dst = s_v + pos * 64 + 16 * qtr;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    v4f o4;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o4[j] = (float)(int8_t)(raw.v[kk] >> (8 * j)) * d;
+                    *(v4f*)(dst + 4 * kk) = o4;
+                }
+            }
+            __syncthreads();
+            const int lim = min(AT_VSUB, r_last - c0 + 1);       // positions past r_last carry p = 0 for every row
+#pragma unroll 4
+            for (int c4 = 0; c4 < lim; c4 += 4) {
+                v2f vv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) vv[j] = *(const v2f*)(s_v + (c4 + j) * 64 + 2 * ep);
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const v4f pp = *(const v4f*)(s_p + (4 * rq + rr) * AT_PPITCH + vs * AT_VSUB + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[rr][j] += (v2f){pp[j], pp[j]} * vv[j];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- output rows in the activation dtype (store_row, gten/ops.h:73-96): a Q8 block = 16 lanes x 2 elements
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        v2f o = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) o += acc[rr][j];
+        const float amax = row16_max(fmaxf(fabsf(o.x), fabsf(o.y)));
+        const Q8Scale sc = q8_scale_from_absmax(amax);
+        const int row = r0 + 4 * rq + rr;
+        if (row < n) {
+            uint8_t* blk = out + (size_t)row * out_pitch + (size_t)h * 68 + (size_t)(ep >> 4) * GTEN_Q8_BYTES;
+            const unsigned b0 = (unsigned)(uint8_t)(int8_t)q8_round(o.x, sc.scale), b1 = (unsigned)(uint8_t)(int8_t)q8_round(o.y, sc.scale);
+            *(uint16_t*)(blk + 2 + 2 * (ep & 15)) = (uint16_t)(b0 | (b1 << 8));
+            if ((ep & 15) == 0) *(uint16_t*)blk = sc.d16;
+        }
+    }
+}
+
+} // namespace
+
+int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
+                           size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos)
+{
+    const int rows = n - start_pos;
+    const dim3 grid(n_heads, (rows + AT_ROWS - 1) / AT_ROWS);
+    GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_q8, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
+               (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+    return 0;
+}

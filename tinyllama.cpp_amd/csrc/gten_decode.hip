@@ -105,6 +105,8 @@ struct Gemv8Args {
     int best_stride;              // best_val / best_idx
     // k_dec_gemvm + EPI_SILUMUL: where the FFN activation is staged (its INPUT stage is act_*)
     int8_t* out_q; float* out_d; int* out_sum; float* out_f;
+    // the qkv launch clears the attention arrival counters of the launch that follows it
+    unsigned* zero_words; int zero_count;
 };
 
 // ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         if (F16W) s.row = a.act_f + (size_t)seq * d;
     }
     const bool stores_x = (EPI == EPI_STAGE) || blockIdx.x == 0;
+    if (a.zero_words && blockIdx.x == 0 && (int)threadIdx.x < a.zero_count) a.zero_words[threadIdx.x] = 0u;
     const int gi = threadIdx.x, base = gi * EPT, blk = gi / LPB, sub = gi % LPB;
     const bool on = base < d;                     // lanes past the row re-read group 0 (never used):
     const int sbase = on ? base : 0;              // an unconditional load has no select on its result
@@ -713,8 +716,9 @@ __device__ __forceinline__ AttnArgs attn_for_seq(const AttnArgs& a, int seq)
 // value) and, for Q8, leaves quants/deltas in qi8/qd/qd16.  The rotate-half
 // partner (j, j + d_head/2) lives d_head/2 lanes away: one xor-shuffle.
 // gten/modules.cpp:196-201 + gten/ops.h:714-755
-__device__ __forceinline__ float head_prep(float raw, bool act, bool do_rope, int pos, int d_head, int adtype,
-                                           const float2* __restrict__ rope, int8_t* qi8, float* qd, uint16_t* qd16)
+// (cs = the rotation of this lane's pair, rope[pos * d_head/2 + (t & (d_head/2 - 1))], loaded by the caller)
+__device__ __forceinline__ float head_prep_cs(float raw, bool act, bool do_rope, const float2 cs, int d_head, int adtype,
+                                              int8_t* qi8, float* qd, uint16_t* qd16)
 {
     const int t = threadIdx.x & 63;
     float v = act ? raw : 0.f;
@@ -729,8 +733,6 @@ __device__ __forceinline__ float head_prep(float raw, bool act, bool do_rope, in
         const int half = d_head >> 1;
         const float other = __shfl_xor(v, half, 64);
         const bool lo = (t & half) == 0;
-        const int j = t & (half - 1);
-        const float2 cs = rope[(size_t)pos * half + j];
         const float x0 = lo ? v : other, x1 = lo ? other : v;
         v = lo ? (x0 * cs.x - x1 * cs.y) : (x0 * cs.y + x1 * cs.x);
         if (!act) v = 0.f;
@@ -747,6 +749,15 @@ __device__ __forceinline__ float head_prep(float raw, bool act, bool do_rope, in
         v = h2f(f2h(v));
     }
     return v;
+}
+
+__device__ __forceinline__ float head_prep(float raw, bool act, bool do_rope, int pos, int d_head, int adtype,
+                                           const float2* __restrict__ rope, int8_t* qi8, float* qd, uint16_t* qd16)
+{
+    const int half = d_head >> 1;
+    float2 cs = make_float2(1.f, 0.f);
+    if (do_rope) cs = rope[(size_t)pos * half + ((threadIdx.x & 63) & (half - 1))];
+    return head_prep_cs(raw, act, do_rope, cs, d_head, adtype, qi8, qd, qd16);
 }
 
 // pass 1: q.k scores of one head over one 256-position chunk, chunk max and sum
@@ -1088,6 +1099,219 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a0)
     }
 }
 
+// ---- both passes in ONE launch (single-sequence decode, d_head 64)
+//
+// The two passes above are separated only by the softmax statistics of the whole row: 2 floats per
+// chunk.  Here the <= 8 chunk workgroups of a head exchange them INSIDE the launch -- statistics
+// stored with agent-scope (sc1) stores, drained, then one agent-scope atomic add on the head's
+// arrival counter; lane 0 polls that counter, the workgroup barrier releases the other waves, and
+// the statistics are read back with agent-scope loads (MI355X guide, Guideline 16, counter form) --
+// so the scores never leave the registers and the V chunk is requested at kernel entry together with
+// the K rows.  MEASURED SLOWER than the two launches (12.7 us vs 11.3 us at n = 2048: store -> drain ->
+// atomic -> poll -> barrier -> reload is ~3 dependent L2 round trips, more than the 1.6 us launch boundary
+// it removes; tools/microbench_flag_chain.hip shows the same for whole GEMV chains), so it is opt-in
+// (GTEN_HIP_ATTN_ONE_LAUNCH=1) and kept as the parity-tested record of that experiment.
+// Residency: 32 heads x <= 8 chunks = <= 256 workgroups of 256 threads, a fraction of what the chip
+// holds at once, and the previous launch has drained; every spin is bounded and reports through
+// `err`.  The arithmetic is that of the two-pass kernels (same values, same order).
+template <int ADT>
+__global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsigned* __restrict__ arrive, unsigned* __restrict__ err)
+{
+    constexpr int dh = 64, nblk = 2;
+    constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
+    const int n = a.step->n, pos = n - 1;
+    const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= n) return;
+    const int grp = a.n_heads / a.n_kv, g = h / grp;
+    const int kv_dim = a.n_kv * dh;
+    const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
+    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+    const int len = min(DEC_CHUNK, n - c0);
+
+    float* red = (float*)g_smem;                 // 16
+    float* qf = red + 16 + dh;                   // dh
+    float* kf = qf + dh;                         // dh
+    float* qd = kf + dh;                         // 8
+    float* kd = qd + 8;                          // 8
+    uint16_t* d16 = (uint16_t*)(kd + 8);         // 16 halves
+    int8_t* qi8 = (int8_t*)(d16 + 16);           // dh
+    int8_t* ki8 = qi8 + dh;                      // dh
+    int8_t* vi8 = ki8 + dh;                      // dh
+    float* vf = (float*)(g_smem + 1536);         // dh   new v row values (f16 mode)
+    float* p = vf + dh;                          // 256
+    float* part = p + DEC_CHUNK;                 // 256
+    unsigned* vl = (unsigned*)(part + DEC_CHUNK);// DEC_CHUNK * NW dwords
+
+    // ---- request, in the order they are needed: this wave's new head row and its rotation,
+    //      this thread's cached K row, its share of the V chunk
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    const int src = (pw == 0) ? h * dh + t : (pw == 1) ? a.n_embd + g * dh + t : (pw == 2) ? a.n_embd + kv_dim + g * dh + t : 0;
+    const float raw = a.qkv_raw[src];
+    const float2 rot = a.rope[(size_t)pos * (dh / 2) + (t & (dh / 2 - 1))];
+    const int c = c0 + threadIdx.x;
+    const int cs = (c < n && c != pos) ? c : c0;
+    const unsigned* kp = (const unsigned*)(a.kcache + (size_t)cs * a.kv_pitch + (size_t)g * head_bytes);
+    unsigned kw[NW], vw[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) kw[j] = kp[j];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int idx = threadIdx.x + k * 256;
+        int row = idx / NW;
+        const int w = idx - row * NW;
+        if (row >= len || c0 + row == pos) row = 0;           // the new row is patched in from LDS below
+        vw[k] = ((const unsigned*)(a.vcache + (size_t)(c0 + row) * a.kv_pitch + (size_t)g * head_bytes))[w];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
+    const bool writer = has_new && (h % grp == 0);
+    if (pw == 0) {
+        qf[t] = head_prep_cs(raw, true, true, rot, dh, ADT, qi8, qd, d16);
+    } else if (pw == 1 && has_new) {
+        const float v = head_prep_cs(raw, true, true, rot, dh, ADT, ki8, kd, d16 + 4);
+        kf[t] = v;
+        if (writer) {
+            uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+            if (ADT == GTEN_Q8) {
+                uint8_t* blk = krow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                blk[2 + (t & 31)] = (uint8_t)ki8[t];
+                if ((t & 31) == 0) *(uint16_t*)blk = d16[4 + (t >> 5)];
+            } else {
+                ((uint16_t*)krow)[t] = f2h(v);
+            }
+        }
+    } else if (pw == 2 && has_new) {
+        // every workgroup of the new row's chunk needs the new V row for its own p.V; one of them stores it
+        const float v = head_prep_cs(raw, true, false, rot, dh, ADT, vi8, kd + 4, d16 + 8);
+        vf[t] = v;
+        if (writer) {
+            uint8_t* vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+            if (ADT == GTEN_Q8) {
+                uint8_t* blk = vrow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                blk[2 + (t & 31)] = (uint8_t)vi8[t];
+                if ((t & 31) == 0) *(uint16_t*)blk = d16[8 + (t >> 5)];
+            } else {
+                ((uint16_t*)vrow)[t] = f2h(v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: this thread's score, the chunk's max and sum of exponentials
+    const float scale = 1.0f / sqrtf((float)dh);
+    float sc = -INFINITY;
+    if (c < n) {
+        float acc = 0.f;
+        if (ADT == GTEN_Q8) {
+            const int* qi = (const int*)qi8;
+            if (c == pos) {
+                const int* ki = (const int*)ki8;
+#pragma unroll
+                for (int b = 0; b < nblk; b++) {
+                    int isum = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) isum = dot4(qi[b * 8 + j], ki[b * 8 + j], isum);
+                    acc += (float)isum * (qd[b] * kd[b]);
+                }
+            } else {
+                int isum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) isum = dot4(qi[j], (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16), isum);
+                acc += (float)isum * (qd[0] * h2f((uint16_t)(kw[0] & 0xffffu)));
+                isum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) isum = dot4(qi[8 + j], (int)kw[9 + j], isum);
+                acc += (float)isum * (qd[1] * h2f((uint16_t)(kw[8] >> 16)));
+            }
+        } else {
+            if (c == pos) {
+                for (int e = 0; e < dh; e++) acc += qf[e] * kf[e];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    acc += qf[2 * j] * h2f((uint16_t)(kw[j] & 0xffffu));
+                    acc += qf[2 * j + 1] * h2f((uint16_t)(kw[j] >> 16));
+                }
+            }
+        }
+        sc = acc * scale;
+    }
+    const float mx = block_max(sc, red);
+    const float ex = (c < n) ? expf(sc - mx) : 0.f;
+    const float sm = block_sum(ex, red);
+
+    // ---- the head's chunks exchange their statistics
+    float* st = a.stats + (size_t)h * a.n_chunks * 2;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(st + chunk * 2 + 0, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st + chunk * 2 + 1, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // both stores have left before the arrival is counted
+        __hip_atomic_fetch_add(arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(arrive + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+    // all 16 words requested at once (words of chunks past nch are stale or another head's: discarded)
+    float sj[8], mj[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        mj[j] = __hip_atomic_load(st + j * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sj[j] = __hip_atomic_load(st + j * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; j++) M = (j < nch) ? fmaxf(M, mj[j]) : M;
+    float S = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float term = sj[j] * expf(mj[j] - M);
+        S = (j < nch) ? S + term : S;
+    }
+
+    // ---- pass 2: probabilities rounded to the activation dtype, times V
+    p[threadIdx.x] = (c < n) ? expf(sc - M) / S : 0.f;
+    round_row_inplace(p, ADT, len);
+#pragma unroll
+    for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
+    __syncthreads();
+    if (has_new && threadIdx.x < 64) {
+        // the new V row comes from LDS (its bytes may not have reached the cache yet)
+        uint8_t* row = (uint8_t*)vl + (size_t)(pos - c0) * (NW * 4);
+        if (ADT == GTEN_Q8) {
+            row[(t < 32) ? 2 + t : 36 + (t - 32)] = (uint8_t)vi8[t];
+            if ((t & 31) == 0) *(uint16_t*)(row + (t >> 5) * 34) = d16[8 + (t >> 5)];
+        } else {
+            ((uint16_t*)row)[t] = f2h(vf[t]);
+        }
+    }
+    __syncthreads();
+
+    const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const uint8_t* vb = (const uint8_t*)vl;
+    float acc = 0.f;
+    if (ADT == GTEN_Q8) {
+        const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+#pragma unroll 8
+        for (int cl = cg; cl < len; cl += 4) {
+            const uint8_t* row = vb + (size_t)cl * 68;
+            acc += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
+        }
+    } else {
+        for (int cl = cg; cl < len; cl += 4) acc += p[cl] * h2f(((const uint16_t*)(vb + (size_t)cl * 128))[e]);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < dh) {
+        float o = 0.f;
+        for (int gi = 0; gi < 4; gi++) o += part[gi * dh + threadIdx.x];
+        a.att_part[((size_t)h * a.n_chunks + chunk) * dh + threadIdx.x] = o;
+    }
+}
+
 // greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424).
 // Works on (value, index) candidates: either the logits themselves (idx == null)
 // or the per-wave winners the lm_head kernel left behind.
@@ -1157,6 +1381,8 @@ struct gten_hip_decoder {
     int* stg_sum = nullptr;
     float* stg_f = nullptr;
     float* logits_m = nullptr;     // [n_seq][n_vocab]
+    unsigned* arrive = nullptr;    // per-head arrival counters of the one-launch attention (+ 1 error word)
+    bool fused_attn = false;
     int n_chunks = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -1230,6 +1456,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         a.step = dc->step; a.d_in = E; a.n_mats = 3;
         set_mat(a, 0, L.wq, WT, E, E); set_mat(a, 1, L.wk, WT, KV, E); set_mat(a, 2, L.wv, WT, KV, E);
         a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = xbuf;
+        if (dc->fused_attn) { a.zero_words = dc->arrive; a.zero_count = d.n_heads; }
         if (l == 0) {
             a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
             rc = launch_gemv8<WT, PRO_EMBED, NE, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
@@ -1245,7 +1472,15 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         t.n_chunks = dc->n_chunks; t.n_embd = E;
         const dim3 agrid(d.n_heads, dc->n_chunks);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        if (int arc = launch_attention(t, agrid, smem1)) return arc;
+        if (dc->fused_attn) {
+            const size_t nw = (d.adtype == GTEN_Q8) ? 17 : 32;
+            const size_t smemf = 1536 + (size_t)(dh + 2 * DEC_CHUNK) * 4 + (size_t)DEC_CHUNK * nw * 4;
+            if (d.adtype == GTEN_Q8) {
+                DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_fused64<GTEN_Q8>), agrid, dim3(256), smemf, t, dc->arrive, dc->arrive + d.n_heads);
+            } else {
+                DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_fused64<GTEN_F16>), agrid, dim3(256), smemf, t, dc->arrive, dc->arrive + d.n_heads);
+            }
+        } else if (int arc = launch_attention(t, agrid, smem1)) return arc;
         Gemv8Args o{};
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
         o.att_part = dc->att_part; o.d_head = dh; o.n_chunks = dc->n_chunks;
@@ -1450,7 +1685,8 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     GTR_CHECK(hipMalloc((void**)&dc->proj_raw, S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->down_raw, S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->scores, S * (size_t)d.n_heads * d.max_ctx * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->stats, S * (size_t)d.n_heads * dc->n_chunks * 2 * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->stats, (S * (size_t)d.n_heads * dc->n_chunks * 2 + 16) * 4));   // + 8 chunks of slack: the one-launch kernel reads 8 per head
+    GTR_CHECK(hipMemset(dc->stats, 0, (S * (size_t)d.n_heads * dc->n_chunks * 2 + 16) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->att_part, S * (size_t)d.n_heads * dc->n_chunks * dh * 4));
     // residual rows between kernels: f32 rows of exact storage values
     GTR_CHECK(hipMalloc((void**)&dc->xbuf, S * (size_t)E * 4));
@@ -1483,6 +1719,15 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
         GTR_CHECK(hipMalloc((void**)&dc->kv_tab, tab.size() * sizeof(void*)));
         GTR_CHECK(hipMemcpy(dc->kv_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
     }
+    // GTEN_HIP_ATTN_ONE_LAUNCH=1: single-sequence decode with 64-wide heads runs scores, softmax and p.V in
+    // one launch (k_dec_attn_fused64).  Off by default: measured 12.7 us against 4.9 + 6.4 us for the two
+    // launches at n = 2048 -- an in-launch exchange through L2 costs more than a kernel boundary here.
+    {
+        const char* one = getenv("GTEN_HIP_ATTN_ONE_LAUNCH");
+        dc->fused_attn = n_seq == 1 && dh == 64 && dc->n_chunks <= 8 && d.n_heads <= 512 && one && one[0] == '1';
+    }
+    GTR_CHECK(hipMalloc((void**)&dc->arrive, (size_t)(d.n_heads + 1) * 4));
+    GTR_CHECK(hipMemset(dc->arrive, 0, (size_t)(d.n_heads + 1) * 4));
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
     *out = dc;
     return 0;
@@ -1511,7 +1756,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
-                    dc->logits_m, (void*)dc->kv_tab};
+                    dc->logits_m, (void*)dc->kv_tab, dc->arrive};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;
@@ -1614,7 +1859,10 @@ int gten_hip_decoder_result_seq(gten_hip_decoder* dc, int seq, int n, int32_t* a
     GTR_REQUIRE(dc && argmax_host && n >= 1 && n <= dc->d.max_ctx, "decoder_result: bad arguments");
     GTR_REQUIRE(seq >= 0 && seq < dc->n_seq, "decoder_result: sequence %d outside [0, %d)", seq, dc->n_seq);
     GTR_CHECK(hipMemcpyAsync(argmax_host, dc->result + (size_t)seq * (dc->d.max_ctx + 2) + n, 4, hipMemcpyDeviceToHost, stream()));
+    unsigned stalled = 0;
+    if (dc->fused_attn) GTR_CHECK(hipMemcpyAsync(&stalled, dc->arrive + dc->d.n_heads, 4, hipMemcpyDeviceToHost, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
+    GTR_REQUIRE(!stalled, "decoder: an attention workgroup gave up waiting for its head's chunks (results invalid)");
     return 0;
 }
 

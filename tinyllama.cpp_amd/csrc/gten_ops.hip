@@ -375,7 +375,7 @@ int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch, const void* w
     // prefill-sized calls go to the matrix cores (gten_mfma.hip); the row-per-workgroup
     // kernel below streams the weights once per row and is meant for a handful of rows
     static const bool no_mfma = [] { const char* e = std::getenv("GTEN_HIP_NO_MFMA"); return e && e[0] == '1'; }();
-    if (n - start_pos >= GTEN_MFMA_MIN_ROWS && !no_mfma)
+    if (n - start_pos >= GTEN_MFMA_MIN_ROWS && d_in % 128 == 0 && !no_mfma)   // the MFMA kernel stages 4 quant blocks at a time
         return gten_launch_matmul_mfma(x, x_dtype, x_pitch, w, w_dtype, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
     const dim3 grid((d_out + 31) / 32, n - start_pos), block(256);
     const size_t act = (w_dtype == GTEN_F16) ? (size_t)d_in * 4 : (size_t)(d_in / 32) * 40;
@@ -464,6 +464,12 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
     GTR_REQUIRE(q_pitch >= gten_hip_row_bytes(dtype, n_heads * d_head) && out_pitch >= gten_hip_row_bytes(dtype, n_heads * d_head) &&
                 kv_pitch >= gten_hip_row_bytes(dtype, n_kv_heads * d_head), "qkv_attn: pitch too small");
     GTR_REQUIRE(n - start_pos <= 65535 && n <= 12288, "qkv_attn: context %d too long for this kernel", n);
+    if (dtype == GTEN_Q8 && d_head == 64 && n - start_pos >= GTEN_ATTN_TILED_MIN_ROWS) {
+        // prompt processing: 32 rows of a head per workgroup, int8 MFMA scores (same bytes as k_attn below)
+        const char* off = getenv("GTEN_HIP_NO_TILED_ATTN");
+        if (!(off && off[0] == '1'))
+            return gten_launch_attn_tiled(q, k, v, out, q_pitch, kv_pitch, out_pitch, n, n_heads, n_kv_heads, start_pos);
+    }
     const int p_cap = (n + 31) & ~31;
     const size_t smem = (size_t)(16 + d_head + 8 + d_head + 256 + p_cap) * 4;
     GTR_LAUNCH(KT_ATTN, k_attn, dim3(n_heads, n - start_pos), dim3(256), smem,

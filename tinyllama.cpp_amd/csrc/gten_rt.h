@@ -44,13 +44,18 @@ int rope_table(int d_head, const float2** out);
 enum {
     KT_PACK = 0, KT_EMBED, KT_MATMUL, KT_RMSNORM, KT_ROPE, KT_ELEMWISE, KT_ATTN,
     KT_DEC_GEMV_QKV, KT_DEC_ATTN_SCORE, KT_DEC_ATTN_PV, KT_DEC_GEMV_O, KT_DEC_GEMV_GATEUP, KT_DEC_GEMV_DOWN,
-    KT_DEC_GEMV_HEAD, KT_DEC_ARGMAX, KT_MATMUL_MFMA, KT_DEC_STAGE, KT_COUNT
+    KT_DEC_GEMV_HEAD, KT_DEC_ARGMAX, KT_MATMUL_MFMA, KT_DEC_STAGE, KT_ATTN_TILED, KT_COUNT
 };
 
 // gten_mfma.hip: ops::matmul_2d for >= GTEN_MFMA_MIN_ROWS new rows
 #define GTEN_MFMA_MIN_ROWS 16
 int gten_launch_matmul_mfma(const void* x, int x_dtype, size_t x_pitch, const void* w, int w_dtype,
                             void* out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos);
+
+// gten_attn_tiled.hip: ops::qkv_attn for >= GTEN_ATTN_TILED_MIN_ROWS new rows (Q8 activations, d_head 64)
+#define GTEN_ATTN_TILED_MIN_ROWS 16
+int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
+                           size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos);
 
 namespace gtr {
 bool prof_on();
