@@ -89,7 +89,7 @@ __device__ __forceinline__ void tile_scores(const QFrag& q, const uint8_t* __res
     }
 }
 
-__global__ __launch_bounds__(256) void k_attn_tiled_q8(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_tiled_q8(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
                                                        const uint8_t* __restrict__ v, uint8_t* __restrict__ out,
                                                        size_t q_pitch, size_t kv_pitch, size_t out_pitch,
                                                        int n_heads, int n_kv, int n, int start_pos)
