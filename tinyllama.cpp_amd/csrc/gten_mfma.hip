@@ -15,13 +15,17 @@
 // MFMAs and a dequantized weight fragment feeds WM, so neither LDS bandwidth nor
 // the dequantization bounds the loop -- the per-block rescale does (3 plain f32
 // instructions per output, the price of the reference's exact block order).
-// Activations of KB quant blocks are converted to f16 once per workgroup into a
-// double-buffered LDS stage (one barrier per stage); the raw weight bytes and the
-// raw activation bytes of the NEXT stage are requested before the current stage is
-// computed.  The K order inside a fragment is permuted (0,2,1,3 per 4 quants) on
-// BOTH operands, which turns the nibble/byte -> f16 expansion into mask-and-or
-// instead of byte shuffles.  Results leave straight from the accumulators: a Q8
-// output block is two adjacent 16-wide tiles of the same wave (DPP row maximum).
+// Memory side: every global access is a 16-byte piece of a contiguous run.  Q8
+// activations are expanded ONCE per call to f16 rows + f32 deltas (k_act_to_f16,
+// a few microseconds) instead of once per column of workgroups; both operands of
+// a stage (4 quant blocks) are requested a stage ahead into registers and land in
+// a double-buffered LDS stage (one barrier per stage).  The first version loaded
+// weight fragments straight from global memory, 8 bytes per lane from 16 rows per
+// instruction: the kernel was bound by L1 tag lookups at 1/5 of its VALU limit.
+// The K order inside a fragment is permuted (0,2,1,3 per 4 quants) on BOTH
+// operands, which turns the nibble/byte -> f16 expansion into mask-and-or instead
+// of byte shuffles.  Results leave straight from the accumulators: a Q8 output
+// block is two adjacent 16-wide tiles of the same wave (DPP row maximum).
 #include "gten_dev.h"
 #include "gten_rt.h"
 
@@ -89,55 +93,150 @@ __device__ __forceinline__ float row16_absmax(float v)
     return fmaxf(v, dpp_mov<0x140>(v));
 }
 
-template <int WT, int WM, int WN>
+template <int WT, int WM, int WN, int KB_ = 4>
 struct MfmaCfg {
+    static constexpr bool QUANT = (WT != GTEN_F16);
     static constexpr int BM = 32 * WM, BN = 32 * WN;       // workgroup tile: 2 x 2 waves
-    static constexpr int KB = 4;                           // quant blocks per stage; staging threads = BM rows x 2 block pairs
-    static constexpr int APITCH = KB * 64 + 16;            // bytes per staged row (odd multiple of 16: conflict-free b128 reads)
-    static constexpr int STAGE = BM * APITCH + KB * BM * 4;  // f16 activations + f32 deltas
+    static constexpr int KB = KB_;                         // quant blocks per stage (4 = 128 K; 2 halves the LDS stage: one more workgroup per CU)
+    static constexpr int APITCH = KB * 64 + 16;            // bytes per staged activation row (odd multiple of 16: conflict-free b128 reads)
+    static constexpr int WROW = (WT == GTEN_Q4) ? KB * 16 : (WT == GTEN_Q8 ? KB * 32 : 0);   // weight bytes per feature per stage
+    static constexpr int WPITCH = WROW + 8;
+    static constexpr int DA_PIECES = (BM * KB + 255) / 256;
+    // (the delta regions are padded to one slot per staging thread: every thread loads and stores, no branch)
+    static constexpr int A_BYTES = BM * APITCH, DA_BYTES = QUANT ? DA_PIECES * 256 * 4 : 0;
+    static constexpr int W_BYTES = QUANT ? BN * WPITCH : 0, DW_BYTES = QUANT ? KB * 256 * 4 : 0;
+    static constexpr int STAGE = A_BYTES + DA_BYTES + W_BYTES + DW_BYTES;
+    static constexpr int A_PIECES = BM * KB * 4 / 256;     // 16-byte pieces of the activation tile per thread
+    static constexpr int W_PIECES = QUANT ? (BN * WROW / 16 + 255) / 256 : 0;
     static constexpr size_t smem() { return (size_t)2 * STAGE; }
 };
 
+// Q8 activation rows [start_pos, n) -> f16 rows in the fragment order (q0,q2,q1,q3 per 4) + f32 block deltas.
+// One thread per (row, quant block).
+__global__ __launch_bounds__(256) void k_act_to_f16(const uint8_t* __restrict__ x, size_t x_pitch, int rows, int nb, int start_pos,
+                                                    uint4* __restrict__ a16, float* __restrict__ da)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nb) return;
+    const int r = idx / nb, b = idx - r * nb;
+    const uint16_t* blk = (const uint16_t*)(x + (size_t)(start_pos + r) * x_pitch + (size_t)b * GTEN_Q8_BYTES);   // 2-byte aligned
+    unsigned q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = (unsigned)blk[1 + 2 * i] | ((unsigned)blk[2 + 2 * i] << 16);
+    uint4* dst = a16 + (size_t)idx * 4;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        unsigned f[4];
+        int8x4_to_f16(q[i], f[0], f[1]);
+        int8x4_to_f16(q[i + 1], f[2], f[3]);
+        dst[i >> 1] = make_uint4(f[0], f[1], f[2], f[3]);
+    }
+    da[idx] = h2f(blk[0]);
+}
+
 // (2 waves per SIMD = a 256-VGPR budget: the block sums then come back in VGPRs instead of AGPRs, which
 //  would cost four v_accvgpr_read per MFMA in a loop that is bound by VALU issue)
-template <int WT, int WM, int WN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_matmul_mfma(const uint8_t* __restrict__ x, size_t x_pitch, const void* __restrict__ w,
-                                                     uint8_t* __restrict__ out, int out_dtype, size_t out_pitch,
-                                                     int n, int d_in, int d_out, int start_pos)
+// a16: f16 activation rows of the NEW rows (row 0 = start_pos), pitch d_in * 2 (quantized) or x itself (f16 weights)
+template <int WT, int WM, int WN, int KB_>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_matmul_mfma(
+    const uint8_t* __restrict__ a16, size_t a_pitch, const float* __restrict__ da_rows, const void* __restrict__ w,
+    uint8_t* __restrict__ out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
 {
-    using C = MfmaCfg<WT, WM, WN>;
-    constexpr int BM = C::BM, KB = C::KB, APITCH = C::APITCH, PAIRS = KB / 2;
-    constexpr bool QUANT = (WT != GTEN_F16);
+    using C = MfmaCfg<WT, WM, WN, KB_>;
+    constexpr int BM = C::BM, BN = C::BN, KB = C::KB, APITCH = C::APITCH, WPITCH = C::WPITCH, WROW = C::WROW;
+    constexpr bool QUANT = C::QUANT;
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     const int g = lane >> 4, l16 = lane & 15;
-    const int row0 = start_pos + blockIdx.y * BM;
-    const int col0 = blockIdx.x * C::BN + wc * 16 * WN;
+    const int rows = n - start_pos;
+    const int row0 = blockIdx.y * BM;                        // relative to start_pos
+    const int colw = blockIdx.x * BN;                        // first feature of the workgroup
+    const int col0 = colw + wc * 16 * WN;                    // first feature of this wave
     const int nb = d_in >> 5;
-    const int nstage = (nb + KB - 1) / KB;
+    const int nstage = nb / KB;
     const PackedW pw = packed_view(w, WT, d_out, d_in);
     const int nibble_shift = (g < 2) ? 4 : 0;
     unsigned nib_mask = 0x000f000fu;
     asm volatile("" : "+v"(nib_mask));                       // keep it in a register (see and_or)
 
-    // this lane's weight rows (one per feature tile, clamped) as 32-bit byte offsets: every load below is
-    // "uniform base of the stage (SGPRs) + lane offset (one VGPR) + immediate", no per-load address arithmetic
-    unsigned wq_off[WN], wd_off[WN];
-    size_t wrow[WN];
+    // ---- staging roles: 16-byte pieces, consecutive threads = consecutive pieces of a row.  All loads are
+    //      buffer loads: descriptor (SGPRs) + lane offset (one VGPR, fixed for the kernel) + stage offset (one SGPR);
+    //      every thread issues every load (out-of-range pieces read 0 or a neighbour and are never used), so the
+    //      loop has no branch around a memory instruction and the in-order vmcnt bookkeeping stays exact.
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a16, 0, (int)((size_t)rows * a_pitch), 0x00020000);
+    const auto rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)da_rows, 0, QUANT ? rows * nb * 4 : 0, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)pw.qs, 0, QUANT ? (int)((size_t)d_out * nb * (WT == GTEN_Q4 ? 16 : 32)) : 0, 0x00020000);
+    const auto rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)pw.ds, 0, QUANT ? d_out * nb * 2 : 0, 0x00020000);
+    // activations: piece p -> (row p / (KB*4), piece-in-row p % (KB*4)); a stage of a row is KB * 64 contiguous bytes
+    unsigned a_src[C::A_PIECES], a_dst[C::A_PIECES];
 #pragma unroll
-    for (int j = 0; j < WN; j++) {
-        const int col = col0 + 16 * j + l16;
-        wrow[j] = (size_t)(col < d_out ? col : d_out - 1);
-        if (WT == GTEN_Q4) wq_off[j] = (unsigned)wrow[j] * nb * 16 + (g & 1) * 8;
-        else wq_off[j] = (unsigned)wrow[j] * nb * 32 + (g >> 1) * nb * 16 + (g & 1) * 8;
-        wd_off[j] = (unsigned)wrow[j] * nb * 2;
+    for (int k = 0; k < C::A_PIECES; k++) {
+        const int p = threadIdx.x + 256 * k, r = p / (KB * 4), c = p % (KB * 4);
+        a_src[k] = (unsigned)min(row0 + r, rows - 1) * (unsigned)a_pitch + c * 16;
+        a_dst[k] = r * APITCH + c * 16;
     }
+    // activation deltas: one float per (row, block): BM * KB of them, DA_PIECES per thread (slots past them are padding)
+    constexpr int DA_PIECES = C::DA_PIECES;
+    unsigned da_src[DA_PIECES], da_dst[DA_PIECES];
+#pragma unroll
+    for (int k = 0; k < DA_PIECES; k++) {
+        const int p = threadIdx.x + 256 * k, r = p / KB, b = p % KB;
+        da_src[k] = ((unsigned)min(row0 + r, rows - 1) * nb + b) * 4;
+        da_dst[k] = (p < BM * KB) ? b * BM + r : p;
+    }
+    // weights: piece p -> (feature p / (WROW/16), piece-in-row); Q8 rows are two planes of nb * 16 bytes
+    constexpr int WP = C::W_PIECES > 0 ? C::W_PIECES : 1;
+    static_assert(!QUANT || BN * (WROW / 16) == C::W_PIECES * 256, "weight tile must be a whole number of pieces per thread");
+    unsigned w_src[WP], w_dst[WP];
+#pragma unroll
+    for (int k = 0; k < C::W_PIECES; k++) {
+        const int p = threadIdx.x + 256 * k, pr = WROW / 16, f = p / pr, c = p % pr;
+        const unsigned frow = (unsigned)min(colw + f, d_out - 1);
+        if (WT == GTEN_Q4) w_src[k] = frow * nb * 16 + c * 16;
+        else w_src[k] = frow * nb * 32 + (c / KB) * nb * 16 + (c % KB) * 16;     // plane c / KB, block c % KB
+        w_dst[k] = f * WPITCH + c * 16;
+    }
+    // weight deltas: thread -> feature t: KB halves per stage (threads past BN fill padding slots)
+    const unsigned dw_src = (unsigned)min(colw + (int)threadIdx.x, d_out - 1) * nb * 2;
 
-    // staging role: thread -> (row, pair of quant blocks) of the stage (the first 2 BM threads)
-    const bool stager = (int)threadIdx.x < BM * PAIRS;
-    const int srow = stager ? threadIdx.x / PAIRS : 0, spair = threadIdx.x % PAIRS;
-    const unsigned x_off = (unsigned)((row0 + srow < n ? row0 + srow : n - 1) - start_pos) * (unsigned)x_pitch + spair * (QUANT ? 2 * GTEN_Q8_BYTES : 128);
-    const uint8_t* x0 = x + (size_t)start_pos * x_pitch;
+    struct Raw { v4i_t a[C::A_PIECES]; v4i_t w[WP]; float da[DA_PIECES]; v2i_t dw; };
+    auto load_stage = [&](int s, Raw& r) {
+#pragma unroll
+        for (int k = 0; k < C::A_PIECES; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_src[k], s * (KB * 64), 0);
+        if (QUANT) {
+#pragma unroll
+            for (int k = 0; k < C::W_PIECES; k++) r.w[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_src[k], s * (KB * 16), 0);
+#pragma unroll
+            for (int k = 0; k < DA_PIECES; k++) r.da[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_da, da_src[k], s * (KB * 4), 0));
+            if (KB == 4) r.dw = __builtin_amdgcn_raw_buffer_load_b64(rs_dw, dw_src, s * (KB * 2), 0);
+            else r.dw[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_dw, dw_src, s * (KB * 2), 0);
+        }
+    };
+    auto store_stage = [&](const Raw& r, int buf) {
+        uint8_t* sa = g_smem + buf * C::STAGE;
+#pragma unroll
+        for (int k = 0; k < C::A_PIECES; k++) *(v4i_t*)(sa + a_dst[k]) = r.a[k];
+        if (QUANT) {
+            float* sda = (float*)(sa + C::A_BYTES);
+            uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
+            float* sdw = (float*)(sw + C::W_BYTES);
+#pragma unroll
+            for (int k = 0; k < DA_PIECES; k++) sda[da_dst[k]] = r.da[k];
+#pragma unroll
+            for (int k = 0; k < C::W_PIECES; k++) {
+                *(v2i_t*)(sw + w_dst[k]) = (v2i_t){r.w[k][0], r.w[k][1]};
+                *(v2i_t*)(sw + w_dst[k] + 8) = (v2i_t){r.w[k][2], r.w[k][3]};
+            }
+            sdw[0 * 256 + threadIdx.x] = h2f((uint16_t)((unsigned)r.dw[0] & 0xffffu));
+            sdw[1 * 256 + threadIdx.x] = h2f((uint16_t)((unsigned)r.dw[0] >> 16));
+            if (KB == 4) {
+                sdw[2 * 256 + threadIdx.x] = h2f((uint16_t)((unsigned)r.dw[1] & 0xffffu));
+                sdw[3 * 256 + threadIdx.x] = h2f((uint16_t)((unsigned)r.dw[1] >> 16));
+            }
+        }
+    };
 
     floatx4 acc[WM][WN];
 #pragma unroll
@@ -145,116 +244,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int j = 0; j < WN; j++) acc[t][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- raw bytes of one stage, in registers
-    struct ARaw { unsigned q[17]; uint4 h[8]; };
-    struct BRaw { uint2 q[WN][KB]; uint2 d[WN][KB / 4]; };
-    auto load_a = [&](int s, ARaw& a) {
-        if (!stager) return;
-        const int sn = min(s, nstage - 1);                              // past the end: re-reads the last stage (never stored)
-        if (QUANT) {
-            // two consecutive 34-byte blocks = 68 bytes, 4-byte aligned: [d0 | q0 x32 | d1 | q1 x32]
-            const uint8_t* sbase = x0 + (size_t)sn * (KB * GTEN_Q8_BYTES);
+    // f16 weights: fragments straight from global memory (16 bytes per lane, 64-byte runs per row)
+    size_t wrow16[WN];
 #pragma unroll
-            for (int i = 0; i < 17; i++) a.q[i] = *(const unsigned*)(sbase + x_off + 4 * i);
-        } else {
-            const uint8_t* sbase = x0 + (size_t)sn * (KB * 64);
-#pragma unroll
-            for (int i = 0; i < 8; i++) a.h[i] = *(const uint4*)(sbase + x_off + 16 * i);
-        }
-    };
-    auto store_a = [&](const ARaw& a, int buf) {
-        if (!stager) return;
-        uint8_t* lds_a = g_smem + buf * C::STAGE;
-        float* lds_da = (float*)(lds_a + BM * APITCH);
-        uint4* dst = (uint4*)(lds_a + srow * APITCH + spair * 128);
-        if (QUANT) {
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {       // block 0: quants straddle dwords by two bytes
-                unsigned f[4];
-                int8x4_to_f16(__builtin_amdgcn_alignbit(a.q[i + 1], a.q[i], 16), f[0], f[1]);
-                int8x4_to_f16(__builtin_amdgcn_alignbit(a.q[i + 2], a.q[i + 1], 16), f[2], f[3]);
-                dst[i >> 1] = make_uint4(f[0], f[1], f[2], f[3]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {       // block 1: quants are dword aligned
-                unsigned f[4];
-                int8x4_to_f16(a.q[9 + i], f[0], f[1]);
-                int8x4_to_f16(a.q[10 + i], f[2], f[3]);
-                dst[4 + (i >> 1)] = make_uint4(f[0], f[1], f[2], f[3]);
-            }
-            lds_da[(spair * 2) * BM + srow] = h2f((uint16_t)(a.q[0] & 0xffffu));
-            lds_da[(spair * 2 + 1) * BM + srow] = h2f((uint16_t)(a.q[8] >> 16));
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) dst[i] = a.h[i];
-        }
-    };
-    // weight bytes: ONE stage-deep register buffer refilled slot by slot -- the bytes of (stage s + 1, block kb)
-    // are requested right after those of (s, kb) were expanded, a whole stage of compute ahead of their use
-    auto load_bq = [&](int s, int kb, int j) -> uint2 {
-        const uint8_t* sbase = pw.qs + (size_t)min(s, nstage - 1) * (KB * 16);
-        return *(const uint2*)(sbase + wq_off[j] + kb * 16);
-    };
-    auto load_bd = [&](int s, int k4, int j) -> uint2 {
-        const uint8_t* sbase = (const uint8_t*)pw.ds + (size_t)min(s, nstage - 1) * (KB * 2);
-        return *(const uint2*)(sbase + wd_off[j] + k4 * 8);
-    };
+    for (int j = 0; j < WN; j++) wrow16[j] = (size_t)min(col0 + 16 * j + l16, d_out - 1) * d_in + g * 8;
 
-    ARaw araw;
-    BRaw braw;
-    load_a(0, araw);
-    if (QUANT) {
-#pragma unroll
-        for (int j = 0; j < WN; j++) {
-#pragma unroll
-            for (int kb = 0; kb < KB; kb++) braw.q[j][kb] = load_bq(0, kb, j);
-#pragma unroll
-            for (int k4 = 0; k4 < KB / 4; k4++) braw.d[j][k4] = load_bd(0, k4, j);
-        }
-    }
-    store_a(araw, 0);
+    // Stage s is computed from LDS buffer s & 1 while stage s + 1 waits in registers (stored behind the compute)
+    // and stage s + 2 is requested: two stages of memory latency are covered by one stage of work each.
+    Raw raw0, raw1;
+    load_stage(0, raw0);
+    store_stage(raw0, 0);
+    load_stage(1, raw1);
     __syncthreads();
 
-    // expand block `kb` of the buffered stage `st` into MFMA fragments and refill its slot with stage st + 1
-    // (past the end: an unused re-read -- no branch in the instruction stream)
-    half8 bf[WN];
-    float dw[WN];
-    auto prep_b = [&](int st, int kb) {
-#pragma unroll
-        for (int j = 0; j < WN; j++) {
-            if (QUANT) {
-                bf[j] = weight_frag<WT>(braw.q[j][kb], nibble_shift, nib_mask);
-                const unsigned dpair = (kb & 2) ? braw.d[j][kb >> 2].y : braw.d[j][kb >> 2].x;
-                dw[j] = h2f((uint16_t)((kb & 1) ? (dpair >> 16) : (dpair & 0xffffu)));
-                braw.q[j][kb] = load_bq(st + 1, kb, j);
-                if ((kb & 3) == 3) braw.d[j][kb >> 2] = load_bd(st + 1, kb >> 2, j);
-            } else {
-                bf[j] = *(const half8*)((const uint16_t*)w + wrow[j] * d_in + (size_t)min(st * KB + kb, nb - 1) * 32 + g * 8);
-            }
-        }
-    };
-    prep_b(0, 0);
-
-    for (int s = 0; s < nstage; s++) {
+    auto stage_body = [&](int s, Raw& fetch, const Raw& land) {
         const int buf = s & 1;
-        const uint8_t* lds_a = g_smem + buf * C::STAGE;
-        const float* lds_da = (const float*)(lds_a + BM * APITCH);
-        const bool more = s + 1 < nstage;
-        load_a(s + 1, araw);                     // (past the end: re-reads the last pair, never stored)
+        const uint8_t* sa = g_smem + buf * C::STAGE;
+        const float* sda = (const float*)(sa + C::A_BYTES);
+        const uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
+        const float* sdw = (const float*)(sw + C::W_BYTES);
+        load_stage(s + 2, fetch);
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) {
-            // ---- matrix phase: every MFMA of this quant block is issued before any result is touched, so the
-            //      rescale below never waits on the matrix pipe (and the SIMD's other wave fills it meanwhile)
+            // ---- operands of this quant block
+            half8 bf[WN];
+            float dw[WN];
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                if (QUANT) {
+                    const int f = wc * 16 * WN + 16 * j + l16;
+                    const uint2 by = (WT == GTEN_Q4) ? *(const uint2*)(sw + f * WPITCH + kb * 16 + (g & 1) * 8)
+                                                     : *(const uint2*)(sw + f * WPITCH + (g >> 1) * (KB * 16) + kb * 16 + (g & 1) * 8);
+                    bf[j] = weight_frag<WT>(by, nibble_shift, nib_mask);
+                    dw[j] = sdw[kb * 256 + f];
+                } else {
+                    bf[j] = *(const half8*)((const uint16_t*)w + wrow16[j] + (size_t)(s * KB + kb) * 32);
+                }
+            }
             half8 af[WM];
             float4 da4[WM];
 #pragma unroll
             for (int t = 0; t < WM; t++) {
                 const int trow = wr * 16 * WM + 16 * t;
-                af[t] = *(const half8*)(lds_a + (trow + l16) * APITCH + kb * 64 + g * 16);
-                if (QUANT) da4[t] = *(const float4*)(lds_da + kb * BM + trow + g * 4);
+                af[t] = *(const half8*)(sa + (trow + l16) * APITCH + kb * 64 + g * 16);
+                if (QUANT) da4[t] = *(const float4*)(sda + kb * BM + trow + g * 4);
             }
+            // ---- matrix phase: every MFMA of the block is issued before any result is touched, so the rescale
+            //      never waits on the matrix pipe (and the SIMD's other wave fills it meanwhile)
             floatx4 isum[WM][WN];
-            float dwc[WN];
 #pragma unroll
             for (int t = 0; t < WM; t++)
 #pragma unroll
@@ -266,11 +303,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[j], acc[t][j], 0, 0, 0);
                     }
                 }
-#pragma unroll
-            for (int j = 0; j < WN; j++) dwc[j] = dw[j];
             __builtin_amdgcn_sched_barrier(0);
-            // ---- vector phase: fragments of the next block, then this block's rescale
-            if (kb + 1 < KB) prep_b(s, kb + 1); else prep_b(s + 1, 0);
+            // ---- vector phase: dot += isum * da * dw, left to right like the scalar build (gten/ops.h:311).
+            //      Plain f32 on purpose: packed f32 beside MFMAs is the slower form on gfx950 (build.py)
             if (QUANT) {
 #pragma unroll
                 for (int t = 0; t < WM; t++) {
@@ -278,8 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                     for (int j = 0; j < WN; j++)
 #pragma unroll
-                        for (int i = 0; i < 4; i++)     // dot += isum * da * dw, left to right like the scalar build (gten/ops.h:311);
-                            acc[t][j][i] = acc[t][j][i] + (isum[t][j][i] * da[i]) * dwc[j];   // plain f32 on purpose (build.py)
+                        for (int i = 0; i < 4; i++) acc[t][j][i] = acc[t][j][i] + (isum[t][j][i] * da[i]) * dw[j];
                 }
                 // the accumulators are pinned here: without it the whole stage's rescale sinks behind its last MFMA
 #pragma unroll
@@ -289,8 +323,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_a(araw, buf ^ 1);    // last read two barriers ago
+        if (s + 1 < nstage) store_stage(land, buf ^ 1);    // stage s + 1 into the buffer last read two barriers ago
         __syncthreads();
+    };
+    for (int s = 0; s < nstage; s += 2) {
+        stage_body(s, raw0, raw1);
+        if (s + 1 < nstage) stage_body(s + 1, raw1, raw0);
     }
 
     // ---- rows written in the output dtype straight from the accumulators (gten/ops.h:73-96)
@@ -299,8 +337,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = row0 + wr * 16 * WM + 16 * t + 4 * g + i;
-            const bool rok = r < n;
-            uint8_t* orow = out + (size_t)(rok ? r : n - 1) * out_pitch;
+            const bool rok = r < rows;
+            uint8_t* orow = out + (size_t)(start_pos + (rok ? r : rows - 1)) * out_pitch;
 #pragma unroll
             for (int j = 0; j < WN; j += 2) {
                 const int c0 = col0 + 16 * j + l16, c1 = c0 + 16;
@@ -325,19 +363,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
-template <int WT, int WM, int WN>
+// f16 copy of the new Q8 activation rows, owned by the library and reused call after call (one stream)
+static int act_scratch(size_t a_bytes, size_t d_bytes, uint8_t** a16, float** da)
+{
+    using namespace gtr;
+    static uint8_t* buf_a = nullptr;
+    static float* buf_d = nullptr;
+    static size_t cap_a = 0, cap_d = 0;
+    if (a_bytes > cap_a) {
+        if (buf_a) { GTR_CHECK(hipStreamSynchronize(stream())); GTR_CHECK(hipFree(buf_a)); }
+        buf_a = nullptr; cap_a = 0;
+        GTR_CHECK(hipMalloc((void**)&buf_a, a_bytes + a_bytes / 2));
+        cap_a = a_bytes + a_bytes / 2;
+    }
+    if (d_bytes > cap_d) {
+        if (buf_d) { GTR_CHECK(hipStreamSynchronize(stream())); GTR_CHECK(hipFree(buf_d)); }
+        buf_d = nullptr; cap_d = 0;
+        GTR_CHECK(hipMalloc((void**)&buf_d, d_bytes + d_bytes / 2));
+        cap_d = d_bytes + d_bytes / 2;
+    }
+    *a16 = buf_a; *da = buf_d;
+    return 0;
+}
+
+template <int WT, int WM, int WN, int KB_ = 4>
 static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, int out_dtype, size_t out_pitch,
                       int n, int d_in, int d_out, int start_pos)
 {
     using namespace gtr;
-    using C = MfmaCfg<WT, WM, WN>;
+    using C = MfmaCfg<WT, WM, WN, KB_>;
     static bool attr_set = false;
     if (!attr_set) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem()));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem()));
         attr_set = true;
     }
-    const dim3 grid((d_out + C::BN - 1) / C::BN, (n - start_pos + C::BM - 1) / C::BM), block(256);
-    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN>), grid, block, C::smem(), (const uint8_t*)x, x_pitch, w, (uint8_t*)out,
+    const int rows = n - start_pos, nb = d_in / 32;
+    const uint8_t* a16 = (const uint8_t*)x + (size_t)start_pos * x_pitch;
+    size_t a_pitch = x_pitch;
+    float* da = nullptr;
+    if (C::QUANT) {
+        uint8_t* buf = nullptr;
+        if (int rc = act_scratch((size_t)rows * d_in * 2, (size_t)rows * nb * 4, &buf, &da)) return rc;
+        GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16, dim3((rows * nb + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos,
+                   (uint4*)buf, da);
+        a16 = buf; a_pitch = (size_t)d_in * 2;
+    }
+    const dim3 grid((d_out + C::BN - 1) / C::BN, (rows + C::BM - 1) / C::BM), block(256);
+    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_>), grid, block, C::smem(), a16, a_pitch, (const float*)da, w, (uint8_t*)out,
                out_dtype, out_pitch, n, d_in, d_out, start_pos);
     return 0;
 }
@@ -349,9 +421,11 @@ static int launch_wt(const void* x, size_t x_pitch, const void* w, void* out, in
 {
     const int rows = n - start_pos;
     auto wgs = [&](int bm, int bn) { return ((d_out + bn - 1) / bn) * ((rows + bm - 1) / bm); };
-    static const int forced = [] { const char* e = std::getenv("GTEN_HIP_MFMA_CFG"); return e ? atoi(e) : 0; }();   // tuning aid: 24 | 22 | 12
+    static const int forced = [] { const char* e = std::getenv("GTEN_HIP_MFMA_CFG"); return e ? atoi(e) : 0; }();   // tuning aid: 44 | 24 | 22 | 12
 #define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos)
-    // (<4,4> and <4,2> register tiles do not fit the 256-VGPR budget of the VGPR-destination MFMA form: they spill)
+    if (forced == 44) MF_GO(4, 4);
+    if (forced == 242) return launch_cfg<WT, 2, 4, 2>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    if (forced == 442) return launch_cfg<WT, 4, 4, 2>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
     if (forced == 24) MF_GO(2, 4);
     if (forced == 22) MF_GO(2, 2);
     if (forced == 12) MF_GO(1, 2);
