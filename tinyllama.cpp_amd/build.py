@@ -43,9 +43,9 @@ def _sources(d, exts):
     return sorted(out)
 
 
-# per-file additions.  gten_mfma.hip: packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32) beside MFMAs costs ~3x a
-# plain f32 instruction on gfx950, so the SLP vectorizer must not pair the per-block rescale.
-HIP_FILE_FLAGS = {"gten_mfma.hip": ["-fno-slp-vectorize"]}
+# per-file additions.  Packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32) issues at half rate on gfx950 (and worse
+# beside MFMAs): the SLP vectorizer must not pair the per-block rescale / the p.V terms.
+HIP_FILE_FLAGS = {"gten_mfma.hip": ["-fno-slp-vectorize"], "gten_attn_tiled.hip": ["-fno-slp-vectorize"]}
 HIP_OBJ = os.path.join(CSRC, "_obj")
 
 

@@ -9,8 +9,9 @@
 // of kept (32 x 2048 f32 would not fit LDS), which costs almost nothing because a Q8 score IS an
 // int8 matrix product: one v_mfma_i32_16x16x32_i8 is exactly one 32-wide quant block of 16 rows x
 // 16 positions, and the two block sums are scaled by delta_q * delta_k in f32 as the scalar code
-// does.  p.V stays on the VALU (packed f32 mul/add): V's per-position deltas sit inside the sum, so
-// it is not an integer matrix product.
+// does.  p.V stays on the VALU (f32 mul + add per term, the bound of this kernel): V's per-position
+// deltas sit inside the sum, so it is not an integer matrix product, and the row kernel's association
+// (which the fused decoder shares) fixes the order of the adds.
 //
 // BIT-IDENTICAL to k_attn (and therefore to the fused decoder for contexts <= 256): every
 // floating-point reduction is laid out so that it reproduces k_attn's association --
@@ -282,8 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const v4f pp = *(const v4f*)(s_p + (4 * rq + rr) * AT_PPITCH + vs * AT_VSUB + c4);
+                    // plain f32 mul + add: v_pk_mul_f32 / v_pk_add_f32 issue at half rate on gfx950 (measured: no gain)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[rr][j] += (v2f){pp[j], pp[j]} * vv[j];
+                    for (int j = 0; j < 4; j++) { acc[rr][j].x = acc[rr][j].x + pp[j] * vv[j].x; acc[rr][j].y = acc[rr][j].y + pp[j] * vv[j].y; }
                 }
             }
             __syncthreads();
