@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--streams", type=int, default=8, choices=[0, 2, 4, 8],
+    ap.add_argument("--streams", type=int, default=8, choices=[0, 2, 4, 8, 16, 32, 48, 64],
                     help="also measure this many sequences sharing each weight pass on the GPU (0 = skip); "
                          "reported separately, `value` stays the single-sequence rate")
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")

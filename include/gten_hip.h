@@ -155,10 +155,12 @@ typedef struct gten_hip_decoder gten_hip_decoder;
 typedef struct { void* kcache; void* vcache; } gten_hip_kv_ptrs;
 
 int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, gten_hip_decoder** out);
-/* Multi-sequence decode: n_seq in {2, 4, 8} independent sequences, each with
+/* Multi-sequence decode: n_seq in {2, 4, 8} (or 16/32/48/64 for quantized weights: W.x on
+ * the matrix cores, rows = sequences) independent sequences, each with
  * its own K/V caches (kv[seq * n_layers + layer]) and token ids, advance by one token per step and
  * SHARE every weight pass (weights are streamed once per step, not once per sequence).  Per sequence
- * the results are bit-identical to the single-sequence decoder.  desc->logits is ignored: read a
+ * the results are bit-identical to the single-sequence decoder for n_seq <= 8 (n_seq >= 16: the linears follow
+ * the matrix-core kernel's block order, i.e. the prefill numerics).  desc->logits is ignored: read a
  * sequence's logits with gten_hip_decoder_logits_seq.  All sequences are at the same position n. */
 int gten_hip_decoder_create_multi(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers,
                                   const gten_hip_kv_ptrs* kv, int n_seq, gten_hip_decoder** out);

@@ -66,7 +66,8 @@ int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph);      
 int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out);  /* waits */
 
 /* ---- several sequences on one GPU sharing one copy of the weights.
- * n_seq in {2, 4, 8}.  Every sequence is a full model object of the gten API with its own K/V
+ * n_seq in {2, 4, 8} (GEMV kernels, bit-identical to single-sequence decode) or {16, 32, 48, 64} (quantized
+ * configurations: every W.x runs as a skinny matrix product on the matrix cores, prefill numerics).  Every sequence is a full model object of the gten API with its own K/V
  * caches; their weight tensors alias sequence 0's storage.  One decode step advances ALL sequences
  * by one token and streams every weight once.  Per sequence the results are bit-identical to
  * gten_host_model_decode_* on a model of its own. */

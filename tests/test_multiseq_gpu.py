@@ -68,3 +68,52 @@ def test_multiseq_graph_replay_equals_eager(hip):
         res.append([[b.decode_result(q, n) for n in (1, 2, 17, 40)] for q in range(4)])
         b.close()
     assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("name,wd,ad", [m for m in MODES() if m[0] != "f16"])
+@pytest.mark.parametrize("n_seq", [16, 32])
+def test_wide_batch_on_matrix_cores_tracks_single_sequence_decode(hip, name, wd, ad, n_seq):
+    """n_seq >= 16: every W.x of the step is a skinny matrix product on the matrix cores (rows = sequences).  The
+    linears follow the MFMA kernel's block order instead of the GEMV wave tree, so per sequence the logits are
+    compared with the single-sequence decoder inside the model band (test_model_gpu.check_logits), the greedy ids
+    must agree wherever the top-2 margin is clear, and graph replay must equal eager launches bit for bit."""
+    from test_model_gpu import check_logits
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    N = 262                                          # crosses the 256-position attention chunk boundary
+    streams = [host.synthetic_tokens(N, seed=300 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
+    runs = []
+    for use_graph in (True, False):
+        batch = host.batch(cfg, n_seq)
+        for i in range(len(cfg.weight_shapes())):
+            batch.set_weight(i, host.synth_weight(cfg, 777, i))
+        for q in range(n_seq):
+            batch.decode_begin(q, streams[q])
+        snap = {}
+        for n in range(1, N + 1):
+            batch.decode_step(n, use_graph)
+            if n in (1, 2, 33, 256, 257, N):
+                snap[n] = [(batch.decode_result(q, n), batch.logits(q).copy()) for q in (0, 1, n_seq // 2, n_seq - 1)]
+        runs.append(snap)
+        batch.close()
+    for n in runs[0]:
+        for (ra, la), (rb, lb) in zip(runs[0][n], runs[1][n]):
+            assert ra == rb and np.array_equal(la, lb), (name, n_seq, n, "graph != eager")
+    # single-sequence decoders for a few of the sequences
+    for k, q in enumerate((0, 1, n_seq // 2, n_seq - 1)):
+        m = host.model(cfg)
+        for i in range(len(cfg.weight_shapes())):
+            m.set_weight(i, host.synth_weight(cfg, 777, i))
+        m.decode_begin(streams[q])
+        for n in range(1, N + 1):
+            m.decode_step(n, True)
+            if n in runs[0]:
+                want = m.logits(streams[q][:n], n - 1)
+                got_id, got = runs[0][n][k]
+                check_logits(name, got, want, float(want.std()))
+                top2 = np.sort(want)[-2:]
+                if top2[1] - top2[0] > 0.05 * float(want.std()):
+                    assert got_id == int(np.argmax(want)), (name, n_seq, q, n)
+        m.close()
+    assert not np.array_equal(runs[0][N][0][1], runs[0][N][1][1])       # independent sequences

@@ -678,6 +678,25 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
     }
 }
 
+// silu(write(gate)) * write(up) for S staged rows (wide multi-sequence decode: the gate and up projections come
+// from the MFMA kernel as raw f32 rows [gate | up]); written as ActQ8 for the down projection.  Same chain as
+// the EPI_SILUMUL epilogues above (gten/modules.cpp:238-247).  One thread per element, 32 lanes = one Q8 block.
+__global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restrict__ gu_raw, int n_ffn,
+                                                          int8_t* __restrict__ out_q, float* __restrict__ out_d, int* __restrict__ out_sum)
+{
+    const int q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;         // n_ffn % 256 == 0
+    const float* row = gu_raw + (size_t)q * 2 * n_ffn;
+    float g = act_round32(row[e], false);                                  // gate projection written in the activation dtype
+    g = act_round32(g / (1.0f + expf(-g)), false);                         // silu in place
+    const float u = act_round32(row[n_ffn + e], false);                    // up projection written
+    const float v = g * u;                                                 // mul in place, then written:
+    const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
+    const int qv = q8_round(v, sc.scale);
+    const int qs = sum32_i(qv);
+    out_q[(size_t)q * n_ffn + e] = (int8_t)qv;
+    if ((e & 31) == 0) { out_d[(size_t)q * (n_ffn >> 5) + (e >> 5)] = sc.ddeq; out_sum[(size_t)q * (n_ffn >> 5) + (e >> 5)] = qs; }
+}
+
 // ------------------------------------------------------------- attention
 
 struct AttnArgs {
@@ -1381,6 +1400,7 @@ struct gten_hip_decoder {
     int* stg_sum = nullptr;
     float* stg_f = nullptr;
     float* logits_m = nullptr;     // [n_seq][n_vocab]
+    float* gu_raw = nullptr;       // [n_seq][2 n_ffn] raw gate | up rows (wide decode, n_seq >= 16)
     unsigned* arrive = nullptr;    // per-head arrival counters of the one-launch attention (+ 1 error word)
     bool fused_attn = false;
     int n_chunks = 0;
@@ -1622,6 +1642,78 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
     return 0;
 }
 
+// ---- n_seq >= 16: every W.x of the step is a skinny matrix product on the matrix cores (gten_mfma.hip, rows =
+// sequences) fed from the same staging launches as above; attention stays one grid plane per sequence.  The
+// linears then follow the MFMA kernel's order (the reference's block order) instead of the GEMV wave tree, so a
+// sequence's logits match the prefill numerics, not bit-for-bit the single-sequence decoder (tests: oracle band).
+template <int WT>
+static int enqueue_step_wide(gten_hip_decoder* dc)
+{
+    const gten_hip_decoder_desc& d = dc->d;
+    const int S = dc->n_seq;
+    const int E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads, V = d.n_vocab;
+    const size_t kv_pitch = gten_hip_row_bytes(d.adtype, KV);
+    float* xbuf = (float*)dc->xbuf;
+    float* hbuf = (float*)dc->hbuf;
+    int rc;
+    Gemv8Args base{};
+    base.step = dc->step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
+    base.best_stride = dc->n_best;
+    auto mm = [&](int tag, const int8_t* aq, const float* ad, float* out, int out_cols, int d_in, const void* w, int d_out,
+                  const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0) -> int {
+        if (g_only_family >= 0 && g_only_family != tag) return 0;
+        return gten_launch_matmul_mfma_a8(aq, ad, w, WT, out, (size_t)out_cols * 4, S, d_in, d_out, w1, d1, w2, d2, tag);
+    };
+    for (int l = 0; l < d.n_layers; l++) {
+        const gten_hip_layer_ptrs& L = dc->layers[l];
+        Gemv8Args st = base;
+        st.d_in = E; st.norm_w = (const uint16_t*)L.attn_norm; st.x_out = xbuf;
+        st.act_q = dc->stg_q; st.act_d = dc->stg_d; st.act_sum = dc->stg_sum; st.act_f = dc->stg_f;
+        if (l == 0) {
+            st.table = d.embed; st.n_vocab = V; st.tokens = dc->tokens;
+            rc = launch_stage<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
+        } else {
+            st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E;
+            rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
+        }
+        if (rc) return rc;
+        const int QW = E + 2 * KV;
+        if ((rc = mm(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->qkv_raw, QW, E, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
+        AttnArgs t{};
+        t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
+        t.att_part = dc->att_part; t.rope = dc->rope;
+        t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
+        t.n_chunks = dc->n_chunks; t.n_embd = E;
+        t.kv_tab = (const void* const*)dc->kv_tab; t.layer = l; t.n_layers = d.n_layers;
+        t.qkv_stride = QW; t.scores_stride = d.n_heads * d.max_ctx; t.stats_stride = d.n_heads * dc->n_chunks * 2;
+        t.part_stride = d.n_heads * dc->n_chunks * dh;
+        const dim3 agrid(d.n_heads, dc->n_chunks, S);
+        const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
+        if ((rc = launch_attention(t, agrid, smem1))) return rc;
+        Gemv8Args sa = base;
+        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.n_chunks = dc->n_chunks;
+        sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
+        if ((rc = launch_stage<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
+        if ((rc = mm(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->proj_raw, E, E, L.wo, E))) return rc;
+        Gemv8Args sh = base;
+        sh.d_in = E; sh.res_a = xbuf; sh.res_raw = dc->proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
+        sh.norm_w = (const uint16_t*)L.ffn_norm;
+        sh.act_q = dc->stg_q; sh.act_d = dc->stg_d; sh.act_sum = dc->stg_sum; sh.act_f = dc->stg_f;
+        if ((rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
+        if ((rc = mm(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->gu_raw, 2 * F, E, L.wgate, F, L.wup, F))) return rc;
+        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, dc->act_q, dc->act_d, dc->act_sum);
+        if ((rc = mm(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, L.wdown, E))) return rc;
+    }
+    Gemv8Args sf = base;
+    sf.d_in = E; sf.res_a = hbuf; sf.res_raw = dc->down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
+    sf.act_q = dc->stg_q; sf.act_d = dc->stg_d; sf.act_sum = dc->stg_sum; sf.act_f = dc->stg_f;
+    if ((rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
+    if ((rc = mm(KT_DEC_GEMV_HEAD, dc->stg_q, dc->stg_d, dc->logits_m, V, E, d.lm_head, V))) return rc;
+    DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)dc->logits_m, (const int*)nullptr,
+               V, dc->step, dc->result, V, d.max_ctx + 2);
+    return 0;
+}
+
 template <int WT>
 static int enqueue_multi(gten_hip_decoder* dc)
 {
@@ -1630,7 +1722,8 @@ static int enqueue_multi(gten_hip_decoder* dc)
     case 4: return enqueue_step_multi<WT, 4>(dc);
     case 8: return enqueue_step_multi<WT, 8>(dc);
     }
-    return fail(-4, "decoder: n_seq %d not in {1, 2, 4, 8}", dc->n_seq);
+    if (dc->n_seq >= 16 && WT != GTEN_F16) return enqueue_step_wide<WT>(dc);
+    return fail(-4, "decoder: n_seq %d not supported for this configuration", dc->n_seq);
 }
 
 static int enqueue(gten_hip_decoder* dc)
@@ -1665,7 +1758,11 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     const bool pair_ok = (d.wdtype == GTEN_F16 && d.adtype == GTEN_F16) || ((d.wdtype == GTEN_Q8 || d.wdtype == GTEN_Q4) && d.adtype == GTEN_Q8);
     GTR_REQUIRE(pair_ok, "decoder_create: unsupported dtype pair (%d,%d) (tinyllama.cpp:258-265)", d.wdtype, d.adtype);
     GTR_REQUIRE(d.embed && d.final_norm && d.lm_head, "decoder_create: null model pointer");
-    GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8, "decoder_create: n_seq %d not in {1, 2, 4, 8}", n_seq);
+    const bool wide = n_seq >= 16;
+    GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8 || (wide && n_seq <= 64 && n_seq % 16 == 0),
+                "decoder_create: n_seq %d not in {1, 2, 4, 8, 16, 32, 48, 64}", n_seq);
+    GTR_REQUIRE(!wide || (d.wdtype != GTEN_F16 && d.n_ffn % 256 == 0 && d.n_embd % 128 == 0 && (dh * d.n_kv_heads) % 64 == 0),
+                "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: quantized weights, n_embd %% 128 == 0, n_ffn %% 256 == 0");
     GTR_REQUIRE(n_seq == 1 || (kv && dh == 64), "decoder_create: multi-sequence decode needs the cache table and d_head 64");
     GTR_REQUIRE(n_seq > 1 || d.logits, "decoder_create: null logits pointer");
     auto* dc = new gten_hip_decoder;
@@ -1708,6 +1805,10 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
         GTR_CHECK(hipMalloc((void**)&dc->stg_sum, S * (size_t)(E / 32) * 4));
         GTR_CHECK(hipMalloc((void**)&dc->stg_f, S * (size_t)E * 4));
         GTR_CHECK(hipMalloc((void**)&dc->logits_m, S * (size_t)d.n_vocab * 4));
+        if (wide) {
+            GTR_CHECK(hipMalloc((void**)&dc->gu_raw, S * (size_t)2 * F * 4));
+            if (int rc = gten_mfma_prepare_a8(d.wdtype)) { delete dc; return rc; }
+        }
         std::vector<const void*> tab(S * d.n_layers * 2);
         for (size_t q = 0; q < S; q++)
             for (int l = 0; l < d.n_layers; l++) {
@@ -1756,7 +1857,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
-                    dc->logits_m, (void*)dc->kv_tab, dc->arrive};
+                    dc->logits_m, (void*)dc->kv_tab, dc->arrive, dc->gu_raw};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;
