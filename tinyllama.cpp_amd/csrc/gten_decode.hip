@@ -68,7 +68,7 @@ __device__ __forceinline__ ActStage carve_stage(int d)
 static size_t stage_bytes(int d) { return 64 + (size_t)d * 4 + (size_t)(d >> 5) * 40; }
 
 enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_ACTQ8 = 4 };
-enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2 };
+enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2, EPI_STAGE_FRAG = 3 };
 
 // ------------------------------------------------------------ W.x kernels
 //
@@ -107,6 +107,7 @@ struct Gemv8Args {
     int8_t* out_q; float* out_d; int* out_sum; float* out_f;
     // the qkv launch clears the attention arrival counters of the launch that follows it
     unsigned* zero_words; int zero_count;
+    int frag_rt;                  // EPI_STAGE_FRAG: row tiles (of 16 sequences) of the fragment-major staging (k_dec_mmv)
 };
 
 // ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
@@ -177,6 +178,37 @@ template <int EPT> __device__ __forceinline__ void q8_stageN(const float (&v)[EP
     if (sub == 0) { a.d[b] = s.ddeq; a.sum[b] = sum; }
 }
 
+// The same block, staged for the matrix-core W.x of many sequences (k_dec_mmv): quants in MFMA-fragment order
+// [block][row tile][lane = 16 * (k % 32 / 8) + row % 16][8 bytes] -- one 512-byte coalesced load per (row tile,
+// block) and wave -- and the block deltas / sums as [block][row] so that a lane's four rows are one 16-byte load.
+struct ActFrag {
+    int8_t* q; float* d; int* sum;
+    int rt, row;
+};
+template <int EPT> __device__ __forceinline__ void q8_stage_frag(const float (&v)[EPT], int b, int sub, ActFrag a)
+{
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) amax = fmaxf(amax, fabsf(v[i]));
+    const Q8Scale s = q8_scale_from_absmax(grp_max<EPT>(amax));
+    int q[EPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { q[i] = q8_round(v[i], s.scale); sum += q[i]; }
+    const int k = sub * EPT;                                   // first element of this thread inside the block
+    int8_t* dst = a.q + ((((size_t)b * a.rt + (a.row >> 4)) * 64 + (k >> 3) * 16 + (a.row & 15)) * 8 + (k & 7));
+    const int lo = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
+    if (EPT == 8) {
+        int2 pk;
+        pk.x = lo;
+        pk.y = (q[EPT - 4] & 0xff) | ((q[EPT - 3] & 0xff) << 8) | ((q[EPT - 2] & 0xff) << 16) | ((q[EPT - 1] & 0xff) << 24);
+        *(int2*)dst = pk;
+    } else {
+        *(int*)dst = lo;
+    }
+    sum = grp_sum_i<EPT>(sum);
+    if (sub == 0) { a.d[(size_t)b * 16 * a.rt + a.row] = s.ddeq; a.sum[(size_t)b * 16 * a.rt + a.row] = sum; }
+}
+
 template <int EPT> __device__ __forceinline__ void ldN(const float* p, float (&v)[EPT])
 {
     const float4 a = ((const float4*)p)[0];
@@ -245,20 +277,21 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // EPI_STAGE: one workgroup per SEQUENCE runs only the prologue and leaves the staged vector in
     // HBM for the multi-sequence W.x kernel (k_dec_gemvm), which then needs no prologue of its own
-    const int seq = (EPI == EPI_STAGE) ? blockIdx.x : 0;
+    constexpr bool STG = (EPI == EPI_STAGE || EPI == EPI_STAGE_FRAG);
+    const int seq = STG ? blockIdx.x : 0;
     const int n = a.step[seq].n;
     const float* res_raw = a.res_raw + (size_t)seq * a.raw_stride;
     const float* res_a = a.res_a + (size_t)seq * d;
     float* x_out = a.x_out ? a.x_out + (size_t)seq * d : nullptr;
     const int32_t* tokens = a.tokens + (size_t)seq * a.tok_stride;
     const float* att_part = a.att_part + (size_t)seq * a.part_stride;
-    if (EPI == EPI_STAGE) {
+    if (STG) {
         s.q8.q = a.act_q + (size_t)seq * d;
         s.q8.d = a.act_d + (size_t)seq * nb;
         s.q8.sum = a.act_sum + (size_t)seq * nb;
         if (F16W) s.row = a.act_f + (size_t)seq * d;
     }
-    const bool stores_x = (EPI == EPI_STAGE) || blockIdx.x == 0;
+    const bool stores_x = STG || blockIdx.x == 0;
     if (a.zero_words && blockIdx.x == 0 && (int)threadIdx.x < a.zero_count) a.zero_words[threadIdx.x] = 0u;
     const int gi = threadIdx.x, base = gi * EPT, blk = gi / LPB, sub = gi % LPB;
     const bool on = base < d;                     // lanes past the row re-read group 0 (never used):
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     uint16_t wd[R][NCH];
 #pragma unroll
     for (int j = 0; j < R; j++) {
-        if (EPI == EPI_STAGE) break;              // no W.x in a staging launch
+        if (STG) break;                           // no W.x in a staging launch
         int lr = r0 + j;
         const bool ok = lr < total;
         const uint8_t* qbase = a.qs[0];
@@ -401,7 +434,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
             act_roundN<WT, EPT>(v);
             if (on) stN<EPT>(s.row + base, v);            // staged as f32 (exact f16 values)
         } else if (on) {
-            q8_stageN<EPT>(v, blk, sub, s.q8);
+            if (EPI == EPI_STAGE_FRAG) q8_stage_frag<EPT>(v, blk, sub, ActFrag{a.act_q, a.act_d, a.act_sum, a.frag_rt, seq});
+            else q8_stageN<EPT>(v, blk, sub, s.q8);
         }
         __syncthreads();
     } else if (F16W) {
@@ -410,7 +444,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         __syncthreads();
     }
 
-    if (EPI == EPI_STAGE) return;
+    if (STG) return;
 
     // ---- 4. this lane's activation blocks, then the dot products
     int av[NCH][8], asum[NCH];
@@ -678,10 +712,170 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
     }
 }
 
+// ------------------------------------------- W.x kernel, many sequences (matrix cores)
+//
+// k_dec_mmv<WT, RT>: the W.x of a decode step for up to 16 RT sequences, GEMV-shaped.  A workgroup owns 16
+// output features for ALL rows; its eight waves split K eight ways.
+//   * the workgroup's whole weight slab (16 features x K: 16-90 KB) is requested at kernel entry as coalesced
+//     16-byte pieces -- ONE memory round trip for all of it, like the single-sequence GEMV kernels -- and parked in
+//     LDS (pieces XOR-swizzled by row so that the 16 rows of a fragment read do not share banks);
+//   * the activations arrive from the staging launches in MFMA-fragment order (q8_stage_frag): one 512-byte
+//     coalesced load per (row tile, quant block) and wave, deltas / block sums as [block][row];
+//   * one v_mfma_i32_16x16x32_i8 per (row tile, quant block) = the exact integer dot of 16 rows x 16 features
+//     over one 32-wide block (Q4 nibbles are turned into int8 (n - 7) byte-parallel, 5 instructions per dword,
+//     shared by the row tiles).  Block sums are scaled (isum * da) * dw and accumulated
+//     in block order inside a wave; the eight K slices are added in wave order (deterministic).
+// The k_matmul_mfma tiles of gten_mfma.hip run this problem at ~1 us per 128 K of serial chain on 40-350
+// workgroups (17 / 41 us for K = 2048 / 5632 at 32 sequences); this shape has d_out / 16 workgroups and a chain of K / 8.
+struct MmvArgs {
+    const int8_t* aq; const float* ad;                        // fragment-major staging (ActFrag): quants, [block][row] deltas
+    const void* w[3]; int d_out[3]; int n_mats;               // concatenated outputs (q|k|v, gate|up): multiples of 16 except the last
+    float* out; int out_cols;                                 // raw f32 rows, pitch in floats
+    int S, d_in;
+};
+
+typedef int mmv_v4i __attribute__((ext_vector_type(4)));
+#define MMV_MAXP 11            // 16-byte weight pieces per thread: 16 features x 5632 B (Q8, K = 5632) / 512 threads / 16
+#define MMV_MAXD 6             // 16-byte pieces of the activation-delta table per thread: 176 blocks x 64 rows x 4 B / 512 / 16
+
+template <int WT, int RT, int CB>
+__global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
+{
+    constexpr int SP = 16 * RT;                               // padded row count
+    const int nb = a.d_in >> 5, nbw = nb >> 3;                // blocks per wave (nb % 8 == 0)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const int rowb = nb * (WT == GTEN_Q4 ? 16 : 32);          // weight bytes per feature
+    uint8_t* wl = g_smem;                                     // [16][rowb], 16-byte pieces swizzled: slot = piece ^ (row & 7)
+    float* red = (float*)g_smem;                              // [8][SP][16] -- over the slab, once the K loop is done
+    uint16_t* dwl = (uint16_t*)(wl + max((size_t)16 * rowb, (size_t)8 * SP * 64));   // [16][nb] weight deltas
+    float* daT = (float*)(dwl + (size_t)16 * nb);             // [nb][SP] activation deltas
+
+    // which matrix (uniform)
+    int colw = blockIdx.x * 16, colbase = 0, m = 0;
+    if (a.n_mats > 1 && colw >= a.d_out[0]) {
+        colw -= a.d_out[0]; colbase = a.d_out[0]; m = 1;
+        if (a.n_mats > 2 && colw >= a.d_out[1]) { colw -= a.d_out[1]; colbase += a.d_out[1]; m = 2; }
+    }
+    const void* w = (m == 0) ? a.w[0] : (m == 1) ? a.w[1] : a.w[2];
+    const int d_out = (m == 0) ? a.d_out[0] : (m == 1) ? a.d_out[1] : a.d_out[2];
+    const PackedW pw = packed_view(w, WT, d_out, a.d_in);
+
+    // ---- 1. everything this workgroup will read, requested at once (one memory round trip):
+    //         the weight slab (32 threads per feature row, pieces c0 + 32 k), its deltas, the delta table of the
+    //         activations, and this wave's first chunk of activation fragments
+    const int ppr = rowb >> 4;                                // pieces per feature row (<= 32 * MMV_MAXP)
+    const int sr = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+    const uint8_t* srow = pw.qs + (size_t)min(colw + sr, d_out - 1) * rowb;
+    uint4 wp[MMV_MAXP];
+#pragma unroll
+    for (int k = 0; k < MMV_MAXP; k++)
+        if (32 * k < ppr) wp[k] = *(const uint4*)(srow + (size_t)min(c0 + 32 * k, ppr - 1) * 16);
+    const unsigned* drow = (const unsigned*)(pw.ds + (size_t)min(colw + sr, d_out - 1) * nb);
+    unsigned dwv[3];                                          // nb / 2 <= 88 dwords per row
+#pragma unroll
+    for (int k = 0; k < 3; k++) dwv[k] = drow[min(c0 + 32 * k, (nb >> 1) - 1)];
+    const int ndp = nb * SP / 4;                              // 16-byte pieces of the [nb][SP] delta table (same layout in LDS)
+    uint4 dap[MMV_MAXD];
+#pragma unroll
+    for (int k = 0; k < MMV_MAXD; k++)
+        if (512 * k < ndp) dap[k] = ((const uint4*)a.ad)[min((int)threadIdx.x + 512 * k, ndp - 1)];
+    const int b0 = wid * nbw;
+    const int8_t* afr = a.aq + (size_t)lane * 8;              // fragment order: 512 contiguous bytes per (block, row tile)
+    uint2 araw[RT][CB];
+    auto request = [&](int bb) {
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+#pragma unroll
+            for (int t = 0; t < RT; t++) araw[t][c] = *(const uint2*)(afr + ((size_t)min(bb + c, nb - 1) * RT + t) * 512);
+    };
+    request(b0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. park slab and tables in LDS
+#pragma unroll
+    for (int k = 0; k < MMV_MAXP; k++) {
+        const int c = c0 + 32 * k;
+        if (c < ppr) *(uint4*)(wl + (size_t)sr * rowb + (size_t)(c ^ (sr & 7)) * 16) = wp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c = c0 + 32 * k;
+        if (c < (nb >> 1)) ((unsigned*)dwl)[sr * (nb >> 1) + c] = dwv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < MMV_MAXD; k++) {
+        const int p = (int)threadIdx.x + 512 * k;
+        if (p < ndp) ((uint4*)daT)[p] = dap[k];
+    }
+    __syncthreads();
+
+    // ---- 3. this wave's K slice
+    const mmv_v4i zero4 = {0, 0, 0, 0};
+    const int nshift = (g < 2) ? 4 : 0;
+    float acc[RT][4];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[t][i] = 0.f;
+    const uint8_t* wrow = wl + (size_t)l16 * rowb + (g & 1) * 8;
+    for (int bb = b0; bb < b0 + nbw; bb += CB) {
+        uint2 aqv[RT][CB];
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+#pragma unroll
+            for (int t = 0; t < RT; t++) aqv[t][c] = araw[t][c];
+        if (bb + CB < b0 + nbw) request(bb + CB);               // next chunk in flight during this one's math
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const int b = min(bb + c, nb - 1);
+            // blocks past this wave's slice (ragged last chunk) are scaled by zero: no branch inside the chunk
+            const float dwf = (bb + c < b0 + nbw) ? h2f(dwl[l16 * nb + b]) : 0.f;
+            long bl;
+            if (WT == GTEN_Q4) {
+                // nibble - 7 as int8, byte-parallel: (n | 0x80) - 7 never borrows across bytes, ^ 0x80 restores the sign
+                const uint2 by = *(const uint2*)(wrow + (size_t)(b ^ (l16 & 7)) * 16);
+                const unsigned x = ((((by.x >> nshift) & 0x0f0f0f0fu) | 0x80808080u) - 0x07070707u) ^ 0x80808080u;
+                const unsigned y = ((((by.y >> nshift) & 0x0f0f0f0fu) | 0x80808080u) - 0x07070707u) ^ 0x80808080u;
+                bl = (long)(((unsigned long)y << 32) | x);
+            } else {
+                // Q8 rows are two planes of nb 16-byte pieces: elements 0-15, then 16-31
+                const int piece = (g >> 1) * nb + b;
+                const uint2 by = *(const uint2*)(wrow + (size_t)(piece ^ (l16 & 7)) * 16);
+                bl = (long)(((unsigned long)by.y << 32) | by.x);
+            }
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                const long al = (long)(((unsigned long)aqv[t][c].y << 32) | aqv[t][c].x);
+                const mmv_v4i isum = __builtin_amdgcn_mfma_i32_16x16x32_i8(al, bl, zero4, 0, 0, 0);
+                const float4 da4 = *(const float4*)(daT + (size_t)b * SP + 16 * t + 4 * g);
+                const float da[4] = {da4.x, da4.y, da4.z, da4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[t][i] = acc[t][i] + ((float)isum[i] * da[i]) * dwf;
+            }
+        }
+    }
+
+    // ---- 4. the eight K slices, added in wave order (the slab is dead: `red` lies over it)
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[(wid * SP + 16 * t + 4 * g + i) * 16 + l16] = acc[t][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < SP * 16; idx += 512) {
+        const int r = idx >> 4, c = idx & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
+        if (r < a.S && colw + c < d_out) a.out[(size_t)r * a.out_cols + colbase + colw + c] = v;
+    }
+}
+
 // silu(write(gate)) * write(up) for S staged rows (wide multi-sequence decode: the gate and up projections come
-// from the MFMA kernel as raw f32 rows [gate | up]); written as ActQ8 for the down projection.  Same chain as
-// the EPI_SILUMUL epilogues above (gten/modules.cpp:238-247).  One thread per element, 32 lanes = one Q8 block.
-__global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restrict__ gu_raw, int n_ffn,
+// from k_dec_mmv as raw f32 rows [gate | up]); written in the fragment-major staging for the down projection.
+// Same chain as the EPI_SILUMUL epilogues above (gten/modules.cpp:238-247).  One thread per element, 32 lanes =
+// one Q8 block.
+__global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restrict__ gu_raw, int n_ffn, int rt,
                                                           int8_t* __restrict__ out_q, float* __restrict__ out_d, int* __restrict__ out_sum)
 {
     const int q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;         // n_ffn % 256 == 0
@@ -693,8 +887,9 @@ __global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restric
     const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
     const int qv = q8_round(v, sc.scale);
     const int qs = sum32_i(qv);
-    out_q[(size_t)q * n_ffn + e] = (int8_t)qv;
-    if ((e & 31) == 0) { out_d[(size_t)q * (n_ffn >> 5) + (e >> 5)] = sc.ddeq; out_sum[(size_t)q * (n_ffn >> 5) + (e >> 5)] = qs; }
+    const int b = e >> 5, k = e & 31;
+    out_q[(((size_t)b * rt + (q >> 4)) * 64 + (k >> 3) * 16 + (q & 15)) * 8 + (k & 7)] = (int8_t)qv;
+    if (k == 0) { out_d[(size_t)b * 16 * rt + q] = sc.ddeq; out_sum[(size_t)b * 16 * rt + q] = qs; }
 }
 
 // ------------------------------------------------------------- attention
@@ -1536,6 +1731,14 @@ static int launch_stage(int tag, Gemv8Args a, int n_seq)
     return 0;
 }
 
+template <int WT, int PRO>
+static int launch_stage_frag(int tag, Gemv8Args a, int n_seq)
+{
+    a.frag_rt = (n_seq + 15) / 16;
+    DEC_LAUNCH(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE_FRAG, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), a);
+    return 0;
+}
+
 static size_t gemvm_lds_bytes(int wt, int n_seq, int d, bool silumul)
 {
     size_t b = silumul ? (size_t)n_seq * 64 * 4 : 0;
@@ -1642,10 +1845,59 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
     return 0;
 }
 
-// ---- n_seq >= 16: every W.x of the step is a skinny matrix product on the matrix cores (gten_mfma.hip, rows =
-// sequences) fed from the same staging launches as above; attention stays one grid plane per sequence.  The
-// linears then follow the MFMA kernel's order (the reference's block order) instead of the GEMV wave tree, so a
-// sequence's logits match the prefill numerics, not bit-for-bit the single-sequence decoder (tests: oracle band).
+static size_t mmv_lds_bytes(int wt, int rt, int d_in)
+{
+    const size_t nb = (size_t)d_in / 32, sp = 16 * (size_t)rt;
+    return std::max(16 * nb * (wt == GTEN_Q4 ? 16 : 32), 8 * sp * 64) + 16 * nb * 2 + nb * sp * 4;
+}
+
+template <int WT, int RT>
+static int launch_mmv_rt(int tag, const MmvArgs& a)
+{
+    const size_t smem = mmv_lds_bytes(WT, RT, a.d_in);
+    GTR_REQUIRE(smem <= 150 * 1024, "decoder: the slab and delta table of d_in %d x %d rows do not fit LDS", a.d_in, a.S);
+    const int cols = a.d_out[0] + (a.n_mats > 1 ? a.d_out[1] : 0) + (a.n_mats > 2 ? a.d_out[2] : 0);
+    const int nbw = a.d_in / 256;                               // quant blocks per wave
+    // activation chunks: all of a wave's blocks at once when that is 8 or fewer, else elevens (5632 / 256 = 22);
+    // more than 32 rows: fours (registers)
+    if (RT > 2)
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4>), dim3((cols + 15) / 16), dim3(512), smem, a);
+    else if (nbw > 8 && nbw % 11 == 0)
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 11>), dim3((cols + 15) / 16), dim3(512), smem, a);
+    else
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 8>), dim3((cols + 15) / 16), dim3(512), smem, a);
+    return 0;
+}
+
+// (before the first launch, outside any stream capture: the slab may need more than 64 KB of LDS)
+template <int WT>
+static int mmv_prepare()
+{
+#define MMV_ATTR(RT_, CB_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmv<WT, RT_, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+    MMV_ATTR(1, 8); MMV_ATTR(2, 8); MMV_ATTR(1, 11); MMV_ATTR(2, 11); MMV_ATTR(3, 4); MMV_ATTR(4, 4);
+#undef MMV_ATTR
+    return 0;
+}
+
+template <int WT>
+static int launch_mmv(int tag, const MmvArgs& a)
+{
+    GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && a.S <= 64, "decoder: skinny W.x wants d_in %% 256 == 0 and <= 64 rows");
+    GTR_REQUIRE((size_t)16 * (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) <= (size_t)MMV_MAXP * 512 * 16 && (size_t)(a.d_in / 32) * 64 * 4 <= (size_t)MMV_MAXD * 512 * 16,
+                "decoder: d_in %d too long for the weight slab / delta table", a.d_in);
+    for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
+    switch ((a.S + 15) / 16) {
+    case 1: return launch_mmv_rt<WT, 1>(tag, a);
+    case 2: return launch_mmv_rt<WT, 2>(tag, a);
+    case 3: return launch_mmv_rt<WT, 3>(tag, a);
+    default: return launch_mmv_rt<WT, 4>(tag, a);
+    }
+}
+
+// ---- n_seq >= 16: every W.x of the step runs on the matrix cores (k_dec_mmv, rows = sequences) fed from the
+// staging launches in fragment order; attention stays one grid plane per sequence.  The linears then add their
+// block sums in k_dec_mmv's order (eight K slices) instead of the GEMV wave tree, so a sequence's logits are not
+// bit-for-bit those of the single-sequence decoder (tests: model band, graph == eager, run-to-run identical).
 template <int WT>
 static int enqueue_step_wide(gten_hip_decoder* dc)
 {
@@ -1659,10 +1911,12 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
     Gemv8Args base{};
     base.step = dc->step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
     base.best_stride = dc->n_best;
-    auto mm = [&](int tag, const int8_t* aq, const float* ad, float* out, int out_cols, int d_in, const void* w, int d_out,
+    auto mm = [&](int tag, const int8_t* aq, const float* ad, const int*, float* out, int out_cols, int d_in, const void* w, int d_out,
                   const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0) -> int {
-        if (g_only_family >= 0 && g_only_family != tag) return 0;
-        return gten_launch_matmul_mfma_a8(aq, ad, w, WT, out, (size_t)out_cols * 4, S, d_in, d_out, w1, d1, w2, d2, tag);
+        MmvArgs a{};
+        a.aq = aq; a.ad = ad; a.w[0] = w; a.w[1] = w1; a.w[2] = w2; a.d_out[0] = d_out; a.d_out[1] = d1; a.d_out[2] = d2;
+        a.n_mats = w2 ? 3 : (w1 ? 2 : 1); a.out = out; a.out_cols = out_cols; a.S = S; a.d_in = d_in;
+        return launch_mmv<WT>(tag, a);
     };
     for (int l = 0; l < d.n_layers; l++) {
         const gten_hip_layer_ptrs& L = dc->layers[l];
@@ -1671,14 +1925,14 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         st.act_q = dc->stg_q; st.act_d = dc->stg_d; st.act_sum = dc->stg_sum; st.act_f = dc->stg_f;
         if (l == 0) {
             st.table = d.embed; st.n_vocab = V; st.tokens = dc->tokens;
-            rc = launch_stage<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
+            rc = launch_stage_frag<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
         } else {
             st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E;
-            rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
+            rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
         }
         if (rc) return rc;
         const int QW = E + 2 * KV;
-        if ((rc = mm(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->qkv_raw, QW, E, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
+        if ((rc = mm(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->stg_sum, dc->qkv_raw, QW, E, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
         AttnArgs t{};
         t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
         t.att_part = dc->att_part; t.rope = dc->rope;
@@ -1693,22 +1947,22 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         Gemv8Args sa = base;
         sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.n_chunks = dc->n_chunks;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
-        if ((rc = launch_stage<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
-        if ((rc = mm(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->proj_raw, E, E, L.wo, E))) return rc;
+        if ((rc = launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
+        if ((rc = mm(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->stg_sum, dc->proj_raw, E, E, L.wo, E))) return rc;
         Gemv8Args sh = base;
         sh.d_in = E; sh.res_a = xbuf; sh.res_raw = dc->proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
         sh.norm_w = (const uint16_t*)L.ffn_norm;
         sh.act_q = dc->stg_q; sh.act_d = dc->stg_d; sh.act_sum = dc->stg_sum; sh.act_f = dc->stg_f;
-        if ((rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
-        if ((rc = mm(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->gu_raw, 2 * F, E, L.wgate, F, L.wup, F))) return rc;
-        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, dc->act_q, dc->act_d, dc->act_sum);
-        if ((rc = mm(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, L.wdown, E))) return rc;
+        if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
+        if ((rc = mm(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->stg_sum, dc->gu_raw, 2 * F, E, L.wgate, F, L.wup, F))) return rc;
+        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16, dc->act_q, dc->act_d, dc->act_sum);
+        if ((rc = mm(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->act_sum, dc->down_raw, E, F, L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
     sf.d_in = E; sf.res_a = hbuf; sf.res_raw = dc->down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
     sf.act_q = dc->stg_q; sf.act_d = dc->stg_d; sf.act_sum = dc->stg_sum; sf.act_f = dc->stg_f;
-    if ((rc = launch_stage<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
-    if ((rc = mm(KT_DEC_GEMV_HEAD, dc->stg_q, dc->stg_d, dc->logits_m, V, E, d.lm_head, V))) return rc;
+    if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
+    if ((rc = mm(KT_DEC_GEMV_HEAD, dc->stg_q, dc->stg_d, dc->stg_sum, dc->logits_m, V, E, d.lm_head, V))) return rc;
     DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)dc->logits_m, (const int*)nullptr,
                V, dc->step, dc->result, V, d.max_ctx + 2);
     return 0;
@@ -1761,8 +2015,8 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     const bool wide = n_seq >= 16;
     GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8 || (wide && n_seq <= 64 && n_seq % 16 == 0),
                 "decoder_create: n_seq %d not in {1, 2, 4, 8, 16, 32, 48, 64}", n_seq);
-    GTR_REQUIRE(!wide || (d.wdtype != GTEN_F16 && d.n_ffn % 256 == 0 && d.n_embd % 128 == 0 && (dh * d.n_kv_heads) % 64 == 0),
-                "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: quantized weights, n_embd %% 128 == 0, n_ffn %% 256 == 0");
+    GTR_REQUIRE(!wide || (d.wdtype != GTEN_F16 && d.n_ffn % 256 == 0 && d.n_embd % 256 == 0 && (dh * d.n_kv_heads) % 16 == 0),
+                "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: quantized weights, n_embd and n_ffn %% 256 == 0");
     GTR_REQUIRE(n_seq == 1 || (kv && dh == 64), "decoder_create: multi-sequence decode needs the cache table and d_head 64");
     GTR_REQUIRE(n_seq > 1 || d.logits, "decoder_create: null logits pointer");
     auto* dc = new gten_hip_decoder;
@@ -1807,7 +2061,7 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
         GTR_CHECK(hipMalloc((void**)&dc->logits_m, S * (size_t)d.n_vocab * 4));
         if (wide) {
             GTR_CHECK(hipMalloc((void**)&dc->gu_raw, S * (size_t)2 * F * 4));
-            if (int rc = gten_mfma_prepare_a8(d.wdtype)) { delete dc; return rc; }
+            if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) { delete dc; return rc; }
         }
         std::vector<const void*> tab(S * d.n_layers * 2);
         for (size_t q = 0; q < S; q++)

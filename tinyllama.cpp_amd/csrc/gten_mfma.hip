@@ -93,10 +93,8 @@ __device__ __forceinline__ float row16_absmax(float v)
     return fmaxf(v, dpp_mov<0x140>(v));
 }
 
-template <int WT, int WM, int WN, int KB_ = 4, bool A8_ = false, int PD_ = 2>
+template <int WT, int WM, int WN, int KB_ = 4>
 struct MfmaCfg {
-    static constexpr int PD = PD_;                         // stages of operands requested ahead (in registers); even
-    static constexpr bool A8 = A8_;                        // activations arrive as int8 rows (decode staging), expanded while staged
     static constexpr bool QUANT = (WT != GTEN_F16);
     static constexpr int BM = 32 * WM, BN = 32 * WN;       // workgroup tile: 2 x 2 waves
     static constexpr int KB = KB_;                         // quant blocks per stage (4 = 128 K; 2 halves the LDS stage: one more workgroup per CU)
@@ -108,7 +106,7 @@ struct MfmaCfg {
     static constexpr int A_BYTES = BM * APITCH, DA_BYTES = QUANT ? DA_PIECES * 256 * 4 : 0;
     static constexpr int W_BYTES = QUANT ? BN * WPITCH : 0, DW_BYTES = QUANT ? KB * 256 * 4 : 0;
     static constexpr int STAGE = A_BYTES + DA_BYTES + W_BYTES + DW_BYTES;
-    static constexpr int A_PIECES = BM * KB * (A8_ ? 2 : 4) / 256;     // 16-byte pieces of the activation tile per thread
+    static constexpr int A_PIECES = BM * KB * 4 / 256;     // 16-byte pieces of the activation tile per thread
     static constexpr int W_PIECES = QUANT ? (BN * WROW / 16 + 255) / 256 : 0;
     static constexpr size_t smem() { return (size_t)2 * STAGE; }
 };
@@ -136,24 +134,15 @@ __global__ __launch_bounds__(256) void k_act_to_f16(const uint8_t* __restrict__ 
     da[idx] = h2f(blk[0]);
 }
 
-// Up to three weight matrices with the same input (q|k|v, gate|up) in one launch: outputs are the columns
-// [0, d_out) of `w`, then d1 columns of w1, then d2 of w2 (d_out and d1 multiples of the workgroup's BN).
-struct MfmaExtra {
-    const void* w1; const void* w2;
-    int d1, d2;
-};
-
 // (2 waves per SIMD = a 256-VGPR budget: the block sums then come back in VGPRs instead of AGPRs, which
 //  would cost four v_accvgpr_read per MFMA in a loop that is bound by VALU issue)
 // a16: f16 activation rows of the NEW rows (row 0 = start_pos), pitch d_in * 2 (quantized) or x itself (f16 weights)
-template <int WT, int WM, int WN, int KB_, bool A8_ = false, int PD_ = 2>
+template <int WT, int WM, int WN, int KB_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_matmul_mfma(
-    const uint8_t* __restrict__ a16, size_t a_pitch, const float* __restrict__ da_rows, const void* __restrict__ w0,
-    uint8_t* __restrict__ out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out0, int start_pos, const MfmaExtra ex)
+    const uint8_t* __restrict__ a16, size_t a_pitch, const float* __restrict__ da_rows, const void* __restrict__ w,
+    uint8_t* __restrict__ out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
 {
-    using C = MfmaCfg<WT, WM, WN, KB_, A8_, PD_>;
-    static_assert(PD_ >= 2 && PD_ % 2 == 0, "prefetch depth: even, >= 2");
-    static_assert(C::A_PIECES >= 1, "tile too small for the staging roles");
+    using C = MfmaCfg<WT, WM, WN, KB_>;
     constexpr int BM = C::BM, BN = C::BN, KB = C::KB, APITCH = C::APITCH, WPITCH = C::WPITCH, WROW = C::WROW;
     constexpr bool QUANT = C::QUANT;
 
@@ -161,13 +150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int g = lane >> 4, l16 = lane & 15;
     const int rows = n - start_pos;
     const int row0 = blockIdx.y * BM;                        // relative to start_pos
-    // which matrix this workgroup's columns belong to (uniform)
-    const void* w = w0;
-    int d_out = d_out0, colw = blockIdx.x * BN, colbase = 0;  // colw: first feature of the workgroup within its matrix
-    if (ex.w1 && colw >= d_out0) {
-        colw -= d_out0; colbase = d_out0; w = ex.w1; d_out = ex.d1;
-        if (ex.w2 && colw >= ex.d1) { colw -= ex.d1; colbase += ex.d1; w = ex.w2; d_out = ex.d2; }
-    }
+    const int colw = blockIdx.x * BN;                        // first feature of the workgroup
     const int col0 = colw + wc * 16 * WN;                    // first feature of this wave
     const int nb = d_in >> 5;
     const int nstage = nb / KB;
@@ -190,10 +173,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     unsigned a_src[C::A_PIECES], a_dst[C::A_PIECES];
 #pragma unroll
     for (int k = 0; k < C::A_PIECES; k++) {
-        constexpr int PR = KB * (A8_ ? 2 : 4);               // pieces per row and stage
-        const int p = threadIdx.x + 256 * k, r = p / PR, c = p % PR;
+        const int p = threadIdx.x + 256 * k, r = p / (KB * 4), c = p % (KB * 4);
         a_src[k] = (unsigned)min(row0 + r, rows - 1) * (unsigned)a_pitch + c * 16;
-        a_dst[k] = r * APITCH + c * (A8_ ? 32 : 16);
+        a_dst[k] = r * APITCH + c * 16;
     }
     // activation deltas: one float per (row, block): BM * KB of them, DA_PIECES per thread (slots past them are padding)
     constexpr int DA_PIECES = C::DA_PIECES;
@@ -222,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     struct Raw { v4i_t a[C::A_PIECES]; v4i_t w[WP]; float da[DA_PIECES]; v2i_t dw; };
     auto load_stage = [&](int s, Raw& r) {
 #pragma unroll
-        for (int k = 0; k < C::A_PIECES; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_src[k], s * (KB * (A8_ ? 32 : 64)), 0);
+        for (int k = 0; k < C::A_PIECES; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_src[k], s * (KB * 64), 0);
         if (QUANT) {
 #pragma unroll
             for (int k = 0; k < C::W_PIECES; k++) r.w[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_src[k], s * (KB * 16), 0);
@@ -235,18 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     auto store_stage = [&](const Raw& r, int buf) {
         uint8_t* sa = g_smem + buf * C::STAGE;
 #pragma unroll
-        for (int k = 0; k < C::A_PIECES; k++) {
-            if (A8_) {
-                // 16 quants -> 16 f16 in the fragment order
-                unsigned f[8];
-#pragma unroll
-                for (int i = 0; i < 4; i++) int8x4_to_f16((unsigned)r.a[k][i], f[2 * i], f[2 * i + 1]);
-                *(v4i_t*)(sa + a_dst[k]) = (v4i_t){(int)f[0], (int)f[1], (int)f[2], (int)f[3]};
-                *(v4i_t*)(sa + a_dst[k] + 16) = (v4i_t){(int)f[4], (int)f[5], (int)f[6], (int)f[7]};
-            } else {
-                *(v4i_t*)(sa + a_dst[k]) = r.a[k];
-            }
-        }
+        for (int k = 0; k < C::A_PIECES; k++) *(v4i_t*)(sa + a_dst[k]) = r.a[k];
         if (QUANT) {
             float* sda = (float*)(sa + C::A_BYTES);
             uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
@@ -278,16 +249,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for (int j = 0; j < WN; j++) wrow16[j] = (size_t)min(col0 + 16 * j + l16, d_out - 1) * d_in + g * 8;
 
-    // Stage s is computed from LDS buffer s & 1 while stages s + 1 .. s + PD - 1 wait in registers (s + 1 is stored
-    // behind the compute) and stage s + PD is requested.  PD = 2 for the big prefill tiles (registers); the skinny
-    // decode launches have few workgroups and nothing else to hide HBM latency behind, so they keep PD = 8 stages
-    // (a 64-feature tile's whole K = 1024 slab and more) in flight.
-    Raw raw[PD_];
-    load_stage(0, raw[0]);
-    store_stage(raw[0], 0);
-#pragma unroll
-    for (int u = 1; u < PD_; u++) load_stage(u, raw[u]);
-    load_stage(PD_, raw[0]);                  // slot 0 is free again
+    // Stage s is computed from LDS buffer s & 1 while stage s + 1 waits in registers (stored behind the compute)
+    // and stage s + 2 is requested: two stages of memory latency are covered by one stage of work each.
+    Raw raw0, raw1;
+    load_stage(0, raw0);
+    store_stage(raw0, 0);
+    load_stage(1, raw1);
     __syncthreads();
 
     auto stage_body = [&](int s, Raw& fetch, const Raw& land) {
@@ -296,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const float* sda = (const float*)(sa + C::A_BYTES);
         const uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
         const float* sdw = (const float*)(sw + C::W_BYTES);
-        if (s > 0) load_stage(s + PD_, fetch);   // (stage PD_ was requested by the prologue)
+        load_stage(s + 2, fetch);
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) {
             // ---- operands of this quant block
@@ -336,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[j], acc[t][j], 0, 0, 0);
                     }
                 }
-            if (WM * WN >= 8) __builtin_amdgcn_sched_barrier(0);     // (small tiles: let the blocks of a stage overlap)
+            __builtin_amdgcn_sched_barrier(0);
             // ---- vector phase: dot += isum * da * dw, left to right like the scalar build (gten/ops.h:311).
             //      Plain f32 on purpose: packed f32 beside MFMAs is the slower form on gfx950 (build.py)
             if (QUANT) {
@@ -354,15 +321,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                     for (int j = 0; j < WN; j++) asm volatile("" : "+v"(acc[t][j]));
             }
-            if (WM * WN >= 8) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < nstage) store_stage(land, buf ^ 1);    // stage s + 1 into the buffer last read two barriers ago
         __syncthreads();
     };
-    for (int s0 = 0; s0 < nstage; s0 += PD_) {
-#pragma unroll
-        for (int u = 0; u < PD_; u++)
-            if (s0 + u < nstage) stage_body(s0 + u, raw[u], raw[(u + 1) % PD_]);
+    for (int s = 0; s < nstage; s += 2) {
+        stage_body(s, raw0, raw1);
+        if (s + 1 < nstage) stage_body(s + 1, raw1, raw0);
     }
 
     // ---- rows written in the output dtype straight from the accumulators (gten/ops.h:73-96)
@@ -381,16 +347,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 if (out_dtype == GTEN_Q8) {
                     // one 32-wide output block = tiles j, j + 1 of this wave
                     const Q8Scale sc = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(v0), fabsf(v1))));
-                    uint8_t* blk = orow + (size_t)((colbase + col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
+                    uint8_t* blk = orow + (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
                     if (ok0) blk[2 + l16] = (uint8_t)(int8_t)q8_round(v0, sc.scale);
                     if (ok1) blk[18 + l16] = (uint8_t)(int8_t)q8_round(v1, sc.scale);
                     if (ok0 && l16 == 0) *(uint16_t*)blk = sc.d16;
                 } else if (out_dtype == GTEN_F16) {
-                    if (ok0) ((uint16_t*)orow)[colbase + c0] = f2h(v0);
-                    if (ok1) ((uint16_t*)orow)[colbase + c1] = f2h(v1);
+                    if (ok0) ((uint16_t*)orow)[c0] = f2h(v0);
+                    if (ok1) ((uint16_t*)orow)[c1] = f2h(v1);
                 } else {
-                    if (ok0) ((float*)orow)[colbase + c0] = v0;
-                    if (ok1) ((float*)orow)[colbase + c1] = v1;
+                    if (ok0) ((float*)orow)[c0] = v0;
+                    if (ok1) ((float*)orow)[c1] = v1;
                 }
             }
         }
@@ -444,57 +410,8 @@ static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, i
     }
     const dim3 grid((d_out + C::BN - 1) / C::BN, (rows + C::BM - 1) / C::BM), block(256);
     GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_>), grid, block, C::smem(), a16, a_pitch, (const float*)da, w, (uint8_t*)out,
-               out_dtype, out_pitch, n, d_in, d_out, start_pos, MfmaExtra{nullptr, nullptr, 0, 0});
+               out_dtype, out_pitch, n, d_in, d_out, start_pos);
     return 0;
-}
-
-// W.x for `rows` staged decode rows: int8 activations [rows][d_in] + f32 block deltas [rows][d_in/32] (the ActQ8
-// staging of gten_decode.hip), f32 results.  No scratch, no lazy state after gten_mfma_prepare(): graph-capturable.
-// (Tried and removed: split-K over blockIdx.z with the last-arriving workgroup adding the slices in order.  Correct and
-//  deterministic, but the agent-scope release/acquire around the arrival counter cost far more than the shorter K
-//  chain saved: q|k|v 17 -> 26 us, lm_head 30 -> 414 us at 32 sequences.)
-template <int WT, int WM, int WN>
-static int launch_a8(const int8_t* aq, const float* ad, const void* w, float* out, size_t out_pitch, int rows, int d_in, int d_out,
-                     const MfmaExtra& ex, int tag)
-{
-    using namespace gtr;
-    using C = MfmaCfg<WT, WM, WN, 4, true, 4>;
-    const int cols = d_out + (ex.w1 ? ex.d1 : 0) + (ex.w2 ? ex.d2 : 0);
-    GTR_REQUIRE(!ex.w1 || (d_out % C::BN == 0 && (!ex.w2 || ex.d1 % C::BN == 0)), "matmul_mfma_a8: concatenated matrices must be multiples of %d wide", C::BN);
-    const dim3 grid((cols + C::BN - 1) / C::BN, (rows + C::BM - 1) / C::BM);
-    GTR_LAUNCH(tag, (k_matmul_mfma<WT, WM, WN, 4, true, 4>), grid, dim3(256), C::smem(), (const uint8_t*)aq, (size_t)d_in, ad, w, (uint8_t*)out,
-               (int)GTEN_F32, out_pitch, rows, d_in, d_out, 0, ex);
-    return 0;
-}
-
-int gten_mfma_prepare_a8(int w_dtype)
-{
-    using namespace gtr;
-    if (w_dtype == GTEN_Q4) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<GTEN_Q4, 1, 2, 4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MfmaCfg<GTEN_Q4, 1, 2, 4, true, 4>::smem()));
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<GTEN_Q4, 2, 2, 4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MfmaCfg<GTEN_Q4, 2, 2, 4, true, 4>::smem()));
-    } else if (w_dtype == GTEN_Q8) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<GTEN_Q8, 1, 2, 4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MfmaCfg<GTEN_Q8, 1, 2, 4, true, 4>::smem()));
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<GTEN_Q8, 2, 2, 4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MfmaCfg<GTEN_Q8, 2, 2, 4, true, 4>::smem()));
-    } else {
-        return fail(-4, "mfma_prepare_a8: quantized weights only (got dtype %d)", w_dtype);
-    }
-    return 0;
-}
-
-int gten_launch_matmul_mfma_a8(const int8_t* aq, const float* ad, const void* w, int w_dtype, float* out, size_t out_pitch,
-                               int rows, int d_in, int d_out, const void* w1, int d1, const void* w2, int d2, int tag)
-{
-    using namespace gtr;
-    GTR_REQUIRE(d_in % 128 == 0 && rows >= 1, "matmul_mfma_a8: d_in %d must be a multiple of 128", d_in);
-    const MfmaExtra ex{w1, w2, d1, d2};
-    if (w_dtype == GTEN_Q4)
-        return rows > 32 ? launch_a8<GTEN_Q4, 2, 2>(aq, ad, w, out, out_pitch, rows, d_in, d_out, ex, tag)
-                         : launch_a8<GTEN_Q4, 1, 2>(aq, ad, w, out, out_pitch, rows, d_in, d_out, ex, tag);
-    if (w_dtype == GTEN_Q8)
-        return rows > 32 ? launch_a8<GTEN_Q8, 2, 2>(aq, ad, w, out, out_pitch, rows, d_in, d_out, ex, tag)
-                         : launch_a8<GTEN_Q8, 1, 2>(aq, ad, w, out, out_pitch, rows, d_in, d_out, ex, tag);
-    return fail(-4, "matmul_mfma_a8: quantized weights only (got dtype %d)", w_dtype);
 }
 
 // the largest tile that still gives the chip enough workgroups

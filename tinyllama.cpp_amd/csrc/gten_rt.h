@@ -52,12 +52,6 @@ enum {
 int gten_launch_matmul_mfma(const void* x, int x_dtype, size_t x_pitch, const void* w, int w_dtype,
                             void* out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos);
 
-// the same kernel fed from the decode staging (int8 rows + f32 block deltas), f32 out; see gten_mfma.hip
-int gten_mfma_prepare_a8(int w_dtype);
-// (w1/w2: further matrices with the same input, their d1/d2 output columns follow w's: q|k|v, gate|up in one launch)
-int gten_launch_matmul_mfma_a8(const int8_t* aq, const float* ad, const void* w, int w_dtype, float* out, size_t out_pitch,
-                               int rows, int d_in, int d_out, const void* w1, int d1, const void* w2, int d2, int tag);
-
 // gten_attn_tiled.hip: ops::qkv_attn for >= GTEN_ATTN_TILED_MIN_ROWS new rows (Q8 activations, d_head 64)
 #define GTEN_ATTN_TILED_MIN_ROWS 16
 int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
