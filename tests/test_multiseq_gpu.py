@@ -117,3 +117,34 @@ def test_wide_batch_on_matrix_cores_tracks_single_sequence_decode(hip, name, wd,
                     assert got_id == int(np.argmax(want)), (name, n_seq, q, n)
         m.close()
     assert not np.array_equal(runs[0][N][0][1], runs[0][N][1][1])       # independent sequences
+
+
+@pytest.mark.parametrize("heads,kv", [(8, 1), (4, 2), (4, 4)])
+def test_grouped_attention_is_bit_identical_to_per_head_kernels(hip, monkeypatch, heads, kv):
+    """wide decode serves all query heads of a kv group from one workgroup (k_dec_attn_score_g / _pv_g): the same
+    bytes as the per-head kernels (GTEN_HIP_ATTN_PER_HEAD=1) -- argmax ids and logits of every sequence, across the
+    attention chunk boundary -- for 8, 2 and 1 query heads per kv head"""
+    from helpers import Q4, Q8
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_embd=64 * heads, n_ffn=512, n_heads=heads, n_kv_heads=kv, max_ctx=320, n_layers=2))
+    n_seq, N = 16, 270
+    streams = [host.synthetic_tokens(N, seed=40 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
+    runs = []
+    for per_head in ("1", "0"):
+        monkeypatch.setenv("GTEN_HIP_ATTN_PER_HEAD", per_head)
+        batch = host.batch(cfg, n_seq)
+        for i in range(len(cfg.weight_shapes())):
+            batch.set_weight(i, host.synth_weight(cfg, 12, i))
+        for q in range(n_seq):
+            batch.decode_begin(q, streams[q])
+        snaps = []
+        for n in range(1, N + 1):
+            batch.decode_step(n, n % 3 != 0)
+            if n in (1, 5, 255, 256, 257, N):
+                snaps.append([(batch.decode_result(q, n), batch.logits(q).copy()) for q in range(n_seq)])
+        runs.append(snaps)
+        batch.close()
+    for sa, sb in zip(*runs):
+        for (ra, la), (rb, lb) in zip(sa, sb):
+            assert ra == rb and np.array_equal(la, lb)

@@ -1526,6 +1526,199 @@ __global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsi
     }
 }
 
+// ---- the two passes for MANY sequences: one workgroup per (kv head, chunk, sequence) serves all the query heads of
+// the group (8 for TinyLlama), so a K / V chunk is read once instead of once per query head and the launch has
+// 8x fewer workgroups -- at 32 sequences the per-head kernels above spend 29 + 44 us per block on 8192 small
+// workgroups.  Q8 activations, d_head 64, <= 8 heads per group.  Per (head, position) the arithmetic and every
+// reduction order are those of k_dec_attn_score64 / k_dec_attn_pv64: byte-identical scores, statistics and outputs.
+#define DEC_MAXGRP 8
+
+template <int GRP>
+__global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
+{
+    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
+    constexpr int dh = 64, nblk = 2, NW = 17;
+    const int n = a.step->n, pos = n - 1;
+    const int g = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= n) return;
+    const int kv_dim = a.n_kv * dh;
+    const size_t head_bytes = (size_t)nblk * GTEN_Q8_BYTES;
+
+    float* red = (float*)g_smem;                                  // [4][GRP]
+    float* qd = red + 4 * GRP;                                    // [GRP][2] (+ pad to 4)
+    float* kd = qd + 4 * GRP;                                     // 8: new k deltas, new v deltas
+    float* qf = kd + 8;                                           // scratch f32 row of head_prep (unused values)
+    uint16_t* d16 = (uint16_t*)(qf + dh);                         // [GRP + 2][4] halves
+    int8_t* qi8 = (int8_t*)(d16 + 4 * (GRP + 2));                 // [GRP][64]
+    int8_t* ki8 = qi8 + GRP * dh;                                 // 64
+    int8_t* vi8 = ki8 + dh;                                       // 64
+
+    // ---- request this thread's cached K row (rows past n re-read row c0; unused)
+    const int c = c0 + threadIdx.x;
+    const int cs = (c < n && c != pos) ? c : c0;
+    const unsigned* kp = (const unsigned*)(a.kcache + (size_t)cs * a.kv_pitch + (size_t)g * head_bytes);
+    unsigned kw[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) kw[j] = kp[j];
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- head vectors: wave w prepares query heads w, w + 4; wave 0 also the new k row, wave 1 the new v row
+    const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+#pragma unroll
+    for (int jj = 0; jj < (GRP + 3) / 4; jj++) {
+        const int j = pw + 4 * jj;
+        if (j < GRP) (void)head_prep(a.qkv_raw[(g * GRP + j) * dh + t], true, true, pos, dh, GTEN_Q8, a.rope, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+    }
+    if (pw == 0 && has_new) {
+        (void)head_prep(a.qkv_raw[a.n_embd + g * dh + t], true, true, pos, dh, GTEN_Q8, a.rope, ki8, kd, d16 + 4 * GRP);
+        uint8_t* blk = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+        blk[2 + (t & 31)] = (uint8_t)ki8[t];
+        if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * GRP + (t >> 5)];
+    } else if (pw == 1 && has_new) {
+        (void)head_prep(a.qkv_raw[a.n_embd + kv_dim + g * dh + t], true, false, pos, dh, GTEN_Q8, a.rope, vi8, kd + 4, d16 + 4 * (GRP + 1));
+        uint8_t* blk = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+        blk[2 + (t & 31)] = (uint8_t)vi8[t];
+        if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * (GRP + 1) + (t >> 5)];
+    }
+    __syncthreads();
+
+    // ---- this position against every head of the group
+    const float scale = 1.0f / sqrtf((float)dh);
+    const float kd0 = (c == pos) ? kd[0] : h2f((uint16_t)(kw[0] & 0xffffu));
+    const float kd1 = (c == pos) ? kd[1] : h2f((uint16_t)(kw[8] >> 16));
+    int kq[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        kq[j] = (c == pos) ? ((const int*)ki8)[j] : (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16);
+        kq[8 + j] = (c == pos) ? ((const int*)ki8)[8 + j] : (int)kw[9 + j];
+    }
+    float sc[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        sc[j] = -INFINITY;
+        if (c < n) {
+            const int* qi = (const int*)(qi8 + j * dh);
+            float acc = 0.f;
+            int isum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum = dot4(qi[k], kq[k], isum);
+            acc += (float)isum * (qd[2 * j] * kd0);
+            isum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], kq[8 + k], isum);
+            acc += (float)isum * (qd[2 * j + 1] * kd1);
+            sc[j] = acc * scale;
+            a.scores[(size_t)(g * GRP + j) * a.max_ctx + c] = sc[j];
+        }
+    }
+    // ---- chunk maximum and sum of exponentials per head (block_max / block_sum, all heads per barrier pair)
+    float mx[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        const float m = wave_max(sc[j]);
+        if (t == 0) red[pw * GRP + j] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        float m = red[j];
+        for (int w = 1; w < 4; w++) m = fmaxf(m, red[w * GRP + j]);
+        mx[j] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        const float ex = (c < n) ? expf(sc[j] - mx[j]) : 0.f;
+        const float sw = wave_sum(ex);
+        if (t == 0) red[pw * GRP + j] = sw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            float sm = 0.f;
+            for (int w = 0; w < 4; w++) sm += red[w * GRP + j];
+            a.stats[((size_t)(g * GRP + j) * a.n_chunks + chunk) * 2 + 0] = mx[j];
+            a.stats[((size_t)(g * GRP + j) * a.n_chunks + chunk) * 2 + 1] = sm;
+        }
+    }
+}
+
+template <int GRP>
+__global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
+{
+    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
+    constexpr int dh = 64, NW = 17;
+    const int n = a.step->n;
+    const int g = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= n) return;
+    const size_t head_bytes = (size_t)2 * GTEN_Q8_BYTES;
+    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+    const int len = min(DEC_CHUNK, n - c0);
+
+    float* p = (float*)g_smem;                                    // [GRP][256]
+    float* part = p + GRP * DEC_CHUNK;                            // [GRP][256]
+    unsigned* vl = (unsigned*)(part + GRP * DEC_CHUNK);           // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
+
+    // ---- request the whole V chunk: dword idx -> (row idx / NW, word idx % NW)
+    unsigned vw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int idx = threadIdx.x + k * 256;
+        int row = idx / NW;
+        const int w = idx - row * NW;
+        if (row >= len) row = 0;
+        vw[k] = ((const unsigned*)(a.vcache + (size_t)(c0 + row) * a.kv_pitch + (size_t)g * head_bytes))[w];
+    }
+    const int c = c0 + threadIdx.x;
+    float scv[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; j++) scv[j] = (c < n) ? a.scores[(size_t)(g * GRP + j) * a.max_ctx + c] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- probabilities of every head of the group, rounded to the activation dtype along the context
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        const float* st = a.stats + (size_t)(g * GRP + j) * a.n_chunks * 2;
+        float M = -INFINITY;
+        for (int q = 0; q < nch; q++) M = fmaxf(M, st[q * 2]);
+        float S = 0.f;
+        for (int q = 0; q < nch; q++) S += st[q * 2 + 1] * expf(st[q * 2] - M);
+        p[j * DEC_CHUNK + threadIdx.x] = (c < n) ? expf(scv[j] - M) / S : 0.f;
+    }
+    // (round_row_inplace touches element i with thread i only: no barrier needed between write and rounding)
+#pragma unroll
+    for (int j = 0; j < GRP; j++) round_row_inplace(p + j * DEC_CHUNK, GTEN_Q8, len);
+#pragma unroll
+    for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
+    __syncthreads();
+
+    // ---- p.V: a V element is dequantized once and feeds all heads
+    const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const uint8_t* vb = (const uint8_t*)vl;
+    const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+    float acc[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; j++) acc[j] = 0.f;
+#pragma unroll 4
+    for (int cl = cg; cl < len; cl += 4) {
+        const uint8_t* row = vb + (size_t)cl * 68;
+        const float v = (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff));
+#pragma unroll
+        for (int j = 0; j < GRP; j++) acc[j] += p[j * DEC_CHUNK + cl] * v;
+    }
+#pragma unroll
+    for (int j = 0; j < GRP; j++) part[j * DEC_CHUNK + threadIdx.x] = acc[j];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < GRP * dh; idx += 256) {
+        const int j = idx >> 6, ee = idx & 63;
+        float o = 0.f;
+        for (int gi = 0; gi < 4; gi++) o += part[j * DEC_CHUNK + gi * dh + ee];
+        a.att_part[((size_t)(g * GRP + j) * a.n_chunks + chunk) * dh + ee] = o;
+    }
+}
+
 // greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424).
 // Works on (value, index) candidates: either the logits themselves (idx == null)
 // or the per-wave winners the lm_head kernel left behind.
@@ -1603,6 +1796,36 @@ struct gten_hip_decoder {
     hipGraphExec_t exec = nullptr;
     const float2* rope = nullptr;
 };
+
+// many sequences, Q8 activations, 64-wide heads, 8 (or 4, 2, 1) query heads per kv head: grouped kernels
+static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
+{
+    const int grp = t.n_heads / t.n_kv;
+    const char* e = std::getenv("GTEN_HIP_ATTN_PER_HEAD");      // =1: the per-head kernels (comparison / tests)
+    const bool off = e && e[0] == '1';
+    return !off && n_seq >= 16 && t.adtype == GTEN_Q8 && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
+}
+
+template <int GRP>
+static int launch_attention_g(const AttnArgs& t, int n_seq)
+{
+    const dim3 grid(t.n_kv, t.n_chunks, n_seq);
+    const size_t smem1 = (size_t)(4 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
+    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4;
+    DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP>), grid, dim3(256), smem1, t);
+    DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP>), grid, dim3(256), smem2, t);
+    return 0;
+}
+
+static int launch_attention_grouped(const AttnArgs& t, int n_seq)
+{
+    switch (t.n_heads / t.n_kv) {
+    case 8: return launch_attention_g<8>(t, n_seq);
+    case 4: return launch_attention_g<4>(t, n_seq);
+    case 2: return launch_attention_g<2>(t, n_seq);
+    default: return launch_attention_g<1>(t, n_seq);
+    }
+}
 
 static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
 {
@@ -1908,6 +2131,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
     float* xbuf = (float*)dc->xbuf;
     float* hbuf = (float*)dc->hbuf;
     int rc;
+    bool grouped = false, grouped_known = false;
     Gemv8Args base{};
     base.step = dc->step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
     base.best_stride = dc->n_best;
@@ -1943,7 +2167,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         t.part_stride = d.n_heads * dc->n_chunks * dh;
         const dim3 agrid(d.n_heads, dc->n_chunks, S);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        if ((rc = launch_attention(t, agrid, smem1))) return rc;
+        if (!grouped_known) { grouped = attention_grouped_ok(t, S); grouped_known = true; }
+        if ((rc = grouped ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
         Gemv8Args sa = base;
         sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.n_chunks = dc->n_chunks;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
