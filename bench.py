@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--wide-streams", type=int, default=64, choices=[0, 16, 32, 48, 64],
+                    help="also report the aggregate rate of this many sequences on the matrix-core decode path (0: skip)")
     ap.add_argument("--streams", type=int, default=8, choices=[0, 2, 4, 8, 16, 32, 48, 64],
                     help="also measure this many sequences sharing each weight pass on the GPU (0 = skip); "
                          "reported separately, `value` stays the single-sequence rate")
@@ -280,9 +282,7 @@ def main():
         "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1)},
     }
     # secondary: several sequences on this GPU sharing every weight pass (not part of `value`)
-    if world == 1 and fused and args.streams > 1:
-        S = args.streams
-        model.close()
+    def multi_stream(S, note):
         batch = host.batch(cfg, S)
         batch.load_synthetic(args.seed)
         for q in range(S):
@@ -299,16 +299,30 @@ def main():
         dt = time.perf_counter() - t0
         ms = dt / K * 1e3
         bytes_step = algorithmic_bytes(args.mode, n_mid) + (S - 1) * (algorithmic_bytes(args.mode, n_mid) - algorithmic_bytes(args.mode, 0))
-        fam_idx = hip.prof_family_index("decode_gemv_gateup")
-        g_us, _ = batch.time_family(fam_idx, N_CTX, 20)
-        out["multi_stream"] = {"streams": S, "tok_s": round(S * K / dt, 1), "ms_per_step": round(ms, 4),
-                               "speedup_vs_single": round(S * K / dt / tok_s, 2),
-                               "hbm": {"achieved": round(bytes_step / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                       "algorithmic_bytes_per_step": int(bytes_step),
-                                       "note": "weights once per step + one K/V history per sequence"},
-                               "gateup_kernel_us": round(g_us, 3), "last_tokens": [batch.decode_result(q, n_of(W + K - 1, total)) for q in range(S)],
-                               "note": "per sequence bit-identical to the single-sequence decoder (tests/test_multiseq_gpu.py)"}
+        fams = {}
+        for fam in ("decode_gemv_qkv", "decode_attn_score", "decode_attn_pv", "decode_gemv_o", "decode_gemv_gateup", "decode_gemv_down"):
+            us, per = batch.time_family(hip.prof_family_index(fam), N_CTX, 20)
+            fams[fam] = {"us": round(us, 2), "launches": per}
+        res = {"streams": S, "tok_s": round(S * K / dt, 1), "ms_per_step": round(ms, 4),
+               "speedup_vs_single": round(S * K / dt / tok_s, 2),
+               "hbm": {"achieved": round(bytes_step / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                       "algorithmic_bytes_per_step": int(bytes_step),
+                       "note": "weights once per step + one K/V history per sequence"},
+               "gateup_kernel_us": fams["decode_gemv_gateup"]["us"], "kernel_us": fams,
+               "last_tokens": [batch.decode_result(q, n_of(W + K - 1, total)) for q in range(min(S, 8))],
+               "note": note}
         batch.close()
+        return res
+
+    if world == 1 and fused and (args.streams > 1 or args.wide_streams > 1):
+        model.close()
+        if args.streams > 1:
+            out["multi_stream"] = multi_stream(args.streams, "GEMV kernels: per sequence bit-identical to the single-sequence decoder "
+                                               "(tests/test_multiseq_gpu.py)" if args.streams <= 8 else "W.x on the matrix cores (k_dec_mmv)")
+        if args.wide_streams > 1 and args.mode != "f16":
+            out["multi_stream_wide"] = multi_stream(args.wide_streams, "W.x of the step as int8 MFMA GEMV (k_dec_mmv, rows = sequences), "
+                                                    "GQA-grouped attention; per sequence inside the model band around single-sequence decode, "
+                                                    "graph == eager bit for bit (tests/test_multiseq_gpu.py)")
         model = host.model(cfg)
         model.load_synthetic(args.seed)
     # secondary: prompt processing on the matrix cores (not part of `value`)

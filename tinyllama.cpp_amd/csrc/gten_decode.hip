@@ -1533,6 +1533,17 @@ __global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsi
 // reduction order are those of k_dec_attn_score64 / k_dec_attn_pv64: byte-identical scores, statistics and outputs.
 #define DEC_MAXGRP 8
 
+// max of the 64 lanes on the DPP path (same result as wave_max: a maximum has no order); every lane gets it
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+    v = quad_max(v);
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_mov<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <int GRP>
 __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 {
@@ -1616,7 +1627,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     float mx[GRP];
 #pragma unroll
     for (int j = 0; j < GRP; j++) {
-        const float m = wave_max(sc[j]);
+        const float m = wave_max_dpp(sc[j]);
         if (t == 0) red[pw * GRP + j] = m;
     }
     __syncthreads();
@@ -1657,9 +1668,10 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
     const int len = min(DEC_CHUNK, n - c0);
 
-    float* p = (float*)g_smem;                                    // [GRP][256]
+    float* p = (float*)g_smem;                                    // [GRP][4][64]: position c at [c & 3][c >> 2]
     float* part = p + GRP * DEC_CHUNK;                            // [GRP][256]
     unsigned* vl = (unsigned*)(part + GRP * DEC_CHUNK);           // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
+    float* ms = (float*)(vl + DEC_CHUNK * NW);                    // [GRP][2]: the row maximum and sum of each head
 
     // ---- request the whole V chunk: dword idx -> (row idx / NW, word idx % NW)
     unsigned vw[NW];
@@ -1677,36 +1689,52 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     for (int j = 0; j < GRP; j++) scv[j] = (c < n) ? a.scores[(size_t)(g * GRP + j) * a.max_ctx + c] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- probabilities of every head of the group, rounded to the activation dtype along the context
-#pragma unroll
-    for (int j = 0; j < GRP; j++) {
-        const float* st = a.stats + (size_t)(g * GRP + j) * a.n_chunks * 2;
+    // ---- row maximum and sum of every head from the chunk statistics: once per workgroup (thread j = head j)
+    if (threadIdx.x < GRP) {
+        const float* st = a.stats + (size_t)(g * GRP + threadIdx.x) * a.n_chunks * 2;
         float M = -INFINITY;
         for (int q = 0; q < nch; q++) M = fmaxf(M, st[q * 2]);
         float S = 0.f;
         for (int q = 0; q < nch; q++) S += st[q * 2 + 1] * expf(st[q * 2] - M);
-        p[j * DEC_CHUNK + threadIdx.x] = (c < n) ? expf(scv[j] - M) / S : 0.f;
+        ms[threadIdx.x * 2] = M; ms[threadIdx.x * 2 + 1] = S;
     }
-    // (round_row_inplace touches element i with thread i only: no barrier needed between write and rounding)
+    __syncthreads();
+    // ---- probabilities of every head of the group, rounded to the activation dtype along the context (the Q8
+    //      block of position c = the 32 lanes around this thread: round_row_inplace, in registers)
 #pragma unroll
-    for (int j = 0; j < GRP; j++) round_row_inplace(p + j * DEC_CHUNK, GTEN_Q8, len);
+    for (int j = 0; j < GRP; j++) {
+        const float x = (c < n) ? expf(scv[j] - ms[2 * j]) / ms[2 * j + 1] : 0.f;
+        const Q8Scale qs = q8_scale_from_absmax(max32(fabsf(x)));
+        p[j * DEC_CHUNK + (threadIdx.x & 3) * 64 + (threadIdx.x >> 2)] = (c < n) ? (float)q8_round(x, qs.scale) * qs.ddeq : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
     __syncthreads();
 
-    // ---- p.V: a V element is dequantized once and feeds all heads
+    // ---- p.V: a V element is dequantized once and feeds all heads; four positions of this thread's stride-4
+    //      sequence per step (their probabilities are one 16-byte LDS read per head)
     const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const uint8_t* vb = (const uint8_t*)vl;
     const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
     float acc[GRP];
 #pragma unroll
     for (int j = 0; j < GRP; j++) acc[j] = 0.f;
-#pragma unroll 4
-    for (int cl = cg; cl < len; cl += 4) {
-        const uint8_t* row = vb + (size_t)cl * 68;
-        const float v = (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff));
+    for (int i = 0; cg + 4 * i < len; i += 4) {
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < GRP; j++) acc[j] += p[j * DEC_CHUNK + cl] * v;
+        for (int u = 0; u < 4; u++) {
+            // positions past the chunk's end read a valid (clamped) row and meet p = 0
+            const uint8_t* row = vb + (size_t)min(cg + 4 * (i + u), DEC_CHUNK - 1) * 68;
+            v[u] = (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff));
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const float4 pp = *(const float4*)(p + j * DEC_CHUNK + cg * 64 + i);
+            acc[j] += pp.x * v[0];
+            acc[j] += pp.y * v[1];
+            acc[j] += pp.z * v[2];
+            acc[j] += pp.w * v[3];
+        }
     }
 #pragma unroll
     for (int j = 0; j < GRP; j++) part[j * DEC_CHUNK + threadIdx.x] = acc[j];
@@ -1811,7 +1839,7 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
 {
     const dim3 grid(t.n_kv, t.n_chunks, n_seq);
     const size_t smem1 = (size_t)(4 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
-    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4;
+    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4 + (size_t)2 * GRP * 4;
     DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP>), grid, dim3(256), smem1, t);
     DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP>), grid, dim3(256), smem2, t);
     return 0;
