@@ -340,8 +340,9 @@ def main():
         flops = 2.0 * 1_034_426_368 * P
         out["prefill"] = {"prompt_tokens": P, "ms": round(dt * 1e3, 3), "tok_s": round(P / dt, 1),
                           "linear_tflops": round(flops / dt / 1e12, 2),
-                          "note": "W.x on v_mfma_f32_16x16x32_f16 (one MFMA = one exact 32-wide quant block), "
-                                  "attention and element-wise ops on the operator kernels"}
+                          "note": "W.x on v_mfma_f32_16x16x32_f16 (one MFMA = one exact 32-wide quant block; gten_mfma.hip), "
+                                  "attention on gten_attn_tiled.hip (int8 MFMA scores; f16 activations: row kernel), element-wise "
+                                  "ops on the operator kernels; linear_tflops = linear-layer FLOPs / whole prefill time"}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(host, cfg, args.mode, args.seed, args.cpu_steps)
