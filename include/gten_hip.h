@@ -172,6 +172,9 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dec, int seq, const int32_
 /* asynchronous: computes row n-1, logits and their argmax.  use_graph != 0
  * replays the captured hipGraph (captured on first use). */
 int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
+/* multi-sequence decoders: sequence q decodes row n_per_seq[q] - 1 (continuous batching: sequences of different
+ * lengths share the weight passes); results are read per sequence with gten_hip_decoder_result_seq(dec, q, n_per_seq[q]) */
+int gten_hip_decoder_step_ragged(gten_hip_decoder* dec, const int* n_per_seq, int use_graph);
 /* HIP-event timing of one kernel family of the step (family index as in gten_hip_prof_family_name):
  * `reps` replays of a graph holding only that family's launches at context length n, bracketed by
  * two events on the library's stream; *avg_us = elapsed / (reps * launches per replay). */

@@ -80,6 +80,7 @@ int  gten_host_batch_set_weight(gten_host_batch* b, int idx, const void* bytes, 
 int  gten_host_batch_prefill(gten_host_batch* b, int seq, const int32_t* tokens, int n, float* logits_out);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
+int  gten_host_batch_decode_step_ragged(gten_host_batch* b, const int32_t* n_per_seq, int use_graph);   /* sequence q at its own n */
 int  gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out); /* waits */
 int  gten_host_batch_logits(gten_host_batch* b, int seq, float* logits_out);                /* waits; f32[n_vocab] */
 int  gten_host_batch_time_family(gten_host_batch* b, int family, int n, int reps, double* avg_us, int* launches);

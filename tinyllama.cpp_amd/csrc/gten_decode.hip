@@ -1807,6 +1807,7 @@ struct gten_hip_decoder {
     int* best_idx = nullptr;
     int n_best = 0;
     int dev_n = -1;                // value of step->n on the device after the queued work (-1: unknown)
+    std::vector<int> dev_ns;       // the same per sequence after a ragged step (empty: uniform, see dev_n)
     int only_family = -1;          // >= 0: enqueue only the launches of this kernel family (timing replays)
     // ---- multi-sequence decode (n_seq > 1): per-sequence rows of every scratch buffer above, plus
     int n_seq = 1;
@@ -2385,19 +2386,8 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t
     return 0;
 }
 
-int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
+static int run_step(gten_hip_decoder* dc, int use_graph)
 {
-    GTR_NEED_INIT();
-    GTR_REQUIRE(dc && n >= 1 && n <= dc->d.max_ctx, "decoder_step: n=%d outside [1, %d]", n, dc ? dc->d.max_ctx : 0);
-    // The step's position lives on the device and the argmax kernel advances it,
-    // so consecutive steps need no host-side update at all.  (All sequences of a
-    // multi-sequence decoder are at the same position.)
-    if (dc->dev_n != n) {
-        std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n, 1});
-        GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
-        GTR_CHECK(hipStreamSynchronize(stream()));    // `st` lives on this stack frame
-    }
-    dc->dev_n = n + 1;
     if (!use_graph || prof_on()) return enqueue(dc);    // event pairs cannot be recorded into a capture
     if (!dc->exec) {
         GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
@@ -2413,10 +2403,46 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
     return 0;
 }
 
-// Average duration of ONE kernel family of the decode step, timed with two HIP events on the
-// library's stream around `reps` replays of a graph that contains only that family's launches
-// (22 per replay for a per-block kernel).  The kernels run on whatever the last step left in the
-// scratch buffers: their timing does not depend on the values.
+int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && n >= 1 && n <= dc->d.max_ctx, "decoder_step: n=%d outside [1, %d]", n, dc ? dc->d.max_ctx : 0);
+    // The step's position lives on the device and the argmax kernel advances it,
+    // so consecutive steps need no host-side update at all.  (All sequences of a
+    // multi-sequence decoder are at the same position.)
+    if (dc->dev_n != n || !dc->dev_ns.empty()) {
+        std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n, 1});
+        GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));    // `st` lives on this stack frame
+    }
+    dc->dev_n = n + 1;
+    dc->dev_ns.clear();
+    return run_step(dc, use_graph);
+}
+
+// Sequences at DIFFERENT positions (continuous batching): sequence q decodes row n[q] - 1.  Every kernel of the
+// step already reads its position from the sequence's own step word, the attention grid covers the longest
+// context and workgroups past a sequence's end return at once.
+int gten_hip_decoder_step_ragged(gten_hip_decoder* dc, const int* n_per_seq, int use_graph)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && n_per_seq, "decoder_step_ragged: null argument");
+    for (int q = 0; q < dc->n_seq; q++)
+        GTR_REQUIRE(n_per_seq[q] >= 1 && n_per_seq[q] <= dc->d.max_ctx, "decoder_step_ragged: n[%d]=%d outside [1, %d]", q, n_per_seq[q], dc->d.max_ctx);
+    bool same = (int)dc->dev_ns.size() == dc->n_seq;
+    for (int q = 0; same && q < dc->n_seq; q++) same = dc->dev_ns[q] == n_per_seq[q];
+    if (!same) {
+        std::vector<DecStep> st((size_t)dc->n_seq);
+        for (int q = 0; q < dc->n_seq; q++) st[q] = DecStep{n_per_seq[q], 1};
+        GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));    // `st` lives on this stack frame
+    }
+    dc->dev_ns.assign(n_per_seq, n_per_seq + dc->n_seq);
+    for (int& v : dc->dev_ns) v += 1;                 // the argmax kernel advances every sequence
+    dc->dev_n = -1;
+    return run_step(dc, use_graph);
+}
+
 int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int reps, double* avg_us, int* launches_per_replay)
 {
     GTR_NEED_INIT();
@@ -2426,6 +2452,7 @@ int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int re
     GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
+    dc->dev_ns.clear();
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     g_only_family = family;

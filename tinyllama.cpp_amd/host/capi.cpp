@@ -197,6 +197,15 @@ int gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph)
     return 0;
 }
 
+int gten_host_batch_decode_step_ragged(gten_host_batch* b, const int32_t* n_per_seq, int use_graph)
+{
+    if (!n_per_seq) return -1;
+    for (int q = 0; q < b->batch->n_seq(); q++)
+        if (n_per_seq[q] < 1 || n_per_seq[q] > b->cfg.max_ctx) return -1;
+    b->batch->decode_step_ragged(n_per_seq, use_graph != 0);
+    return 0;
+}
+
 int gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out)
 {
     if (!argmax_out || seq < 0 || seq >= b->batch->n_seq()) return -1;

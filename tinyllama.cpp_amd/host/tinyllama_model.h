@@ -330,6 +330,12 @@ public:
         ensure_decoder();
         GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
     }
+    // asynchronous: row n[q]-1 of sequence q (continuous batching)
+    void decode_step_ragged(const int* n_per_seq, bool use_graph)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_step_ragged(dec_, n_per_seq, use_graph ? 1 : 0));
+    }
     int decode_result(int seq_i, int n)
     {
         ensure_decoder();

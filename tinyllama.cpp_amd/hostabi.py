@@ -38,7 +38,7 @@ class GtenHost:
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
-        "gten_host_batch_prefill", "gten_host_batch_decode_begin", "gten_host_batch_decode_step",
+        "gten_host_batch_prefill", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
         "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
     ]
 
@@ -72,6 +72,7 @@ class GtenHost:
         self._bprefill = _sig(L, "gten_host_batch_prefill", ci, [vp, ci, vp, ci, vp])
         self._bbegin = _sig(L, "gten_host_batch_decode_begin", ci, [vp, ci, vp, ci])
         self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
+        self._bstepr = _sig(L, "gten_host_batch_decode_step_ragged", ci, [vp, vp, ci])
         self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
         self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
         self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
@@ -232,6 +233,12 @@ class HostBatch:
 
     def decode_step(self, n, use_graph=True):
         self._ck(self.host._bstep(self.h, n, 1 if use_graph else 0), f"batch_decode_step({n})")
+
+    def decode_step_ragged(self, ns, use_graph=True):
+        """sequence q decodes row ns[q] - 1 (continuous batching)"""
+        ns = np.ascontiguousarray(ns, dtype=np.int32)
+        assert len(ns) == self.n_seq
+        self._ck(self.host._bstepr(self.h, ns.ctypes.data_as(C.c_void_p), 1 if use_graph else 0), "batch_decode_step_ragged")
 
     def decode_result(self, seq, n):
         out = C.c_int32(-1)
