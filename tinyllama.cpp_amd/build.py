@@ -46,6 +46,7 @@ def _sources(d, exts):
 # per-file additions.  Packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32) issues at half rate on gfx950 (and worse
 # beside MFMAs): the SLP vectorizer must not pair the per-block rescale / the p.V terms.
 HIP_FILE_FLAGS = {"gten_mfma.hip": ["-fno-slp-vectorize"], "gten_attn_tiled.hip": ["-fno-slp-vectorize"]}
+# (gten_decode.hip keeps the default: measured, no difference for its kernels)
 HIP_OBJ = os.path.join(CSRC, "_obj")
 
 

@@ -1547,11 +1547,14 @@ __device__ __forceinline__ float wave_max_dpp(float v)
 template <int GRP>
 __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 {
-    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
+    // grid = (sequence, chunk, kv head): the workgroups of a SHORT context's few live chunks are consecutive
+    // sequence indices, i.e. spread over all XCDs (with the kv head in x they were 4 of every 32 workgroups: half
+    // the chip idle at n <= 256)
     constexpr int dh = 64, nblk = 2, NW = 17;
+    const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= a0.step[blockIdx.x].n) return;                  // (measured: ahead of the cache-pointer loads of attn_for_seq)
+    const AttnArgs a = attn_for_seq(a0, blockIdx.x);
     const int n = a.step->n, pos = n - 1;
-    const int g = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= n) return;
     const int kv_dim = a.n_kv * dh;
     const size_t head_bytes = (size_t)nblk * GTEN_Q8_BYTES;
 
@@ -1659,11 +1662,11 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 template <int GRP>
 __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 {
-    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
     constexpr int dh = 64, NW = 17;
+    const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    if (c0 >= a0.step[blockIdx.x].n) return;
+    const AttnArgs a = attn_for_seq(a0, blockIdx.x);
     const int n = a.step->n;
-    const int g = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= n) return;
     const size_t head_bytes = (size_t)2 * GTEN_Q8_BYTES;
     const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
     const int len = min(DEC_CHUNK, n - c0);
@@ -1838,7 +1841,7 @@ static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
 template <int GRP>
 static int launch_attention_g(const AttnArgs& t, int n_seq)
 {
-    const dim3 grid(t.n_kv, t.n_chunks, n_seq);
+    const dim3 grid(n_seq, t.n_chunks, t.n_kv);
     const size_t smem1 = (size_t)(4 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
     const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4 + (size_t)2 * GRP * 4;
     DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP>), grid, dim3(256), smem1, t);
