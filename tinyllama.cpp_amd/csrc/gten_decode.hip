@@ -738,20 +738,25 @@ typedef int mmv_v4i __attribute__((ext_vector_type(4)));
 #define MMV_MAXP 11            // 16-byte weight pieces per thread: 16 features x 5632 B (Q8, K = 5632) / 512 threads / 16
 #define MMV_MAXD 6             // 16-byte pieces of the activation-delta table per thread: 176 blocks x 64 rows x 4 B / 512 / 16
 
-template <int WT, int RT, int CB>
+// FT = 16-feature tiles per workgroup: 1 for the launches that have about one workgroup per CU anyway (q|k|v, o,
+// down); 4 (Q4) / 2 (Q8) for gate|up and the lm_head at K = 2048, whose 704 / 2001 sixteen-feature workgroups would
+// run in several rounds -- each activation fragment and delta then feeds FT matrix instructions.
+template <int WT, int RT, int CB, int FT>
 __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
 {
     constexpr int SP = 16 * RT;                               // padded row count
+    constexpr int FR = 16 * FT;                               // features per workgroup
+    constexpr int NPF = MMV_MAXP / FT;                        // 16-byte weight pieces per thread and feature tile
     const int nb = a.d_in >> 5, nbw = nb >> 3;                // blocks per wave (nb % 8 == 0)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int rowb = nb * (WT == GTEN_Q4 ? 16 : 32);          // weight bytes per feature
-    uint8_t* wl = g_smem;                                     // [16][rowb], 16-byte pieces swizzled: slot = piece ^ (row & 7)
+    uint8_t* wl = g_smem;                                     // [FR][rowb], 16-byte pieces swizzled: slot = piece ^ (row & 7)
     float* red = (float*)g_smem;                              // [8][SP][16] -- over the slab, once the K loop is done
-    uint16_t* dwl = (uint16_t*)(wl + max((size_t)16 * rowb, (size_t)8 * SP * 64));   // [16][nb] weight deltas
-    float* daT = (float*)(dwl + (size_t)16 * nb);             // [nb][SP] activation deltas
+    uint16_t* dwl = (uint16_t*)(wl + max((size_t)FR * rowb, (size_t)8 * SP * 64));   // [FR][nb] weight deltas
+    float* daT = (float*)(dwl + (size_t)FR * nb);             // [nb][SP] activation deltas
 
     // which matrix (uniform)
-    int colw = blockIdx.x * 16, colbase = 0, m = 0;
+    int colw = blockIdx.x * FR, colbase = 0, m = 0;
     if (a.n_mats > 1 && colw >= a.d_out[0]) {
         colw -= a.d_out[0]; colbase = a.d_out[0]; m = 1;
         if (a.n_mats > 2 && colw >= a.d_out[1]) { colw -= a.d_out[1]; colbase += a.d_out[1]; m = 2; }
@@ -763,17 +768,21 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
     // ---- 1. everything this workgroup will read, requested at once (one memory round trip):
     //         the weight slab (32 threads per feature row, pieces c0 + 32 k), its deltas, the delta table of the
     //         activations, and this wave's first chunk of activation fragments
-    const int ppr = rowb >> 4;                                // pieces per feature row (<= 32 * MMV_MAXP)
+    const int ppr = rowb >> 4;                                // pieces per feature row (<= 32 * NPF)
     const int sr = threadIdx.x >> 5, c0 = threadIdx.x & 31;
-    const uint8_t* srow = pw.qs + (size_t)min(colw + sr, d_out - 1) * rowb;
-    uint4 wp[MMV_MAXP];
+    uint4 wp[FT][NPF];
+    unsigned dwv[FT][3];                                      // nb / 2 <= 88 dwords per row
 #pragma unroll
-    for (int k = 0; k < MMV_MAXP; k++)
-        if (32 * k < ppr) wp[k] = *(const uint4*)(srow + (size_t)min(c0 + 32 * k, ppr - 1) * 16);
-    const unsigned* drow = (const unsigned*)(pw.ds + (size_t)min(colw + sr, d_out - 1) * nb);
-    unsigned dwv[3];                                          // nb / 2 <= 88 dwords per row
+    for (int f = 0; f < FT; f++) {
+        const size_t frow = (size_t)min(colw + 16 * f + sr, d_out - 1);
+        const uint8_t* srow = pw.qs + frow * rowb;
 #pragma unroll
-    for (int k = 0; k < 3; k++) dwv[k] = drow[min(c0 + 32 * k, (nb >> 1) - 1)];
+        for (int k = 0; k < NPF; k++)
+            if (32 * k < ppr) wp[f][k] = *(const uint4*)(srow + (size_t)min(c0 + 32 * k, ppr - 1) * 16);
+        const unsigned* drow = (const unsigned*)(pw.ds + frow * nb);
+#pragma unroll
+        for (int k = 0; k < 3; k++) dwv[f][k] = drow[min(c0 + 32 * k, (nb >> 1) - 1)];
+    }
     const int ndp = nb * SP / 4;                              // 16-byte pieces of the [nb][SP] delta table (same layout in LDS)
     uint4 dap[MMV_MAXD];
 #pragma unroll
@@ -793,14 +802,18 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
 
     // ---- 2. park slab and tables in LDS
 #pragma unroll
-    for (int k = 0; k < MMV_MAXP; k++) {
-        const int c = c0 + 32 * k;
-        if (c < ppr) *(uint4*)(wl + (size_t)sr * rowb + (size_t)(c ^ (sr & 7)) * 16) = wp[k];
-    }
+    for (int f = 0; f < FT; f++) {
+        const int r = 16 * f + sr;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int c = c0 + 32 * k;
-        if (c < (nb >> 1)) ((unsigned*)dwl)[sr * (nb >> 1) + c] = dwv[k];
+        for (int k = 0; k < NPF; k++) {
+            const int c = c0 + 32 * k;
+            if (c < ppr) *(uint4*)(wl + (size_t)r * rowb + (size_t)(c ^ (r & 7)) * 16) = wp[f][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int c = c0 + 32 * k;
+            if (c < (nb >> 1)) ((unsigned*)dwl)[r * (nb >> 1) + c] = dwv[f][k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < MMV_MAXD; k++) {
@@ -812,12 +825,14 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
     // ---- 3. this wave's K slice
     const mmv_v4i zero4 = {0, 0, 0, 0};
     const int nshift = (g < 2) ? 4 : 0;
-    float acc[RT][4];
+    float acc[FT][RT][4];
 #pragma unroll
-    for (int t = 0; t < RT; t++)
+    for (int f = 0; f < FT; f++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc[t][i] = 0.f;
-    const uint8_t* wrow = wl + (size_t)l16 * rowb + (g & 1) * 8;
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[f][t][i] = 0.f;
+    const uint8_t* wrow = wl + (size_t)l16 * rowb + (g & 1) * 8;        // feature tile f: + 16 f rows (same swizzle: (16 f + l16) & 7 == l16 & 7)
     for (int bb = b0; bb < b0 + nbw; bb += CB) {
         uint2 aqv[RT][CB];
 #pragma unroll
@@ -828,46 +843,57 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
 #pragma unroll
         for (int c = 0; c < CB; c++) {
             const int b = min(bb + c, nb - 1);
-            // blocks past this wave's slice (ragged last chunk) are scaled by zero: no branch inside the chunk
-            const float dwf = (bb + c < b0 + nbw) ? h2f(dwl[l16 * nb + b]) : 0.f;
-            long bl;
-            if (WT == GTEN_Q4) {
-                // nibble - 7 as int8, byte-parallel: (n | 0x80) - 7 never borrows across bytes, ^ 0x80 restores the sign
-                const uint2 by = *(const uint2*)(wrow + (size_t)(b ^ (l16 & 7)) * 16);
-                const unsigned x = ((((by.x >> nshift) & 0x0f0f0f0fu) | 0x80808080u) - 0x07070707u) ^ 0x80808080u;
-                const unsigned y = ((((by.y >> nshift) & 0x0f0f0f0fu) | 0x80808080u) - 0x07070707u) ^ 0x80808080u;
-                bl = (long)(((unsigned long)y << 32) | x);
-            } else {
-                // Q8 rows are two planes of nb 16-byte pieces: elements 0-15, then 16-31
-                const int piece = (g >> 1) * nb + b;
-                const uint2 by = *(const uint2*)(wrow + (size_t)(piece ^ (l16 & 7)) * 16);
-                bl = (long)(((unsigned long)by.y << 32) | by.x);
+            const bool live = bb + c < b0 + nbw;                 // blocks past this wave's slice (ragged last chunk) are scaled by zero
+            long bl[FT];
+            float dwf[FT];
+#pragma unroll
+            for (int f = 0; f < FT; f++) {
+                dwf[f] = live ? h2f(dwl[(16 * f + l16) * nb + b]) : 0.f;
+                const uint8_t* wr = wrow + (size_t)16 * f * rowb;
+                if (WT == GTEN_Q4) {
+                    // nibble - 7 as int8, byte-parallel: (n | 0x80) - 7 never borrows across bytes, ^ 0x80 restores the sign
+                    const uint2 by = *(const uint2*)(wr + (size_t)(b ^ (l16 & 7)) * 16);
+                    const unsigned x = ((((by.x >> nshift) & 0x0f0f0f0fu) | 0x80808080u) - 0x07070707u) ^ 0x80808080u;
+                    const unsigned y = ((((by.y >> nshift) & 0x0f0f0f0fu) | 0x80808080u) - 0x07070707u) ^ 0x80808080u;
+                    bl[f] = (long)(((unsigned long)y << 32) | x);
+                } else {
+                    // Q8 rows are two planes of nb 16-byte pieces: elements 0-15, then 16-31
+                    const int piece = (g >> 1) * nb + b;
+                    const uint2 by = *(const uint2*)(wr + (size_t)(piece ^ (l16 & 7)) * 16);
+                    bl[f] = (long)(((unsigned long)by.y << 32) | by.x);
+                }
             }
 #pragma unroll
             for (int t = 0; t < RT; t++) {
                 const long al = (long)(((unsigned long)aqv[t][c].y << 32) | aqv[t][c].x);
-                const mmv_v4i isum = __builtin_amdgcn_mfma_i32_16x16x32_i8(al, bl, zero4, 0, 0, 0);
                 const float4 da4 = *(const float4*)(daT + (size_t)b * SP + 16 * t + 4 * g);
                 const float da[4] = {da4.x, da4.y, da4.z, da4.w};
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc[t][i] = acc[t][i] + ((float)isum[i] * da[i]) * dwf;
+                for (int f = 0; f < FT; f++) {
+                    const mmv_v4i isum = __builtin_amdgcn_mfma_i32_16x16x32_i8(al, bl[f], zero4, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[f][t][i] = acc[f][t][i] + ((float)isum[i] * da[i]) * dwf[f];
+                }
             }
         }
     }
 
-    // ---- 4. the eight K slices, added in wave order (the slab is dead: `red` lies over it)
-    __syncthreads();
+    // ---- 4. the eight K slices, added in wave order (the slab is dead: `red` lies over it), one feature tile at a time
 #pragma unroll
-    for (int t = 0; t < RT; t++)
+    for (int f = 0; f < FT; f++) {
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; i++) red[(wid * SP + 16 * t + 4 * g + i) * 16 + l16] = acc[t][i];
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < SP * 16; idx += 512) {
-        const int r = idx >> 4, c = idx & 15;
-        float v = 0.f;
+        for (int t = 0; t < RT; t++)
 #pragma unroll
-        for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
-        if (r < a.S && colw + c < d_out) a.out[(size_t)r * a.out_cols + colbase + colw + c] = v;
+            for (int i = 0; i < 4; i++) red[(wid * SP + 16 * t + 4 * g + i) * 16 + l16] = acc[f][t][i];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < SP * 16; idx += 512) {
+            const int r = idx >> 4, c = idx & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
+            if (r < a.S && colw + 16 * f + c < d_out) a.out[(size_t)r * a.out_cols + colbase + colw + 16 * f + c] = v;
+        }
     }
 }
 
@@ -2100,27 +2126,44 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
     return 0;
 }
 
-static size_t mmv_lds_bytes(int wt, int rt, int d_in)
+static size_t mmv_lds_bytes(int wt, int rt, int ft, int d_in)
 {
-    const size_t nb = (size_t)d_in / 32, sp = 16 * (size_t)rt;
-    return std::max(16 * nb * (wt == GTEN_Q4 ? 16 : 32), 8 * sp * 64) + 16 * nb * 2 + nb * sp * 4;
+    const size_t nb = (size_t)d_in / 32, sp = 16 * (size_t)rt, fr = 16 * (size_t)ft;
+    return std::max(fr * nb * (wt == GTEN_Q4 ? 16 : 32), 8 * sp * 64) + fr * nb * 2 + nb * sp * 4;
+}
+
+// feature tiles per workgroup: wide outputs at short K take 4 (Q4, <= 32 rows) / 2 -- see k_dec_mmv
+template <int WT, int RT>
+static int mmv_feature_tiles(const MmvArgs& a)
+{
+    constexpr int FTW = (WT == GTEN_Q4 && RT <= 2) ? 4 : 2;
+    const int cols = a.d_out[0] + (a.n_mats > 1 ? a.d_out[1] : 0) + (a.n_mats > 2 ? a.d_out[2] : 0);
+    const int ppr = (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) / 16;
+    bool ok = cols >= 4096 && ppr <= 32 * (MMV_MAXP / FTW);
+    for (int k = 0; k + 1 < a.n_mats; k++) ok = ok && a.d_out[k] % (16 * FTW) == 0;
+    return ok ? FTW : 1;
 }
 
 template <int WT, int RT>
 static int launch_mmv_rt(int tag, const MmvArgs& a)
 {
-    const size_t smem = mmv_lds_bytes(WT, RT, a.d_in);
+    constexpr int FTW = (WT == GTEN_Q4 && RT <= 2) ? 4 : 2;
+    const int ft = mmv_feature_tiles<WT, RT>(a);
+    const size_t smem = mmv_lds_bytes(WT, RT, ft, a.d_in);
     GTR_REQUIRE(smem <= 150 * 1024, "decoder: the slab and delta table of d_in %d x %d rows do not fit LDS", a.d_in, a.S);
     const int cols = a.d_out[0] + (a.n_mats > 1 ? a.d_out[1] : 0) + (a.n_mats > 2 ? a.d_out[2] : 0);
     const int nbw = a.d_in / 256;                               // quant blocks per wave
+    const dim3 grid((cols + 16 * ft - 1) / (16 * ft));
     // activation chunks: all of a wave's blocks at once when that is 8 or fewer, else elevens (5632 / 256 = 22);
-    // more than 32 rows: fours (registers)
-    if (RT > 2)
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4>), dim3((cols + 15) / 16), dim3(512), smem, a);
+    // more than 32 rows or several feature tiles: fours (registers)
+    if (ft > 1)
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, FTW>), grid, dim3(512), smem, a);
+    else if (RT > 2)
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, 1>), grid, dim3(512), smem, a);
     else if (nbw > 8 && nbw % 11 == 0)
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 11>), dim3((cols + 15) / 16), dim3(512), smem, a);
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 11, 1>), grid, dim3(512), smem, a);
     else
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 8>), dim3((cols + 15) / 16), dim3(512), smem, a);
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 8, 1>), grid, dim3(512), smem, a);
     return 0;
 }
 
@@ -2128,8 +2171,10 @@ static int launch_mmv_rt(int tag, const MmvArgs& a)
 template <int WT>
 static int mmv_prepare()
 {
-#define MMV_ATTR(RT_, CB_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmv<WT, RT_, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
-    MMV_ATTR(1, 8); MMV_ATTR(2, 8); MMV_ATTR(1, 11); MMV_ATTR(2, 11); MMV_ATTR(3, 4); MMV_ATTR(4, 4);
+    constexpr int FTA = (WT == GTEN_Q4) ? 4 : 2;        // <= 32 rows
+#define MMV_ATTR(RT_, CB_, FT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmv<WT, RT_, CB_, FT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+    MMV_ATTR(1, 8, 1); MMV_ATTR(2, 8, 1); MMV_ATTR(1, 11, 1); MMV_ATTR(2, 11, 1); MMV_ATTR(3, 4, 1); MMV_ATTR(4, 4, 1);
+    MMV_ATTR(1, 4, FTA); MMV_ATTR(2, 4, FTA); MMV_ATTR(3, 4, 2); MMV_ATTR(4, 4, 2);
 #undef MMV_ATTR
     return 0;
 }
