@@ -198,3 +198,28 @@ def test_sequences_at_different_positions(hip, n_seq):
                         assert gid == int(np.argmax(want)), (n_seq, q, n)
         assert len(got[q]) == 7
         m.close()
+
+
+def test_multiseq_argument_errors_are_reported(hip):
+    """bad batch sizes / positions fail loudly through the C-ABI instead of launching"""
+    from helpers import Q4, Q8
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=64, n_layers=1))
+    for bad in (1, 3, 12, 24, 80):
+        with pytest.raises(pkg.GtenHipError):
+            host.batch(cfg, bad)
+    b = host.batch(cfg, 16)
+    for i in range(len(cfg.weight_shapes())):
+        b.set_weight(i, host.synth_weight(cfg, 1, i))
+    for q in range(16):
+        b.decode_begin(q, host.synthetic_tokens(8, seed=q, n_vocab=cfg.n_vocab))
+    with pytest.raises(pkg.GtenHipError):
+        b.decode_step_ragged([1] * 15 + [65])            # past max_ctx
+    with pytest.raises(pkg.GtenHipError):
+        b.decode_step_ragged([0] + [1] * 15)             # position 0 does not exist
+    with pytest.raises(pkg.GtenHipError):
+        b.decode_step(65)
+    b.decode_step_ragged([1 + (q % 8) for q in range(16)])     # valid: runs
+    assert 0 <= b.decode_result(3, 1 + 3) < cfg.n_vocab
+    b.close()
