@@ -32,6 +32,7 @@ using namespace gtd;
 extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
 
 #define DEC_CHUNK 256            // attention positions per workgroup
+#define DEC_ATT_MAXCH 8          // chunk partials / statistics a consumer requests up front (2048 positions)
 #define GEMVM_F16_LDS_LIMIT 61440  // multi-sequence f16 inputs are staged in LDS up to this many bytes (stays under the 64 KiB default)
 
 // launches of a decode step can be restricted to one kernel family (gten_hip_decoder_time_family)
@@ -93,7 +94,8 @@ struct Gemv8Args {
     const float* res_a; const float* res_raw;                   // PRO_RESID (f32 rows)
     float* x_out;                                               // PRO_EMBED/PRO_RESID: new residual row, f32
     const uint16_t* norm_w;
-    const float* att_part; int d_head, n_chunks;                // PRO_ATT
+    const float* att_part; int d_head, n_chunks;                // PRO_ATT (d_head a power of two)
+    int d_head_shift;
     float* best_val; int* best_idx;                             // lm_head: per-wave running argmax (may be null)
     // EPI_SILUMUL writes / PRO_ACTQ8 reads the staged FFN activation in HBM (ActQ8 layout)
     int8_t* act_q; float* act_d; int* act_sum;
@@ -108,6 +110,9 @@ struct Gemv8Args {
     // the qkv launch clears the attention arrival counters of the launch that follows it
     unsigned* zero_words; int zero_count;
     int frag_rt;                  // EPI_STAGE_FRAG: row tiles (of 16 sequences) of the fragment-major staging (k_dec_mmv)
+    // PRO_EMBED (the step's first launch) copies the RoPE rotation of the current position where the score
+    // kernels find it without knowing the position: rope_now[seq][rope_half]
+    const float2* rope; float2* rope_now; int rope_half;
 };
 
 // ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
@@ -302,10 +307,22 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
 #pragma unroll
     for (int i = 0; i < EPT; i++) { pin0[i] = 0.f; pin1[i] = 0.f; }
     if (PRO == PRO_RESID) { ldN<EPT>(res_raw + sbase, pin0); ldN<EPT>(res_a + sbase, pin1); }
+    // (norm_w is required for PRO_EMBED / PRO_RESID: a null check here would be a branch whose join
+    // makes hipcc wait for every outstanding load BEFORE the weight rows below are even requested)
     unsigned nw[4] = {0, 0, 0, 0};
-    if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
+    if (PRO == PRO_EMBED || PRO == PRO_RESID) {
         if (EPT == 8) { const uint4 t = *(const uint4*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; nw[2] = t.z; nw[3] = t.w; }
         else { const uint2 t = *(const uint2*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; }
+    }
+    // PRO_ATT: all chunk partials of this thread's elements, requested at once (chunks past the context hold
+    // stale but readable data and are dropped by a select below); contexts of more than DEC_ATT_MAXCH chunks
+    // take the sequential loop for the rest
+    float apart[PRO == PRO_ATT ? DEC_ATT_MAXCH : 1][EPT];
+    if (PRO == PRO_ATT) {
+        const int h = sbase >> a.d_head_shift, e = sbase & (a.d_head - 1);
+#pragma unroll
+        for (int j = 0; j < DEC_ATT_MAXCH; j++)
+            ldN<EPT>(att_part + ((size_t)h * a.n_chunks + min(j, a.n_chunks - 1)) * a.d_head + e, apart[j]);
     }
     unsigned emb[4] = {0, 0, 0, 0};
     float emb_delta = 0.f;
@@ -314,6 +331,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         if (EPT == 8) { const uint4 t = *(const uint4*)src; emb[0] = t.x; emb[1] = t.y; emb[2] = t.z; emb[3] = t.w; }
         else { const uint2 t = *(const uint2*)src; emb[0] = t.x; emb[1] = t.y; }
     }
+    float2 rot_now = make_float2(1.f, 0.f);
+    if (PRO == PRO_EMBED) rot_now = a.rope[(size_t)(n - 1) * a.rope_half + (threadIdx.x & (a.rope_half - 1))];
     if (PRO == PRO_EMBED && !F16W) {
         const int tok = tokens[n - 1];
         const int sb = on ? blk : 0, ssub = on ? sub : 0;
@@ -404,31 +423,33 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
             act_roundN<WT, EPT>(v);                       // Residual output written in the activation dtype
         } else {                                          // PRO_ATT: sum of the per-chunk partials, fixed order
             const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-            const int h = sbase / a.d_head, e = sbase % a.d_head;
+            const int h = sbase >> a.d_head_shift, e = sbase & (a.d_head - 1);
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = 0.f;
-            for (int j = 0; j < nch; j++) {
+#pragma unroll
+            for (int j = 0; j < DEC_ATT_MAXCH; j++)
+#pragma unroll
+                for (int i = 0; i < EPT; i++) v[i] += (j < nch) ? apart[j][i] : 0.f;     // v + 0 == v: same sum as the loop
+            for (int j = DEC_ATT_MAXCH; j < nch; j++) {
                 float t[EPT];
                 ldN<EPT>(att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
 #pragma unroll
                 for (int i = 0; i < EPT; i++) v[i] += t[i];
             }
         }
-        if ((PRO == PRO_EMBED || PRO == PRO_RESID) && a.norm_w) {
+        if (PRO == PRO_EMBED || PRO == PRO_RESID) {
             if (on) {
                 if (x_out && stores_x) stN<EPT>(x_out + base, v);
                 ss = sumsq_treeN<EPT>(v);
             }
             // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
-            ss = block_sum_tree(ss, s.red);
+            ss = block_sum_tree_n<NW, true>(ss, s.red);             // first use of s.red in this kernel
             const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);  // see k_rms_norm
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 const uint16_t hw = (uint16_t)((i & 1) ? (nw[i >> 1] >> 16) : (nw[i >> 1] & 0xffffu));
                 v[i] = v[i] * inv * h2f(hw);
             }
-        } else if (PRO == PRO_EMBED || PRO == PRO_RESID) {
-            if (on && x_out && stores_x) stN<EPT>(x_out + base, v);
         }
         if (F16W) {
             act_roundN<WT, EPT>(v);
@@ -444,6 +465,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         __syncthreads();
     }
 
+    if (PRO == PRO_EMBED && stores_x && (int)threadIdx.x < a.rope_half) a.rope_now[(size_t)seq * a.rope_half + threadIdx.x] = rot_now;
     if (STG) return;
 
     // ---- 4. this lane's activation blocks, then the dot products
@@ -928,12 +950,20 @@ struct AttnArgs {
     float* stats;                 // [n_heads][n_chunks][2] (max, sum of exp)
     float* att_part;              // [n_heads][n_chunks][d_head]
     const float2* rope;
+    const float2* rope_now;       // [seq][d_head / 2]: the rotation of each sequence's CURRENT position, left by the step's first
+                                  // launch (PRO_EMBED) so that the score kernels can request it without knowing the position
     int adtype, n_heads, n_kv, d_head, max_ctx, n_chunks, n_embd;
     // multi-sequence decode: blockIdx.z = sequence; its caches come from a device table
     // [seq][layer][k|v], its scratch rows lie `*_stride` elements apart
     const void* const* kv_tab; int layer, n_layers;
     int qkv_stride, scores_stride, stats_stride, part_stride;
 };
+
+// The cache pointers may come out of the device table (multi-sequence), so hipcc only knows them as generic pointers
+// and would use FLAT loads -- which count on the LDS counter as well and force full vmcnt(0) waits (FLAT may return
+// out of order).  They always point to device memory: say so.
+typedef const unsigned __attribute__((address_space(1)))* gmem_u32;
+__device__ __forceinline__ gmem_u32 as_global(const void* p) { return (gmem_u32)(uintptr_t)p; }
 
 // per-sequence view of the arguments (identity for single-sequence launches)
 __device__ __forceinline__ AttnArgs attn_for_seq(const AttnArgs& a, int seq)
@@ -944,6 +974,7 @@ __device__ __forceinline__ AttnArgs attn_for_seq(const AttnArgs& a, int seq)
     t.scores = a.scores + (size_t)seq * a.scores_stride;
     t.stats = a.stats + (size_t)seq * a.stats_stride;
     t.att_part = a.att_part + (size_t)seq * a.part_stride;
+    t.rope_now = a.rope_now + (size_t)seq * (a.d_head >> 1);
     if (a.kv_tab) {
         t.kcache = (uint8_t*)a.kv_tab[((size_t)seq * a.n_layers + a.layer) * 2];
         t.vcache = (uint8_t*)a.kv_tab[((size_t)seq * a.n_layers + a.layer) * 2 + 1];
@@ -1167,9 +1198,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
     const AttnArgs a = attn_for_seq(a0, blockIdx.z);
     constexpr int dh = 64, nblk = 2;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
-    const int n = a.step->n, pos = n - 1;
     const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= n) return;
     const int grp = a.n_heads / a.n_kv, g = h / grp;
     const int kv_dim = a.n_kv * dh;
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
@@ -1184,43 +1213,44 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
     int8_t* ki8 = qi8 + dh;                      // dh
     int8_t* vi8 = ki8 + dh;                      // dh
 
-    // ---- request this thread's cached K row (rows past n re-read row c0; unused)
+    // ---- everything is requested before the context length is known: this thread's cached K row (rows past the
+    //      context are readable -- the caches span max_ctx -- and unused; the row AT the new position is being
+    //      written by this very launch and is not used either: that score comes from the new k row on chip), the
+    //      raw projection this wave turns into a head vector (wave 0: q, 1: new k row, 2: new v row), its rotation
     const int c = c0 + threadIdx.x;
-    const int cs = (c < n && c != pos) ? c : c0;
-    const unsigned* kp = (const unsigned*)(a.kcache + (size_t)cs * a.kv_pitch + (size_t)g * head_bytes);
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    const int roff = (pw == 1) ? a.n_embd + g * dh : (pw == 2) ? a.n_embd + kv_dim + g * dh : h * dh;
+    const float raw = a.qkv_raw[roff + t];
+    const float2 rot = a.rope_now[t & 31];
+    __builtin_amdgcn_sched_barrier(0);            // these two come back first (vmcnt is in order): the head vectors are built while the K rows fly
+    const int cs = min(c, a.max_ctx - 1);
+    const gmem_u32 kp = as_global(a.kcache + (size_t)g * head_bytes) + (unsigned)cs * (unsigned)(a.kv_pitch >> 2);
     unsigned kw[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) kw[j] = kp[j];
     __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
 
     const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
     const bool writer = has_new && (h % grp == 0);
-    // the three new head vectors are independent: one wave each (q | new k row | new v row)
-    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
-    if (pw == 0) {
-        qf[t] = head_prep(a.qkv_raw[h * dh + t], true, true, pos, dh, ADT, a.rope, qi8, qd, d16);
-    } else if (pw == 1 && has_new) {
-        const float v = head_prep(a.qkv_raw[a.n_embd + g * dh + t], true, true, pos, dh, ADT, a.rope, ki8, kd, d16 + 4);
-        kf[t] = v;
-        if (writer) {
-            uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+    // the three new head vectors are independent: one wave each (0: q | 1: new k row | 2: new v row), one copy of
+    // the code (the k / v waves also run where their row is not needed: it only lands in this workgroup's scratch)
+    if (pw < 3) {
+        int8_t* dq = (pw == 0) ? qi8 : (pw == 1) ? ki8 : vi8;
+        float* dd = (pw == 0) ? qd : (pw == 1) ? kd : kd + 4;
+        const float v = head_prep_cs(raw, true, pw != 2, rot, dh, ADT, dq, dd, d16 + 4 * pw);
+        if (pw == 0) qf[t] = v;
+        if (pw == 1) kf[t] = v;
+        if (pw >= 1 && writer) {
+            uint8_t* row = ((pw == 1) ? a.kcache : a.vcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
             if (ADT == GTEN_Q8) {
-                uint8_t* blk = krow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-                blk[2 + (t & 31)] = (uint8_t)ki8[t];
-                if ((t & 31) == 0) *(uint16_t*)blk = d16[4 + (t >> 5)];
+                uint8_t* blk = row + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                blk[2 + (t & 31)] = (uint8_t)dq[t];
+                if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * pw + (t >> 5)];
             } else {
-                ((uint16_t*)krow)[t] = f2h(v);
+                ((uint16_t*)row)[t] = f2h(v);
             }
-        }
-    } else if (pw == 2 && writer) {
-        const float v = head_prep(a.qkv_raw[a.n_embd + kv_dim + g * dh + t], true, false, pos, dh, ADT, a.rope, vi8, kd + 4, d16 + 8);
-        uint8_t* vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
-        if (ADT == GTEN_Q8) {
-            uint8_t* blk = vrow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-            blk[2 + (t & 31)] = (uint8_t)vi8[t];
-            if ((t & 31) == 0) *(uint16_t*)blk = d16[8 + (t >> 5)];
-        } else {
-            ((uint16_t*)vrow)[t] = f2h(v);
         }
     }
     __syncthreads();
@@ -1265,13 +1295,29 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
         sc = acc * scale;
         a.scores[(size_t)h * a.max_ctx + c] = sc;
     }
-    const float mx = block_max(sc, red);
+    const float mx = block_max_n<4>(sc, red);               // red: first use; the sum takes its own words
     const float ex = (c < n) ? expf(sc - mx) : 0.f;
-    const float sm = block_sum(ex, red);
+    const float sm = block_sum_n<4>(ex, red + 4);
     if (threadIdx.x == 0) {
         a.stats[((size_t)h * a.n_chunks + chunk) * 2 + 0] = mx;
         a.stats[((size_t)h * a.n_chunks + chunk) * 2 + 1] = sm;
     }
+}
+
+// Softmax statistics of a head for the p.V passes: global max M and S = sum_j l_j * exp(m_j - M), chunks in order.
+// Up to DEC_ATT_MAXCH chunks the (max, sum) pairs are ONE load per lane (lane j & 7 holds chunk j; requested by the
+// caller at kernel entry as `st`), the eight exponentials run in eight lanes at once, and the sum is taken in chunk
+// order through readlanes -- the same values and the same order as the sequential loop it replaces (x + 0 == x).
+__device__ __forceinline__ void softmax_stats8(const float2 st, int nch, float& M, float& S)
+{
+    const int j = threadIdx.x & 7;
+    float m = (j < nch) ? st.x : -INFINITY;
+    m = quad_max(m);
+    M = fmaxf(m, dpp_mov<0x141>(m));                         // row_half_mirror: all 8 lanes of the group
+    const float t = (j < nch) ? st.y * expf(st.x - M) : 0.f;
+    S = 0.f;
+#pragma unroll
+    for (int q = 0; q < DEC_ATT_MAXCH; q++) S += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), q));
 }
 
 template <int ADT>
@@ -1280,39 +1326,63 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a0)
     const AttnArgs a = attn_for_seq(a0, blockIdx.z);
     constexpr int dh = 64;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
-    const int n = a.step->n;
     const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= n) return;
     const int grp = a.n_heads / a.n_kv, g = h / grp;
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)2 * GTEN_Q8_BYTES : (size_t)dh * 2;
-    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-    const int len = min(DEC_CHUNK, n - c0);
 
     float* p = (float*)g_smem;                   // 256
     float* part = p + DEC_CHUNK;                 // 256
     unsigned* vl = (unsigned*)(part + DEC_CHUNK);// DEC_CHUNK * NW dwords: the chunk's V slices, row-major
 
-    // ---- request the whole V chunk: dword idx -> (row idx / NW, word idx % NW)
+    // ---- everything this workgroup reads is requested before the context length is even known: this thread's
+    //      score, the head's chunk statistics (the stats array has DEC_ATT_MAXCH chunks of slack), then the whole
+    //      V chunk: dword idx -> (row idx / NW, word idx % NW).  Rows past the context are readable (the caches
+    //      span max_ctx) and never used.
+    const int c = c0 + threadIdx.x;
+    const float sc_raw = a.scores[(size_t)h * a.max_ctx + min(c, a.max_ctx - 1)];
+    const float2 st = ((const float2*)a.stats)[(size_t)h * a.n_chunks + (threadIdx.x & 7)];
+    __builtin_amdgcn_sched_barrier(0);            // these two come back first (vmcnt is in order): the softmax math starts on them
     unsigned vw[NW];
+    {
+        // idx = t + 256 k -> (row, word) = (idx / NW, idx % NW), stepped without a division: 256 = (256 / NW) NW + 256 % NW
+        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        const gmem_u32 vbase = as_global(a.vcache + (size_t)g * head_bytes);
+        const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);   // rows are 4-byte aligned (68 / 128-byte head slices);
+        const int last = a.max_ctx - 1 - c0;                    // a cache is far below 4 GiB: 32-bit word offsets
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const int idx = threadIdx.x + k * 256;
-        int row = idx / NW;
-        const int w = idx - row * NW;
-        if (row >= len) row = 0;
-        vw[k] = ((const unsigned*)(a.vcache + (size_t)(c0 + row) * a.kv_pitch + (size_t)g * head_bytes))[w];
+        for (int k = 0; k < NW; k++) {
+            vw[k] = vbase[(unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w];
+            row += 256 / NW; w += 256 % NW;
+            if (w >= NW) { w -= NW; row++; }
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n;
+    if (c0 >= n) return;
+    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+    const int len = min(DEC_CHUNK, n - c0);
 
-    float M = -INFINITY;
-    for (int j = 0; j < nch; j++) M = fmaxf(M, a.stats[((size_t)h * a.n_chunks + j) * 2]);
-    float S = 0.f;
-    for (int j = 0; j < nch; j++)
-        S += a.stats[((size_t)h * a.n_chunks + j) * 2 + 1] * expf(a.stats[((size_t)h * a.n_chunks + j) * 2] - M);
+    float M, S;
+    if (nch <= DEC_ATT_MAXCH) {
+        softmax_stats8(st, nch, M, S);
+    } else {
+        M = -INFINITY;
+        for (int j = 0; j < nch; j++) M = fmaxf(M, a.stats[((size_t)h * a.n_chunks + j) * 2]);
+        S = 0.f;
+        for (int j = 0; j < nch; j++)
+            S += a.stats[((size_t)h * a.n_chunks + j) * 2 + 1] * expf(a.stats[((size_t)h * a.n_chunks + j) * 2] - M);
+    }
 
-    const int c = c0 + threadIdx.x;
-    p[threadIdx.x] = (c < n) ? expf(a.scores[(size_t)h * a.max_ctx + c] - M) / S : 0.f;
-    round_row_inplace(p, ADT, len);
+    // probabilities, rounded to the activation dtype in registers (a Q8 block = 32 consecutive lanes; the partial
+    // tail block takes its absmax over the live positions, zeros beyond: round_row_inplace's rule)
+    float pr = (c < n) ? expf(sc_raw - M) / S : 0.f;
+    if (ADT == GTEN_Q8) {
+        const Q8Scale s8 = q8_scale_from_absmax(max32(fabsf(pr)));
+        if (c < n) pr = (float)q8_round(pr, s8.scale) * s8.ddeq;
+    } else {
+        pr = h2f(f2h(pr));
+    }
+    p[threadIdx.x] = pr;
 #pragma unroll
     for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
     __syncthreads();
@@ -1558,17 +1628,6 @@ __global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsi
 // workgroups.  Q8 activations, d_head 64, <= 8 heads per group.  Per (head, position) the arithmetic and every
 // reduction order are those of k_dec_attn_score64 / k_dec_attn_pv64: byte-identical scores, statistics and outputs.
 #define DEC_MAXGRP 8
-
-// max of the 64 lanes on the DPP path (same result as wave_max: a maximum has no order); every lane gets it
-__device__ __forceinline__ float wave_max_dpp(float v)
-{
-    v = quad_max(v);
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    v = fmaxf(v, dpp_mov<0x140>(v));
-    v = fmaxf(v, dpp_mov<0x142, 0xA>(v));
-    v = fmaxf(v, dpp_mov<0x143, 0xC>(v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
 
 template <int GRP>
 __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
@@ -1853,6 +1912,7 @@ struct gten_hip_decoder {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const float2* rope = nullptr;
+    float2* rope_now = nullptr;       // [n_seq][d_head / 2], see Gemv8Args
 };
 
 // many sequences, Q8 activations, 64-wide heads, 8 (or 4, 2, 1) query heads per kv head: grouped kernels
@@ -1954,7 +2014,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = xbuf;
         if (dc->fused_attn) { a.zero_words = dc->arrive; a.zero_count = d.n_heads; }
         if (l == 0) {
-            a.table = d.embed; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
+            a.table = d.embed; a.rope = dc->rope; a.rope_now = dc->rope_now; a.rope_half = dh / 2; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
             rc = launch_gemv8<WT, PRO_EMBED, NE, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
         } else {
             a.res_a = hbuf; a.res_raw = dc->down_raw;
@@ -1963,7 +2023,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         if (rc) return rc;
         AttnArgs t{};
         t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kcache = (uint8_t*)L.kcache; t.vcache = (uint8_t*)L.vcache;
-        t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats; t.att_part = dc->att_part; t.rope = dc->rope;
+        t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats; t.att_part = dc->att_part; t.rope = dc->rope; t.rope_now = dc->rope_now;
         t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
         t.n_chunks = dc->n_chunks; t.n_embd = E;
         const dim3 agrid(d.n_heads, dc->n_chunks);
@@ -1979,7 +2039,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         } else if (int arc = launch_attention(t, agrid, smem1)) return arc;
         Gemv8Args o{};
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
-        o.att_part = dc->att_part; o.d_head = dh; o.n_chunks = dc->n_chunks;
+        o.att_part = dc->att_part; o.d_head = dh; o.d_head_shift = __builtin_ctz(dh); o.n_chunks = dc->n_chunks;
         if ((rc = launch_gemv8<WT, PRO_ATT, NE, 2, 512>(KT_DEC_GEMV_O, o, E))) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
@@ -2061,7 +2121,7 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         st.d_in = E; st.norm_w = (const uint16_t*)L.attn_norm; st.x_out = xbuf;
         st.act_q = dc->stg_q; st.act_d = dc->stg_d; st.act_sum = dc->stg_sum; st.act_f = dc->stg_f;
         if (l == 0) {
-            st.table = d.embed; st.n_vocab = V; st.tokens = dc->tokens;
+            st.table = d.embed; st.rope = dc->rope; st.rope_now = dc->rope_now; st.rope_half = dh / 2; st.n_vocab = V; st.tokens = dc->tokens;
             rc = launch_stage<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
         } else {
             st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E;
@@ -2077,7 +2137,7 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         // attention, one grid plane per sequence
         AttnArgs t{};
         t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
-        t.att_part = dc->att_part; t.rope = dc->rope;
+        t.att_part = dc->att_part; t.rope = dc->rope; t.rope_now = dc->rope_now;
         t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
         t.n_chunks = dc->n_chunks; t.n_embd = E;
         t.kv_tab = (const void* const*)dc->kv_tab; t.layer = l; t.n_layers = d.n_layers;
@@ -2088,7 +2148,7 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         if ((rc = launch_attention(t, agrid, smem1))) return rc;
         // attention rows -> stage -> o projection
         Gemv8Args sa = base;
-        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.n_chunks = dc->n_chunks;
+        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
         if ((rc = launch_stage<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
         Gemv8Args o = base;
@@ -2225,7 +2285,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         st.d_in = E; st.norm_w = (const uint16_t*)L.attn_norm; st.x_out = xbuf;
         st.act_q = dc->stg_q; st.act_d = dc->stg_d; st.act_sum = dc->stg_sum; st.act_f = dc->stg_f;
         if (l == 0) {
-            st.table = d.embed; st.n_vocab = V; st.tokens = dc->tokens;
+            st.table = d.embed; st.rope = dc->rope; st.rope_now = dc->rope_now; st.rope_half = dh / 2; st.n_vocab = V; st.tokens = dc->tokens;
             rc = launch_stage_frag<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
         } else {
             st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E;
@@ -2236,7 +2296,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         if ((rc = mm(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->stg_sum, dc->qkv_raw, QW, E, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
         AttnArgs t{};
         t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
-        t.att_part = dc->att_part; t.rope = dc->rope;
+        t.att_part = dc->att_part; t.rope = dc->rope; t.rope_now = dc->rope_now;
         t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
         t.n_chunks = dc->n_chunks; t.n_embd = E;
         t.kv_tab = (const void* const*)dc->kv_tab; t.layer = l; t.n_layers = d.n_layers;
@@ -2247,7 +2307,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         if (!grouped_known) { grouped = attention_grouped_ok(t, S); grouped_known = true; }
         if ((rc = grouped ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
         Gemv8Args sa = base;
-        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.n_chunks = dc->n_chunks;
+        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
         if ((rc = launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
         if ((rc = mm(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->stg_sum, dc->proj_raw, E, E, L.wo, E))) return rc;
@@ -2386,6 +2446,8 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     GTR_CHECK(hipMalloc((void**)&dc->arrive, (size_t)(d.n_heads + 1) * 4));
     GTR_CHECK(hipMemset(dc->arrive, 0, (size_t)(d.n_heads + 1) * 4));
     if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
+    GTR_CHECK(hipMalloc((void**)&dc->rope_now, S * (size_t)(dh / 2) * sizeof(float2)));
+    GTR_CHECK(hipMemset(dc->rope_now, 0, S * (size_t)(dh / 2) * sizeof(float2)));
     *out = dc;
     return 0;
 }
@@ -2413,7 +2475,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
-                    dc->logits_m, (void*)dc->kv_tab, dc->arrive, dc->gu_raw};
+                    dc->logits_m, (void*)dc->kv_tab, dc->arrive, dc->gu_raw, dc->rope_now};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;

@@ -76,6 +76,21 @@ __device__ __forceinline__ float wave_max(float v)
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// the same on the DPP path (lanes outside a row_bcast's rows keep their own value: old = v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+    v = quad_max(v);
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, dpp_keep<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_keep<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ int wave_sum_i(int v)
 {
 #pragma unroll
@@ -112,6 +127,31 @@ __device__ __forceinline__ float block_sum_tree(float v, float* scratch)
     return t[0];
 }
 
+// The same tree for a workgroup of NW waves known at compile time (NW = 4 or 8): no branch per wave slot, the
+// partials come back as 16-byte LDS reads, and -- with FRESH -- no barrier ahead of the scratch write (the caller
+// guarantees nobody is still reading `scratch`, e.g. its first use in the kernel).  Bit-identical to block_sum_tree.
+template <int NW, bool FRESH>
+__device__ __forceinline__ float block_sum_tree_n(float v, float* scratch)
+{
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (!FRESH) __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float t[16];
+    const float4 a = ((const float4*)scratch)[0];
+    t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w;
+    if (NW == 8) { const float4 b = ((const float4*)scratch)[1]; t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w; }
+#pragma unroll
+    for (int i = NW; i < 16; i++) t[i] = 0.f;
+#pragma unroll
+    for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2 * w) t[i] = t[i] + t[i + w];
+    return t[0];
+}
+
 // block-wide sum through LDS scratch (>= 16 floats); every thread gets the result
 __device__ __forceinline__ float block_sum(float v, float* scratch)
 {
@@ -133,6 +173,34 @@ __device__ __forceinline__ float block_max(float v, float* scratch)
     __syncthreads();
     float t = scratch[0];
     for (int i = 1; i < nw; i++) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+// block_max / block_sum for a workgroup of NW waves known at compile time, on a scratch area nobody else is using
+// (no barrier ahead of the write; give the two reductions of a kernel DIFFERENT scratch words).  Same values, and for
+// the sum the same wave order, as block_max / block_sum.
+template <int NW>
+__device__ __forceinline__ float block_max_n(float v, float* scratch)
+{
+    static_assert(NW == 4, "4 waves");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_max_dpp(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    const float4 a = *(const float4*)scratch;
+    return fmaxf(fmaxf(fmaxf(a.x, a.y), a.z), a.w);
+}
+template <int NW>
+__device__ __forceinline__ float block_sum_n(float v, float* scratch)
+{
+    static_assert(NW == 4, "4 waves");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    const float4 a = *(const float4*)scratch;
+    float t = 0.f;
+    t += a.x; t += a.y; t += a.z; t += a.w;
     return t;
 }
 
