@@ -117,11 +117,9 @@ struct Gemv8Args {
 
 // ---- prologue building blocks: a thread owns EPT (8 or 4) consecutive elements, so a
 // Q8 block is a group of 32/EPT (4 or 8) adjacent lanes and its absmax / sum are DPP steps.
-template <int EPT> __device__ __forceinline__ float grp_max(float v)
+template <int EPT> __device__ __forceinline__ float grp_max(float v)   // v >= 0 (an absolute maximum)
 {
-    v = quad_max(v);
-    if (EPT == 4) v = fmaxf(v, dpp_mov<0x141>(v));      // + row_half_mirror: 8 lanes
-    return v;
+    return (EPT == 4) ? nn_max8(v) : nn_max4(v);
 }
 template <int EPT> __device__ __forceinline__ int grp_sum_i(int v)
 {
@@ -236,20 +234,8 @@ template <int EPT> __device__ __forceinline__ float sumsq_treeN(const float (&v)
 }
 
 // max / integer sum over the 32 lanes of a half wave (lane = element of one Q8 block)
-__device__ __forceinline__ float max32(float v)
-{
-    v = quad_max(v);
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    v = fmaxf(v, dpp_mov<0x140>(v));
-    return fmaxf(v, __shfl_xor(v, 16, 64));
-}
-__device__ __forceinline__ int sum32_i(int v)
-{
-    v = quad_sum_i(v);
-    v += dpp_mov_i<0x141>(v);
-    v += dpp_mov_i<0x140>(v);
-    return v + __shfl_xor(v, 16, 64);
-}
+__device__ __forceinline__ float max32(float v) { return nn_max32(v); }      // v >= 0 (absolute values)
+__device__ __forceinline__ int sum32_i(int v) { return sum32_lanes_i(v); }
 // one value per lane, the half wave is one Q8 block: v <- q * fp16(delta)
 __device__ __forceinline__ float q8_round32(float v)
 {
@@ -995,7 +981,7 @@ __device__ __forceinline__ float head_prep_cs(float raw, bool act, bool do_rope,
     float v = act ? raw : 0.f;
     // Linear output written in the activation dtype
     if (adtype == GTEN_Q8) {
-        const Q8Scale sc = q8_scale_from_absmax(group_max<32>(fabsf(v)));
+        const Q8Scale sc = q8_scale_from_absmax(nn_max32(fabsf(v)));
         v = (float)q8_round(v, sc.scale) * sc.ddeq;
     } else {
         v = h2f(f2h(v));
@@ -1009,7 +995,7 @@ __device__ __forceinline__ float head_prep_cs(float raw, bool act, bool do_rope,
         if (!act) v = 0.f;
     }
     if (adtype == GTEN_Q8) {
-        const Q8Scale sc = q8_scale_from_absmax(group_max<32>(fabsf(v)));
+        const Q8Scale sc = q8_scale_from_absmax(nn_max32(fabsf(v)));
         const int qv = q8_round(v, sc.scale);
         if (act) {
             qi8[t] = (int8_t)qv;
@@ -1255,43 +1241,47 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
     }
     __syncthreads();
 
+    // every lane scores its cached row (the lane AT the new position holds unused bytes there); the chunk that
+    // contains the new position then scores the new k row from the chip -- uniform control flow, same arithmetic
     const float scale = 1.0f / sqrtf((float)dh);
-    float sc = -INFINITY;
-    if (c < n) {
-        float acc = 0.f;
+    float acc = 0.f;
+    if (ADT == GTEN_Q8) {
+        const int* qi = (const int*)qi8;
+        // slice bytes: [d0 | q0 x32 | d1 | q1 x32]; q0 straddles dwords by 2 bytes
+        int isum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) isum = dot4(qi[j], (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16), isum);
+        acc += (float)isum * (qd[0] * h2f((uint16_t)(kw[0] & 0xffffu)));
+        isum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) isum = dot4(qi[8 + j], (int)kw[9 + j], isum);
+        acc += (float)isum * (qd[1] * h2f((uint16_t)(kw[8] >> 16)));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            acc += qf[2 * j] * h2f((uint16_t)(kw[j] & 0xffffu));
+            acc += qf[2 * j + 1] * h2f((uint16_t)(kw[j] >> 16));
+        }
+    }
+    if (has_new) {
+        float accn = 0.f;
         if (ADT == GTEN_Q8) {
             const int* qi = (const int*)qi8;
-            if (c == pos) {
-                const int* ki = (const int*)ki8;
+            const int* ki = (const int*)ki8;
 #pragma unroll
-                for (int b = 0; b < nblk; b++) {
-                    int isum = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) isum = dot4(qi[b * 8 + j], ki[b * 8 + j], isum);
-                    acc += (float)isum * (qd[b] * kd[b]);
-                }
-            } else {
-                // slice bytes: [d0 | q0 x32 | d1 | q1 x32]; q0 straddles dwords by 2 bytes
+            for (int b = 0; b < nblk; b++) {
                 int isum = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) isum = dot4(qi[j], (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16), isum);
-                acc += (float)isum * (qd[0] * h2f((uint16_t)(kw[0] & 0xffffu)));
-                isum = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) isum = dot4(qi[8 + j], (int)kw[9 + j], isum);
-                acc += (float)isum * (qd[1] * h2f((uint16_t)(kw[8] >> 16)));
+                for (int j = 0; j < 8; j++) isum = dot4(qi[b * 8 + j], ki[b * 8 + j], isum);
+                accn += (float)isum * (qd[b] * kd[b]);
             }
         } else {
-            if (c == pos) {
-                for (int e = 0; e < dh; e++) acc += qf[e] * kf[e];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    acc += qf[2 * j] * h2f((uint16_t)(kw[j] & 0xffffu));
-                    acc += qf[2 * j + 1] * h2f((uint16_t)(kw[j] >> 16));
-                }
-            }
+            for (int e = 0; e < dh; e++) accn += qf[e] * kf[e];
         }
+        if (c == pos) acc = accn;
+    }
+    float sc = -INFINITY;
+    if (c < n) {
         sc = acc * scale;
         a.scores[(size_t)h * a.max_ctx + c] = sc;
     }
@@ -1637,14 +1627,12 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     // the chip idle at n <= 256)
     constexpr int dh = 64, nblk = 2, NW = 17;
     const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= a0.step[blockIdx.x].n) return;                  // (measured: ahead of the cache-pointer loads of attn_for_seq)
-    const AttnArgs a = attn_for_seq(a0, blockIdx.x);
-    const int n = a.step->n, pos = n - 1;
+    const AttnArgs a = attn_for_seq(a0, blockIdx.x);              // (the cache pointers and the position are requested together)
     const int kv_dim = a.n_kv * dh;
     const size_t head_bytes = (size_t)nblk * GTEN_Q8_BYTES;
 
-    float* red = (float*)g_smem;                                  // [4][GRP]
-    float* qd = red + 4 * GRP;                                    // [GRP][2] (+ pad to 4)
+    float* red = (float*)g_smem;                                  // [2][4][GRP]: maxima, then sums
+    float* qd = red + 8 * GRP;                                    // [GRP][2] (+ pad to 4)
     float* kd = qd + 4 * GRP;                                     // 8: new k deltas, new v deltas
     float* qf = kd + 8;                                           // scratch f32 row of head_prep (unused values)
     uint16_t* d16 = (uint16_t*)(qf + dh);                         // [GRP + 2][4] halves
@@ -1652,51 +1640,59 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     int8_t* ki8 = qi8 + GRP * dh;                                 // 64
     int8_t* vi8 = ki8 + dh;                                       // 64
 
-    // ---- request this thread's cached K row (rows past n re-read row c0; unused)
+    // ---- requests, none of which needs the context length: the raw projections this wave turns into head vectors
+    //      (wave w: query heads w, w + 4; wave 0 also the new k row, wave 1 the new v row), the rotation of the
+    //      current position (left by the step's first launch), then this thread's cached K row (rows past the
+    //      context are readable and unused; the row AT the new position is taken from the chip instead)
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    constexpr int NJ = (GRP + 3) / 4;
+    float qraw[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+    const float kvraw = a.qkv_raw[a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+    const float2 rot = a.rope_now[t & 31];
+    __builtin_amdgcn_sched_barrier(0);
     const int c = c0 + threadIdx.x;
-    const int cs = (c < n && c != pos) ? c : c0;
-    const unsigned* kp = (const unsigned*)(a.kcache + (size_t)cs * a.kv_pitch + (size_t)g * head_bytes);
+    const int cs = min(c, a.max_ctx - 1);
+    const gmem_u32 kp = as_global(a.kcache + (size_t)g * head_bytes) + (unsigned)cs * (unsigned)(a.kv_pitch >> 2);
     unsigned kw[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) kw[j] = kp[j];
     __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
 
-    // ---- head vectors: wave w prepares query heads w, w + 4; wave 0 also the new k row, wave 1 the new v row
+    // ---- head vectors
     const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
-    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
 #pragma unroll
-    for (int jj = 0; jj < (GRP + 3) / 4; jj++) {
+    for (int jj = 0; jj < NJ; jj++) {
         const int j = pw + 4 * jj;
-        if (j < GRP) (void)head_prep(a.qkv_raw[(g * GRP + j) * dh + t], true, true, pos, dh, GTEN_Q8, a.rope, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+        if (j < GRP) (void)head_prep_cs(qraw[jj], true, true, rot, dh, GTEN_Q8, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
     }
-    if (pw == 0 && has_new) {
-        (void)head_prep(a.qkv_raw[a.n_embd + g * dh + t], true, true, pos, dh, GTEN_Q8, a.rope, ki8, kd, d16 + 4 * GRP);
-        uint8_t* blk = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-        blk[2 + (t & 31)] = (uint8_t)ki8[t];
-        if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * GRP + (t >> 5)];
-    } else if (pw == 1 && has_new) {
-        (void)head_prep(a.qkv_raw[a.n_embd + kv_dim + g * dh + t], true, false, pos, dh, GTEN_Q8, a.rope, vi8, kd + 4, d16 + 4 * (GRP + 1));
-        uint8_t* blk = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-        blk[2 + (t & 31)] = (uint8_t)vi8[t];
-        if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * (GRP + 1) + (t >> 5)];
+    if (pw < 2 && has_new) {
+        int8_t* dq = pw ? vi8 : ki8;
+        (void)head_prep_cs(kvraw, true, pw == 0, rot, dh, GTEN_Q8, dq, kd + 4 * pw, d16 + 4 * (GRP + pw));
+        uint8_t* blk = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+        blk[2 + (t & 31)] = (uint8_t)dq[t];
+        if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * (GRP + pw) + (t >> 5)];
     }
     __syncthreads();
 
-    // ---- this position against every head of the group
+    // ---- this position against every head of the group: every lane scores its cached row (the lane AT the new
+    //      position holds unused bytes there); the chunk that contains the new position then scores the new k row
+    //      from the chip -- uniform control flow, same arithmetic
     const float scale = 1.0f / sqrtf((float)dh);
-    const float kd0 = (c == pos) ? kd[0] : h2f((uint16_t)(kw[0] & 0xffffu));
-    const float kd1 = (c == pos) ? kd[1] : h2f((uint16_t)(kw[8] >> 16));
-    int kq[16];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        kq[j] = (c == pos) ? ((const int*)ki8)[j] : (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16);
-        kq[8 + j] = (c == pos) ? ((const int*)ki8)[8 + j] : (int)kw[9 + j];
-    }
     float sc[GRP];
+    {
+        const float kd0 = h2f((uint16_t)(kw[0] & 0xffffu)), kd1 = h2f((uint16_t)(kw[8] >> 16));
+        int kq[16];
 #pragma unroll
-    for (int j = 0; j < GRP; j++) {
-        sc[j] = -INFINITY;
-        if (c < n) {
+        for (int j = 0; j < 8; j++) {
+            kq[j] = (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16);
+            kq[8 + j] = (int)kw[9 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
             const int* qi = (const int*)(qi8 + j * dh);
             float acc = 0.f;
             int isum = 0;
@@ -1708,8 +1704,29 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
             for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], kq[8 + k], isum);
             acc += (float)isum * (qd[2 * j + 1] * kd1);
             sc[j] = acc * scale;
-            a.scores[(size_t)(g * GRP + j) * a.max_ctx + c] = sc[j];
         }
+    }
+    if (has_new) {
+        const int* ki = (const int*)ki8;
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int* qi = (const int*)(qi8 + j * dh);
+            float acc = 0.f;
+            int isum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum = dot4(qi[k], ki[k], isum);
+            acc += (float)isum * (qd[2 * j] * kd[0]);
+            isum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], ki[8 + k], isum);
+            acc += (float)isum * (qd[2 * j + 1] * kd[1]);
+            if (c == pos) sc[j] = acc * scale;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        if (c < n) a.scores[(size_t)(g * GRP + j) * a.max_ctx + c] = sc[j];
+        else sc[j] = -INFINITY;
     }
     // ---- chunk maximum and sum of exponentials per head (block_max / block_sum, all heads per barrier pair)
     float mx[GRP];
@@ -1725,19 +1742,19 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
         for (int w = 1; w < 4; w++) m = fmaxf(m, red[w * GRP + j]);
         mx[j] = m;
     }
-    __syncthreads();
+    float* reds = red + 4 * GRP;                                  // the sums take their own words: no barrier between the two
 #pragma unroll
     for (int j = 0; j < GRP; j++) {
         const float ex = (c < n) ? expf(sc[j] - mx[j]) : 0.f;
         const float sw = wave_sum(ex);
-        if (t == 0) red[pw * GRP + j] = sw;
+        if (t == 0) reds[pw * GRP + j] = sw;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < GRP; j++) {
             float sm = 0.f;
-            for (int w = 0; w < 4; w++) sm += red[w * GRP + j];
+            for (int w = 0; w < 4; w++) sm += reds[w * GRP + j];
             a.stats[((size_t)(g * GRP + j) * a.n_chunks + chunk) * 2 + 0] = mx[j];
             a.stats[((size_t)(g * GRP + j) * a.n_chunks + chunk) * 2 + 1] = sm;
         }
@@ -1749,41 +1766,68 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 {
     constexpr int dh = 64, NW = 17;
     const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= a0.step[blockIdx.x].n) return;
     const AttnArgs a = attn_for_seq(a0, blockIdx.x);
-    const int n = a.step->n;
     const size_t head_bytes = (size_t)2 * GTEN_Q8_BYTES;
-    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-    const int len = min(DEC_CHUNK, n - c0);
 
     float* p = (float*)g_smem;                                    // [GRP][4][64]: position c at [c & 3][c >> 2]
     float* part = p + GRP * DEC_CHUNK;                            // [GRP][256]
     unsigned* vl = (unsigned*)(part + GRP * DEC_CHUNK);           // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
     float* ms = (float*)(vl + DEC_CHUNK * NW);                    // [GRP][2]: the row maximum and sum of each head
+    float* tl = ms + 16;                                          // [GRP][8]: the heads' chunk terms l_j exp(m_j - M) (16-byte aligned)
 
-    // ---- request the whole V chunk: dword idx -> (row idx / NW, word idx % NW)
-    unsigned vw[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const int idx = threadIdx.x + k * 256;
-        int row = idx / NW;
-        const int w = idx - row * NW;
-        if (row >= len) row = 0;
-        vw[k] = ((const unsigned*)(a.vcache + (size_t)(c0 + row) * a.kv_pitch + (size_t)g * head_bytes))[w];
-    }
+    // ---- requests, none of which needs the context length: the chunk statistics (lane 8 j + q of wave 0: head j,
+    //      chunk q; the stats array has DEC_ATT_MAXCH chunks of slack), this position's score under every head, then
+    //      the whole V chunk: dword idx -> (row idx / NW, word idx % NW), rows past the context readable and unused
     const int c = c0 + threadIdx.x;
+    const int sj = min((int)threadIdx.x >> 3, GRP - 1), sq = threadIdx.x & 7;
+    const float2 st = ((const float2*)a.stats)[(size_t)(g * GRP + sj) * a.n_chunks + sq];
     float scv[GRP];
 #pragma unroll
-    for (int j = 0; j < GRP; j++) scv[j] = (c < n) ? a.scores[(size_t)(g * GRP + j) * a.max_ctx + c] : 0.f;
+    for (int j = 0; j < GRP; j++) scv[j] = a.scores[(size_t)(g * GRP + j) * a.max_ctx + min(c, a.max_ctx - 1)];
     __builtin_amdgcn_sched_barrier(0);
+    unsigned vw[NW];
+    {
+        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        const gmem_u32 vbase = as_global(a.vcache + (size_t)g * head_bytes);
+        const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
+        const int last = a.max_ctx - 1 - c0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            vw[k] = vbase[(unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w];
+            row += 256 / NW; w += 256 % NW;
+            if (w >= NW) { w -= NW; row++; }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n;
+    if (c0 >= n) return;
+    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+    const int len = min(DEC_CHUNK, n - c0);
 
-    // ---- row maximum and sum of every head from the chunk statistics: once per workgroup (thread j = head j)
-    if (threadIdx.x < GRP) {
-        const float* st = a.stats + (size_t)(g * GRP + threadIdx.x) * a.n_chunks * 2;
+    // ---- row maximum and sum of every head from the chunk statistics, once per workgroup: the exponentials of all
+    //      (head, chunk) pairs at once in wave 0, each head's terms then added in chunk order by one lane -- the
+    //      values and the order of the sequential loop (x + 0 == x)
+    if (nch <= DEC_ATT_MAXCH) {
+        if (threadIdx.x < 64) {
+            float m = (sq < nch) ? st.x : -INFINITY;
+            m = quad_max(m);
+            const float M = fmaxf(m, dpp_mov<0x141>(m));
+            if (threadIdx.x < 8 * GRP) tl[threadIdx.x] = (sq < nch) ? st.y * expf(st.x - M) : 0.f;
+            const float Mj = __shfl(M, (threadIdx.x & 7) * 8, 64);   // all 64 lanes take part: a shuffle reads live lanes only
+            if (threadIdx.x < GRP) {
+                // (same wave: the LDS writes above are ordered before these reads)
+                const float4 t0 = *(const float4*)(tl + threadIdx.x * 8), t1 = *(const float4*)(tl + threadIdx.x * 8 + 4);
+                float S = 0.f;
+                S += t0.x; S += t0.y; S += t0.z; S += t0.w; S += t1.x; S += t1.y; S += t1.z; S += t1.w;
+                ms[threadIdx.x * 2] = Mj; ms[threadIdx.x * 2 + 1] = S;
+            }
+        }
+    } else if (threadIdx.x < GRP) {
+        const float* stp = a.stats + (size_t)(g * GRP + threadIdx.x) * a.n_chunks * 2;
         float M = -INFINITY;
-        for (int q = 0; q < nch; q++) M = fmaxf(M, st[q * 2]);
+        for (int q = 0; q < nch; q++) M = fmaxf(M, stp[q * 2]);
         float S = 0.f;
-        for (int q = 0; q < nch; q++) S += st[q * 2 + 1] * expf(st[q * 2] - M);
+        for (int q = 0; q < nch; q++) S += stp[q * 2 + 1] * expf(stp[q * 2] - M);
         ms[threadIdx.x * 2] = M; ms[threadIdx.x * 2 + 1] = S;
     }
     __syncthreads();
@@ -1928,8 +1972,8 @@ template <int GRP>
 static int launch_attention_g(const AttnArgs& t, int n_seq)
 {
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
-    const size_t smem1 = (size_t)(4 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
-    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4 + (size_t)2 * GRP * 4;
+    const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
+    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4 + (size_t)(16 + 8 * GRP) * 4;
     DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP>), grid, dim3(256), smem1, t);
     DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP>), grid, dim3(256), smem2, t);
     return 0;

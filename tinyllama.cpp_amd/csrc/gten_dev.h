@@ -57,6 +57,44 @@ __device__ __forceinline__ int quad_sum_i(int v)
     return v + dpp_mov_i<0x4E>(v);
 }
 
+// ---- maxima of NON-NEGATIVE floats (absolute values, the Q8 absmax): IEEE order is the integer order of the bit
+// patterns, so each step is one v_max_i32_dpp instead of mov_dpp + canonicalize + max; rows 16 lanes apart are
+// combined by gfx950's v_permlane16_swap instead of a trip through the LDS crossbar.  Exact (a maximum has no order).
+template <int CTRL>
+__device__ __forceinline__ int nn_max_step(int i)
+{
+    return max(i, __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float nn_max4(float v)              // the 4 lanes of a quad
+{
+    int i = __float_as_int(v);
+    i = nn_max_step<0xB1>(i);
+    i = nn_max_step<0x4E>(i);
+    return __int_as_float(i);
+}
+__device__ __forceinline__ float nn_max8(float v)              // aligned groups of 8 lanes
+{
+    int i = __float_as_int(nn_max4(v));
+    i = nn_max_step<0x141>(i);
+    return __int_as_float(i);
+}
+__device__ __forceinline__ float nn_max32(float v)             // the two 32-lane halves of the wave
+{
+    int i = __float_as_int(nn_max8(v));
+    i = nn_max_step<0x140>(i);
+    const auto r = __builtin_amdgcn_permlane16_swap(i, i, false, false);   // rows {0,0,2,2} | {1,1,3,3}
+    return __int_as_float(max((int)r[0], (int)r[1]));
+}
+__device__ __forceinline__ int sum32_lanes_i(int v)            // integer sum over each 32-lane half
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (int)r[0] + (int)r[1];
+}
+
 // ---- wavefront reductions (all 64 lanes end with the same value) ----
 // Sum of the 64 lanes in a fixed tree: quads, 8, 16 (DPP mirrors), then the
 // four 16-lane rows chained through row_bcast15/31; the total lands in lane 63.
