@@ -1965,7 +1965,9 @@ static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
     const int grp = t.n_heads / t.n_kv;
     const char* e = std::getenv("GTEN_HIP_ATTN_PER_HEAD");      // =1: the per-head kernels (comparison / tests)
     const bool off = e && e[0] == '1';
-    return !off && n_seq >= 16 && t.adtype == GTEN_Q8 && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
+    const char* m = std::getenv("GTEN_HIP_ATTN_GROUPED_MIN");   // fewest sequences that take the grouped kernels
+    const int min_seq = (m && atoi(m) > 1) ? atoi(m) : 8;        // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
+    return !off && n_seq >= min_seq && t.adtype == GTEN_Q8 && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
 }
 
 template <int GRP>
@@ -2189,7 +2191,7 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         t.part_stride = d.n_heads * dc->n_chunks * dh;
         const dim3 agrid(d.n_heads, dc->n_chunks, S);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        if ((rc = launch_attention(t, agrid, smem1))) return rc;
+        if ((rc = attention_grouped_ok(t, S) ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
         // attention rows -> stage -> o projection
         Gemv8Args sa = base;
         sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
