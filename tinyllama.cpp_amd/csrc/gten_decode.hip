@@ -301,8 +301,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         else { const uint2 t = *(const uint2*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; }
     }
     // PRO_ATT: all chunk partials of this thread's elements, requested at once (chunks past the context hold
-    // stale but readable data and are dropped by a select below); contexts of more than DEC_ATT_MAXCH chunks
-    // take the sequential loop for the rest
+    // stale but readable data and are dropped by a select below; decoder_create: n_chunks <= DEC_ATT_MAXCH)
     float apart[PRO == PRO_ATT ? DEC_ATT_MAXCH : 1][EPT];
     if (PRO == PRO_ATT) {
         const int h = sbase >> a.d_head_shift, e = sbase & (a.d_head - 1);
@@ -416,12 +415,6 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
             for (int j = 0; j < DEC_ATT_MAXCH; j++)
 #pragma unroll
                 for (int i = 0; i < EPT; i++) v[i] += (j < nch) ? apart[j][i] : 0.f;     // v + 0 == v: same sum as the loop
-            for (int j = DEC_ATT_MAXCH; j < nch; j++) {
-                float t[EPT];
-                ldN<EPT>(att_part + ((size_t)h * a.n_chunks + j) * a.d_head + e, t);
-#pragma unroll
-                for (int i = 0; i < EPT; i++) v[i] += t[i];
-            }
         }
         if (PRO == PRO_EMBED || PRO == PRO_RESID) {
             if (on) {
@@ -1353,15 +1346,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a0)
     const int len = min(DEC_CHUNK, n - c0);
 
     float M, S;
-    if (nch <= DEC_ATT_MAXCH) {
-        softmax_stats8(st, nch, M, S);
-    } else {
-        M = -INFINITY;
-        for (int j = 0; j < nch; j++) M = fmaxf(M, a.stats[((size_t)h * a.n_chunks + j) * 2]);
-        S = 0.f;
-        for (int j = 0; j < nch; j++)
-            S += a.stats[((size_t)h * a.n_chunks + j) * 2 + 1] * expf(a.stats[((size_t)h * a.n_chunks + j) * 2] - M);
-    }
+    softmax_stats8(st, nch, M, S);                // decoder_create: n_chunks <= DEC_ATT_MAXCH
 
     // probabilities, rounded to the activation dtype in registers (a Q8 block = 32 consecutive lanes; the partial
     // tail block takes its absmax over the live positions, zeros beyond: round_row_inplace's rule)
@@ -1807,7 +1792,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     // ---- row maximum and sum of every head from the chunk statistics, once per workgroup: the exponentials of all
     //      (head, chunk) pairs at once in wave 0, each head's terms then added in chunk order by one lane -- the
     //      values and the order of the sequential loop (x + 0 == x)
-    if (nch <= DEC_ATT_MAXCH) {
+    {
         if (threadIdx.x < 64) {
             float m = (sq < nch) ? st.x : -INFINITY;
             m = quad_max(m);
@@ -1822,13 +1807,6 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
                 ms[threadIdx.x * 2] = Mj; ms[threadIdx.x * 2 + 1] = S;
             }
         }
-    } else if (threadIdx.x < GRP) {
-        const float* stp = a.stats + (size_t)(g * GRP + threadIdx.x) * a.n_chunks * 2;
-        float M = -INFINITY;
-        for (int q = 0; q < nch; q++) M = fmaxf(M, stp[q * 2]);
-        float S = 0.f;
-        for (int q = 0; q < nch; q++) S += stp[q * 2 + 1] * expf(stp[q * 2] - M);
-        ms[threadIdx.x * 2] = M; ms[threadIdx.x * 2 + 1] = S;
     }
     __syncthreads();
     // ---- probabilities of every head of the group, rounded to the activation dtype along the context (the Q8
@@ -2432,6 +2410,7 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     dc->n_seq = n_seq;
     dc->layers.assign(layers, layers + d.n_layers);
     dc->n_chunks = (d.max_ctx + DEC_CHUNK - 1) / DEC_CHUNK;
+    static_assert(GTEN_ROPE_MAX_POS <= DEC_ATT_MAXCH * DEC_CHUNK, "max_ctx (checked above) bounds the attention chunks the consumers request up front");
     const int E = d.n_embd, F = d.n_ffn, KV = dh * d.n_kv_heads;
     const size_t S = (size_t)n_seq;
     GTR_CHECK(hipMalloc((void**)&dc->step, S * sizeof(DecStep)));
