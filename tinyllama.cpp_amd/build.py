@@ -24,7 +24,11 @@ HOST_LIB = os.path.join(HOST, "libgten_host.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the reference rounds every multiply and add separately
 # (gten/simd_ops.h:59-61); fused multiply-adds would move results off its grid.
+# -amdgpu-kernarg-preload-count: the command processor loads the leading scalar kernel arguments into SGPRs while
+# the waves are created, so a kernel can form its first addresses without a scalar-load round trip (measured:
+# -0.3 us per dependent launch, tools/microbench_launch_floor.hip; 14 dwords fit beside the segment pointer).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+             "-mllvm", "-amdgpu-kernarg-preload-count=16",
              "-Wall", "-Wno-unused-function", "-I" + INCLUDE]
 CXX_FLAGS = ["-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I" + INCLUDE, "-I" + PKG]
 

@@ -42,6 +42,10 @@ static int g_only_family = -1;
         if (g_only_family < 0 || g_only_family == (tag)) GTR_LAUNCH(tag, kernel, grid, block, smem, __VA_ARGS__); \
     } while (0)
 
+// a launch whose kernel takes seven preloadable 64-bit words ahead of its argument struct (hot arguments, below)
+#define DEC_LAUNCH_HOT(tag, kernel, grid, block, smem, hw, a) \
+    DEC_LAUNCH(tag, kernel, grid, block, smem, (hw).w[0], (hw).w[1], (hw).w[2], (hw).w[3], (hw).w[4], (hw).w[5], (hw).w[6], a)
+
 struct DecStep {
     int n;                        // context length of this step; the new row is n-1
     int advance;                  // argmax kernel bumps n afterwards (free-running replay)
@@ -80,6 +84,21 @@ enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2, EPI_STAGE_FRAG = 3 };
 //   * the prologue keeps 8 consecutive elements per thread in registers, so a
 //     Q8 block is one quad of lanes and its absmax / sum are two DPP steps;
 //   * the residual rows between kernels are kept as f32 (exact storage values).
+
+// a device pointer that travelled as a 64-bit kernel argument (hot arguments, below): rebuilt through the global
+// address space -- a pointer made from an integer would otherwise be a generic one and every access a FLAT access
+template <typename T>
+__device__ __forceinline__ const T* from_word(unsigned long long w)
+{
+    return (const T*)(const __attribute__((address_space(1))) T*)w;
+}
+// stores through a pointer hipcc only knows as generic (cache rows): global, not FLAT (a FLAT store also counts on
+// the LDS counter, so the next barrier would wait for its round trip)
+template <typename T>
+__device__ __forceinline__ void store_global(void* p, T v)
+{
+    *(__attribute__((address_space(1))) T*)(uintptr_t)p = v;
+}
 
 struct Gemv8Args {
     const DecStep* step;
@@ -254,28 +273,61 @@ __device__ __forceinline__ float act_round32(float v, bool f16)
 // EPI_SILUMUL: 8 waves, block = one 32-wide slice of the FFN: waves 0-3 its gate rows, waves 4-7
 //              its up rows (R = 8); the slice's silu(gate)*up chain runs ONCE here, in the
 //              epilogue, and is stored quantized for the down projection (PRO_ACTQ8)
+// HOT ARGUMENTS.  A kernel reads its arguments with scalar loads before it can form a single address: one more
+// memory round trip at the head of every launch of the chain (~0.3 us each, tools/microbench_launch_floor.hip built
+// with and without preloading).  gfx950's command processor can PRELOAD the first 14 dwords of the argument segment
+// into SGPRs while the waves are being created (-mllvm -amdgpu-kernarg-preload-count, build.py) -- but only leading
+// scalar arguments, never a by-value struct.  So the launch passes the few words the first requests are formed from
+// as seven leading 64-bit scalars (GemvHot), ahead of the full struct; what a prologue kind does not need carries
+// its small integers instead.
+struct GemvHot {
+    const void* p0;               // PRO_RESID res_raw | PRO_EMBED table | PRO_ATT att_part | PRO_ACTQ8 act_q (f16: act_f)
+    const void* p1;               // PRO_RESID res_a   | PRO_EMBED tokens | PRO_ATT {d_head_shift, n_chunks} | PRO_ACTQ8 act_d
+    const void* p2;               // PRO_RESID / PRO_EMBED norm_w | PRO_ACTQ8 act_sum
+    const uint8_t* qs0; const uint16_t* ds0;
+    int d_in, rows0;
+    const DecStep* step;
+};
+static_assert(sizeof(GemvHot) == 56, "seven 64-bit scalars: the preloadable part of the argument segment");
+union GemvHotWords {
+    unsigned long long w[7];
+    GemvHot h;
+    __host__ __device__ GemvHotWords() : w{0, 0, 0, 0, 0, 0, 0} {}
+};
+
 template <int WT, int PRO, int NCH, int R, int EPI, int NT>
-__global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
+__global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, const unsigned long long h1, const unsigned long long h2,
+                                                  const unsigned long long h3, const unsigned long long h4, const unsigned long long h5,
+                                                  const unsigned long long h6, const Gemv8Args a)
 {
+    // (rebuilt word by word, through the global address space: a pointer made from an integer would otherwise be
+    // a generic one and every load through it a FLAT load)
+    GemvHot hot;
+    hot.p0 = from_word<void>(h0); hot.p1 = from_word<void>(h1); hot.p2 = from_word<void>(h2);
+    hot.qs0 = from_word<uint8_t>(h3); hot.ds0 = from_word<uint16_t>(h4);
+    hot.d_in = (int)(unsigned)(h5 & 0xffffffffull); hot.rows0 = (int)(unsigned)(h5 >> 32);
+    hot.step = from_word<DecStep>(h6);
     constexpr int EPT = 2048 / NT;                // prologue elements per thread (d <= 2048 unless PRO_ACTQ8)
     constexpr int LPB = 32 / EPT;                 // lanes per Q8 block
     constexpr int NW = NT / 64;
     static_assert(NT == 256 || NT == 512, "256 or 512 threads");
     static_assert(EPI != EPI_SILUMUL || NT == 512, "the FFN slice epilogue wants 8 waves");
     constexpr bool F16W = (WT == GTEN_F16);        // f16 weights <=> f16 activations (tinyllama.cpp:258-265)
-    const int d = a.d_in, nb = d >> 5;
+    const int d = hot.d_in, nb = d >> 5;
     ActStage s = carve_stage((PRO == PRO_ACTQ8 && !F16W) ? 32 : d);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // EPI_STAGE: one workgroup per SEQUENCE runs only the prologue and leaves the staged vector in
     // HBM for the multi-sequence W.x kernel (k_dec_gemvm), which then needs no prologue of its own
     constexpr bool STG = (EPI == EPI_STAGE || EPI == EPI_STAGE_FRAG);
     const int seq = STG ? blockIdx.x : 0;
-    const int n = a.step[seq].n;
-    const float* res_raw = a.res_raw + (size_t)seq * a.raw_stride;
-    const float* res_a = a.res_a + (size_t)seq * d;
+    const int n = hot.step[seq].n;
+    const float* res_raw = (const float*)hot.p0 + (size_t)seq * a.raw_stride;     // PRO_RESID only
+    const float* res_a = (const float*)hot.p1 + (size_t)seq * d;
     float* x_out = a.x_out ? a.x_out + (size_t)seq * d : nullptr;
-    const int32_t* tokens = a.tokens + (size_t)seq * a.tok_stride;
-    const float* att_part = a.att_part + (size_t)seq * a.part_stride;
+    const int32_t* tokens = (const int32_t*)hot.p1 + (size_t)seq * a.tok_stride;        // PRO_EMBED only
+    const float* att_part = (const float*)hot.p0 + (size_t)seq * a.part_stride;      // PRO_ATT only
+    const uint16_t* norm_w = (const uint16_t*)hot.p2;
+    const int att_shift = (int)((uintptr_t)hot.p1 & 0xff), att_chunks = (int)(((uintptr_t)hot.p1 >> 8) & 0xffff), att_dh = 1 << att_shift;
     if (STG) {
         s.q8.q = a.act_q + (size_t)seq * d;
         s.q8.d = a.act_d + (size_t)seq * nb;
@@ -283,7 +335,6 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         if (F16W) s.row = a.act_f + (size_t)seq * d;
     }
     const bool stores_x = STG || blockIdx.x == 0;
-    if (a.zero_words && blockIdx.x == 0 && (int)threadIdx.x < a.zero_count) a.zero_words[threadIdx.x] = 0u;
     const int gi = threadIdx.x, base = gi * EPT, blk = gi / LPB, sub = gi % LPB;
     const bool on = base < d;                     // lanes past the row re-read group 0 (never used):
     const int sbase = on ? base : 0;              // an unconditional load has no select on its result
@@ -297,22 +348,22 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     // makes hipcc wait for every outstanding load BEFORE the weight rows below are even requested)
     unsigned nw[4] = {0, 0, 0, 0};
     if (PRO == PRO_EMBED || PRO == PRO_RESID) {
-        if (EPT == 8) { const uint4 t = *(const uint4*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; nw[2] = t.z; nw[3] = t.w; }
-        else { const uint2 t = *(const uint2*)(a.norm_w + sbase); nw[0] = t.x; nw[1] = t.y; }
+        if (EPT == 8) { const uint4 t = *(const uint4*)(norm_w + sbase); nw[0] = t.x; nw[1] = t.y; nw[2] = t.z; nw[3] = t.w; }
+        else { const uint2 t = *(const uint2*)(norm_w + sbase); nw[0] = t.x; nw[1] = t.y; }
     }
     // PRO_ATT: all chunk partials of this thread's elements, requested at once (chunks past the context hold
     // stale but readable data and are dropped by a select below; decoder_create: n_chunks <= DEC_ATT_MAXCH)
     float apart[PRO == PRO_ATT ? DEC_ATT_MAXCH : 1][EPT];
     if (PRO == PRO_ATT) {
-        const int h = sbase >> a.d_head_shift, e = sbase & (a.d_head - 1);
+        const int h = sbase >> att_shift, e = sbase & (att_dh - 1);
 #pragma unroll
         for (int j = 0; j < DEC_ATT_MAXCH; j++)
-            ldN<EPT>(att_part + ((size_t)h * a.n_chunks + min(j, a.n_chunks - 1)) * a.d_head + e, apart[j]);
+            ldN<EPT>(att_part + ((size_t)h * att_chunks + min(j, att_chunks - 1)) * att_dh + e, apart[j]);
     }
     unsigned emb[4] = {0, 0, 0, 0};
     float emb_delta = 0.f;
     if (PRO == PRO_EMBED && F16W) {
-        const uint16_t* src = (const uint16_t*)a.table + (size_t)tokens[n - 1] * d + sbase;
+        const uint16_t* src = (const uint16_t*)hot.p0 + (size_t)tokens[n - 1] * d + sbase;
         if (EPT == 8) { const uint4 t = *(const uint4*)src; emb[0] = t.x; emb[1] = t.y; emb[2] = t.z; emb[3] = t.w; }
         else { const uint2 t = *(const uint2*)src; emb[0] = t.x; emb[1] = t.y; }
     }
@@ -326,11 +377,11 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         const uint8_t* src;
         const uint16_t* dsp;
         if (WT == GTEN_Q4) {
-            src = (const uint8_t*)a.table + ((size_t)tok * nb + sb) * 16 + byte0;
-            dsp = (const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 16);
+            src = (const uint8_t*)hot.p0 + ((size_t)tok * nb + sb) * 16 + byte0;
+            dsp = (const uint16_t*)((const uint8_t*)hot.p0 + (size_t)a.n_vocab * nb * 16);
         } else {
-            src = (const uint8_t*)a.table + (size_t)tok * nb * 32 + (size_t)((ssub * EPT) >> 4) * nb * 16 + (size_t)sb * 16 + byte0;
-            dsp = (const uint16_t*)((const uint8_t*)a.table + (size_t)a.n_vocab * nb * 32);
+            src = (const uint8_t*)hot.p0 + (size_t)tok * nb * 32 + (size_t)((ssub * EPT) >> 4) * nb * 16 + (size_t)sb * 16 + byte0;
+            dsp = (const uint16_t*)((const uint8_t*)hot.p0 + (size_t)a.n_vocab * nb * 32);
         }
         emb[0] = *(const unsigned*)src;
         if (EPT == 8) emb[1] = *(const unsigned*)(src + 4);
@@ -338,7 +389,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
     }
 
     // ---- 2. request this wave's weight rows; they stay in flight during the prologue
-    const int rows0 = a.rows[0], rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
+    const int rows0 = hot.rows0, rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
     const int total = rows0 + rows1 + rows2;
     const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
                                         : (blockIdx.x * NW + wid) * R;
@@ -349,8 +400,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         if (STG) break;                           // no W.x in a staging launch
         int lr = r0 + j;
         const bool ok = lr < total;
-        const uint8_t* qbase = a.qs[0];
-        const uint16_t* dbase = a.ds[0];
+        const uint8_t* qbase = hot.qs0;
+        const uint16_t* dbase = hot.ds0;
         if (lr >= rows0 && rows1 > 0) {
             lr -= rows0; qbase = a.qs[1]; dbase = a.ds[1];
             if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; }
@@ -381,6 +432,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         }
     }
     __builtin_amdgcn_sched_barrier(0);            // keep every request above ahead of the prologue's arithmetic
+    if (a.zero_words && blockIdx.x == 0 && (int)threadIdx.x < a.zero_count) a.zero_words[threadIdx.x] = 0u;
 
     // ---- 3. prologue: the element-wise chain of the reference, on chip
     //         (PRO_ACTQ8: nothing to do, the input was staged in HBM by the producer's epilogue)
@@ -408,7 +460,6 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
             act_roundN<WT, EPT>(v);                       // Residual output written in the activation dtype
         } else {                                          // PRO_ATT: sum of the per-chunk partials, fixed order
             const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-            const int h = sbase >> a.d_head_shift, e = sbase & (a.d_head - 1);
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = 0.f;
 #pragma unroll
@@ -440,7 +491,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         __syncthreads();
     } else if (F16W) {
         // the FFN activation row was stored by the gate/up epilogue: bring it on chip
-        for (int i = threadIdx.x * 4; i < d; i += NT * 4) *(float4*)(s.row + i) = *(const float4*)(a.act_f + i);
+        for (int i = threadIdx.x * 4; i < d; i += NT * 4) *(float4*)(s.row + i) = *(const float4*)((const float*)hot.p0 + i);
         __syncthreads();
     }
 
@@ -456,13 +507,13 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const Gemv8Args a)
         const int b = c * 64 + lane;
         const bool in = b < nb;
         const int bs = in ? b : 0;
-        const int8_t* qsrc = (PRO == PRO_ACTQ8) ? a.act_q : s.q8.q;
+        const int8_t* qsrc = (PRO == PRO_ACTQ8) ? (const int8_t*)hot.p0 : s.q8.q;
         const int4* ap = (const int4*)(qsrc + (size_t)bs * 32);
         const int4 a0 = ap[0], a1 = ap[1];
         av[c][0] = a0.x; av[c][1] = a0.y; av[c][2] = a0.z; av[c][3] = a0.w;
         av[c][4] = a1.x; av[c][5] = a1.y; av[c][6] = a1.z; av[c][7] = a1.w;
-        const float dd = (PRO == PRO_ACTQ8) ? a.act_d[bs] : s.q8.d[bs];
-        const int sm = (PRO == PRO_ACTQ8) ? a.act_sum[bs] : s.q8.sum[bs];
+        const float dd = (PRO == PRO_ACTQ8) ? ((const float*)hot.p1)[bs] : s.q8.d[bs];
+        const int sm = (PRO == PRO_ACTQ8) ? ((const int*)hot.p2)[bs] : s.q8.sum[bs];
         ad[c] = in ? dd : 0.f;
         asum[c] = in ? sm : 0;
     }
@@ -932,6 +983,7 @@ struct AttnArgs {
     const float2* rope_now;       // [seq][d_head / 2]: the rotation of each sequence's CURRENT position, left by the step's first
                                   // launch (PRO_EMBED) so that the score kernels can request it without knowing the position
     int adtype, n_heads, n_kv, d_head, max_ctx, n_chunks, n_embd;
+    int grp_shift1;               // log2(n_heads / n_kv) + 1 when that ratio is a power of two, else 0 (set by the launchers)
     // multi-sequence decode: blockIdx.z = sequence; its caches come from a device table
     // [seq][layer][k|v], its scratch rows lie `*_stride` elements apart
     const void* const* kv_tab; int layer, n_layers;
@@ -1171,14 +1223,29 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv(const AttnArgs a)
 // bytes in f16, always 4-byte aligned), so a pass costs one memory latency
 // instead of one per cached row.
 
-template <int ADT>
-__global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
+// Hot arguments of the two single-sequence attention launches (see GemvHot): seven preloadable 64-bit words.
+//   score: qkv_raw | rope_now | kcache | step | kv_pitch, max_ctx | n_embd, n_heads + (n_kv << 16) | scores
+//   p.V:   scores  | stats    | vcache | step | kv_pitch, max_ctx | n_chunks, n_heads + (n_kv << 16) | att_part
+// MULTI launches (blockIdx.z = sequence) take everything from the struct through attn_for_seq.
+struct AttnHotWords { unsigned long long w[7]; };
+
+template <int ADT, bool MULTI>
+__global__ __launch_bounds__(256) void k_dec_attn_score64(const unsigned long long h0, const unsigned long long h1, const unsigned long long h2,
+                                                         const unsigned long long h3, const unsigned long long h4, const unsigned long long h5,
+                                                         const unsigned long long h6, const AttnArgs a0)
 {
-    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
+    AttnArgs a = MULTI ? attn_for_seq(a0, blockIdx.z) : a0;
+    if (!MULTI) {
+        a.qkv_raw = from_word<float>(h0); a.rope_now = from_word<float2>(h1); a.kcache = (uint8_t*)from_word<uint8_t>(h2);
+        a.step = from_word<DecStep>(h3); a.kv_pitch = (size_t)(unsigned)(h4 & 0xffffffffull); a.max_ctx = (int)(h4 >> 32);
+        a.n_embd = (int)(unsigned)(h5 & 0xffffffffull); a.n_heads = (int)((h5 >> 32) & 0xffu); a.n_kv = (int)((h5 >> 40) & 0xffu); a.grp_shift1 = (int)(h5 >> 48);
+        a.scores = (float*)from_word<float>(h6);
+    }
     constexpr int dh = 64, nblk = 2;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
     const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    const int grp = a.n_heads / a.n_kv, g = h / grp;
+    // (heads per kv head: a shift when it is a power of two -- two integer divisions ahead of the first request otherwise)
+    const int grp = a.grp_shift1 ? (1 << (a.grp_shift1 - 1)) : a.n_heads / a.n_kv, g = a.grp_shift1 ? (h >> (a.grp_shift1 - 1)) : h / grp;
     const int kv_dim = a.n_kv * dh;
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
 
@@ -1212,7 +1279,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
     if (c0 >= n) return;
 
     const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
-    const bool writer = has_new && (h % grp == 0);
+    const bool writer = has_new && (h == g * grp);
     // the three new head vectors are independent: one wave each (0: q | 1: new k row | 2: new v row), one copy of
     // the code (the k / v waves also run where their row is not needed: it only lands in this workgroup's scratch)
     if (pw < 3) {
@@ -1225,10 +1292,10 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const AttnArgs a0)
             uint8_t* row = ((pw == 1) ? a.kcache : a.vcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
             if (ADT == GTEN_Q8) {
                 uint8_t* blk = row + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-                blk[2 + (t & 31)] = (uint8_t)dq[t];
-                if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * pw + (t >> 5)];
+                store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
+                if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * pw + (t >> 5)]);
             } else {
-                ((uint16_t*)row)[t] = f2h(v);
+                store_global<uint16_t>((uint16_t*)row + t, f2h(v));
             }
         }
     }
@@ -1303,14 +1370,23 @@ __device__ __forceinline__ void softmax_stats8(const float2 st, int nch, float& 
     for (int q = 0; q < DEC_ATT_MAXCH; q++) S += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), q));
 }
 
-template <int ADT>
-__global__ __launch_bounds__(256) void k_dec_attn_pv64(const AttnArgs a0)
+template <int ADT, bool MULTI>
+__global__ __launch_bounds__(256) void k_dec_attn_pv64(const unsigned long long h0, const unsigned long long h1, const unsigned long long h2,
+                                                      const unsigned long long h3, const unsigned long long h4, const unsigned long long h5,
+                                                      const unsigned long long h6, const AttnArgs a0)
 {
-    const AttnArgs a = attn_for_seq(a0, blockIdx.z);
+    AttnArgs a = MULTI ? attn_for_seq(a0, blockIdx.z) : a0;
+    if (!MULTI) {
+        a.scores = (float*)from_word<float>(h0); a.stats = (float*)from_word<float>(h1); a.vcache = (uint8_t*)from_word<uint8_t>(h2);
+        a.step = from_word<DecStep>(h3); a.kv_pitch = (size_t)(unsigned)(h4 & 0xffffffffull); a.max_ctx = (int)(h4 >> 32);
+        a.n_chunks = (int)(unsigned)(h5 & 0xffffffffull); a.n_heads = (int)((h5 >> 32) & 0xffu); a.n_kv = (int)((h5 >> 40) & 0xffu); a.grp_shift1 = (int)(h5 >> 48);
+        a.att_part = (float*)from_word<float>(h6);
+    }
     constexpr int dh = 64;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
     const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    const int grp = a.n_heads / a.n_kv, g = h / grp;
+    // (heads per kv head: a shift when it is a power of two -- two integer divisions ahead of the first request otherwise)
+    const int grp = a.grp_shift1 ? (1 << (a.grp_shift1 - 1)) : a.n_heads / a.n_kv, g = a.grp_shift1 ? (h >> (a.grp_shift1 - 1)) : h / grp;
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)2 * GTEN_Q8_BYTES : (size_t)dh * 2;
 
     float* p = (float*)g_smem;                   // 256
@@ -1658,8 +1734,8 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
         int8_t* dq = pw ? vi8 : ki8;
         (void)head_prep_cs(kvraw, true, pw == 0, rot, dh, GTEN_Q8, dq, kd + 4 * pw, d16 + 4 * (GRP + pw));
         uint8_t* blk = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-        blk[2 + (t & 31)] = (uint8_t)dq[t];
-        if ((t & 31) == 0) *(uint16_t*)blk = d16[4 * (GRP + pw) + (t >> 5)];
+        store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
+        if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
     }
     __syncthreads();
 
@@ -1969,18 +2045,36 @@ static int launch_attention_grouped(const AttnArgs& t, int n_seq)
     }
 }
 
-static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
+static int grp_shift1_of(int n_heads, int n_kv)
 {
+    const int grp = n_heads / n_kv;
+    return (grp > 0 && (grp & (grp - 1)) == 0) ? __builtin_ctz(grp) + 1 : 0;
+}
+
+static int launch_attention(const AttnArgs& t0, dim3 agrid, size_t smem1)
+{
+    AttnArgs t = t0;
+    t.grp_shift1 = grp_shift1_of(t.n_heads, t.n_kv);
     if (t.d_head == 64) {
         const size_t nw = (t.adtype == GTEN_Q8) ? 17 : 32;
         const size_t smem2 = (size_t)2 * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * nw * 4;
-        if (t.adtype == GTEN_Q8) {
-            DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_Q8>), agrid, dim3(256), smem1, t);
-            DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_Q8>), agrid, dim3(256), smem2, t);
-        } else {
-            DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_F16>), agrid, dim3(256), smem1, t);
-            DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv64<GTEN_F16>), agrid, dim3(256), smem2, t);
-        }
+        // single-sequence launches hand the words the first requests are formed from as preloadable scalars
+        const unsigned long long geo = (unsigned long long)(unsigned)t.kv_pitch | ((unsigned long long)(unsigned)t.max_ctx << 32);
+        const unsigned long long heads = ((unsigned long long)(unsigned)t.n_heads << 32) | ((unsigned long long)(unsigned)t.n_kv << 40) |
+                                         ((unsigned long long)(unsigned)t.grp_shift1 << 48);
+        const AttnHotWords hs{{(unsigned long long)(uintptr_t)t.qkv_raw, (unsigned long long)(uintptr_t)t.rope_now, (unsigned long long)(uintptr_t)t.kcache,
+                               (unsigned long long)(uintptr_t)t.step, geo, (unsigned long long)(unsigned)t.n_embd | heads, (unsigned long long)(uintptr_t)t.scores}};
+        const AttnHotWords hp{{(unsigned long long)(uintptr_t)t.scores, (unsigned long long)(uintptr_t)t.stats, (unsigned long long)(uintptr_t)t.vcache,
+                               (unsigned long long)(uintptr_t)t.step, geo, (unsigned long long)(unsigned)t.n_chunks | heads, (unsigned long long)(uintptr_t)t.att_part}};
+        const bool multi = agrid.z > 1 || t.kv_tab != nullptr;
+#define ATT_LAUNCH2(ADT, MULTI)                                                                                                          \
+        do {                                                                                                                             \
+            DEC_LAUNCH_HOT(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<ADT, MULTI>), agrid, dim3(256), smem1, hs, t);                         \
+            DEC_LAUNCH_HOT(KT_DEC_ATTN_PV, (k_dec_attn_pv64<ADT, MULTI>), agrid, dim3(256), smem2, hp, t);                               \
+        } while (0)
+        if (t.adtype == GTEN_Q8) { if (multi) ATT_LAUNCH2(GTEN_Q8, true); else ATT_LAUNCH2(GTEN_Q8, false); }
+        else { if (multi) ATT_LAUNCH2(GTEN_F16, true); else ATT_LAUNCH2(GTEN_F16, false); }
+#undef ATT_LAUNCH2
         return 0;
     }
     DEC_LAUNCH(KT_DEC_ATTN_SCORE, k_dec_attn_score, agrid, dim3(256), smem1, t);
@@ -1988,12 +2082,27 @@ static int launch_attention(const AttnArgs& t, dim3 agrid, size_t smem1)
     return 0;
 }
 
+// the preloadable words of a k_dec_gemv8 launch (GemvHot)
+template <int WT, int PRO>
+static GemvHotWords hot_of(const Gemv8Args& a)
+{
+    GemvHotWords hw;
+    GemvHot& h = hw.h;
+    if (PRO == PRO_RESID) { h.p0 = a.res_raw; h.p1 = a.res_a; h.p2 = a.norm_w; }
+    else if (PRO == PRO_EMBED) { h.p0 = a.table; h.p1 = a.tokens; h.p2 = a.norm_w; }
+    else if (PRO == PRO_ATT) { h.p0 = a.att_part; h.p1 = (const void*)(uintptr_t)((unsigned)a.d_head_shift | ((unsigned)a.n_chunks << 8)); h.p2 = nullptr; }
+    else { h.p0 = (WT == GTEN_F16) ? (const void*)a.act_f : (const void*)a.act_q; h.p1 = a.act_d; h.p2 = a.act_sum; }
+    h.qs0 = a.qs[0]; h.ds0 = a.ds[0]; h.d_in = a.d_in; h.rows0 = a.rows[0]; h.step = a.step;
+    return hw;
+}
+
 template <int WT, int PRO, int NCH, int R, int NT>
 static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
     const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
-    DEC_LAUNCH(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), a);
+    const GemvHotWords hw = hot_of<WT, PRO>(a);
+    DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), hw, a);
     return 0;
 }
 
@@ -2002,7 +2111,8 @@ template <int WT>
 static int launch_gateup8(const Gemv8Args& a, int n_ffn)
 {
     const dim3 grid(n_ffn / 32), block(512);
-    DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), a);
+    const GemvHotWords hw = hot_of<WT, PRO_RESID>(a);
+    DEC_LAUNCH_HOT(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), hw, a);
     return 0;
 }
 
@@ -2092,7 +2202,8 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
 template <int WT, int PRO>
 static int launch_stage(int tag, Gemv8Args a, int n_seq)
 {
-    DEC_LAUNCH(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), a);
+    const GemvHotWords hw = hot_of<WT, PRO>(a);
+    DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), hw, a);
     return 0;
 }
 
@@ -2100,7 +2211,8 @@ template <int WT, int PRO>
 static int launch_stage_frag(int tag, Gemv8Args a, int n_seq)
 {
     a.frag_rt = (n_seq + 15) / 16;
-    DEC_LAUNCH(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE_FRAG, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), a);
+    const GemvHotWords hw = hot_of<WT, PRO>(a);
+    DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE_FRAG, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), hw, a);
     return 0;
 }
 
