@@ -295,7 +295,9 @@ union GemvHotWords {
     __host__ __device__ GemvHotWords() : w{0, 0, 0, 0, 0, 0, 0} {}
 };
 
-template <int WT, int PRO, int NCH, int R, int EPI, int NT>
+// NM: matrices concatenated along the output rows -- 1 (o, down, lm_head: the weight requests are formed from the
+// preloaded words alone), or 0 = a.n_mats at run time (q|k|v, gate|up)
+template <int WT, int PRO, int NCH, int R, int EPI, int NT, int NM = 0>
 __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, const unsigned long long h1, const unsigned long long h2,
                                                   const unsigned long long h3, const unsigned long long h4, const unsigned long long h5,
                                                   const unsigned long long h6, const Gemv8Args a)
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     }
 
     // ---- 2. request this wave's weight rows; they stay in flight during the prologue
-    const int rows0 = hot.rows0, rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
+    const int rows0 = hot.rows0, rows1 = (NM != 1 && a.n_mats > 1) ? a.rows[1] : 0, rows2 = (NM != 1 && a.n_mats > 2) ? a.rows[2] : 0;
     const int total = rows0 + rows1 + rows2;
     const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
                                         : (blockIdx.x * NW + wid) * R;
@@ -2096,13 +2098,13 @@ static GemvHotWords hot_of(const Gemv8Args& a)
     return hw;
 }
 
-template <int WT, int PRO, int NCH, int R, int NT>
+template <int WT, int PRO, int NCH, int R, int NT, int NM = 0>
 static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
     const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
     const GemvHotWords hw = hot_of<WT, PRO>(a);
-    DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), hw, a);
+    DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT, NM>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), hw, a);
     return 0;
 }
 
@@ -2174,7 +2176,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         Gemv8Args o{};
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
         o.att_part = dc->att_part; o.d_head = dh; o.d_head_shift = __builtin_ctz(dh); o.n_chunks = dc->n_chunks;
-        if ((rc = launch_gemv8<WT, PRO_ATT, NE, 2, 512>(KT_DEC_GEMV_O, o, E))) return rc;
+        if ((rc = launch_gemv8<WT, PRO_ATT, NE, 2, 512, 1>(KT_DEC_GEMV_O, o, E))) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
         gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
@@ -2184,15 +2186,15 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         dn.step = dc->step; dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw;
         dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum;
         dn.act_f = dc->act_f;
-        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, NF, 2, 256>(KT_DEC_GEMV_DOWN, dn, E)
-                   : launch_gemv8<WT, PRO_ACTQ8, NE, 2, 256>(KT_DEC_GEMV_DOWN, dn, E);
+        rc = wideF ? launch_gemv8<WT, PRO_ACTQ8, NF, 2, 256, 1>(KT_DEC_GEMV_DOWN, dn, E)
+                   : launch_gemv8<WT, PRO_ACTQ8, NE, 2, 256, 1>(KT_DEC_GEMV_DOWN, dn, E);
         if (rc) return rc;
     }
     Gemv8Args hd{};
     hd.step = dc->step; hd.d_in = E; hd.n_mats = 1; set_mat(hd, 0, d.lm_head, WT, d.n_vocab, E); hd.out = d.logits;
     hd.res_a = hbuf; hd.res_raw = dc->down_raw; hd.x_out = nullptr; hd.norm_w = (const uint16_t*)d.final_norm;
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
-    if ((rc = launch_gemv8<WT, PRO_RESID, NE, F16W ? 4 : 8, 512>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
+    if ((rc = launch_gemv8<WT, PRO_RESID, NE, F16W ? 4 : 8, 512, 1>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
     DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
                dc->n_best, dc->step, dc->result, 0, 0);
     return 0;
