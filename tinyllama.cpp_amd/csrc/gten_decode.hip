@@ -592,16 +592,27 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
 // sequence, or an f32 row for f16).  Per sequence the arithmetic, its order and therefore the
 // result are exactly those of the single-sequence kernel (tested bit for bit).
 template <int WT, int NCH, int R, int S, int EPI, int NT>
-__global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
+__global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, const unsigned long long h1, const unsigned long long h2,
+                                                  const unsigned long long h3, const unsigned long long h4, const unsigned long long h5,
+                                                  const unsigned long long h6, const Gemv8Args a)
 {
+    // hot arguments (GemvHot, PRO_ACTQ8 form): staged inputs, first matrix, sizes
+    const int8_t* act_q = from_word<int8_t>(h0);
+    const float* act_f = from_word<float>(h0);
+    const float* act_d = from_word<float>(h1);
+    const int* act_sum = from_word<int>(h2);
+    const uint8_t* qs0 = from_word<uint8_t>(h3);
+    const uint16_t* ds0 = from_word<uint16_t>(h4);
+    const int hot_d_in = (int)(unsigned)(h5 & 0xffffffffull), hot_rows0 = (int)(unsigned)(h5 >> 32);
+    (void)h6;
     constexpr int NW = NT / 64;
     constexpr bool F16W = (WT == GTEN_F16);
     static_assert(EPI != EPI_SILUMUL || (NT == 512 && S <= 8), "FFN slice epilogue: 8 waves, one per sequence");
-    const int d = a.d_in, nb = d >> 5;
+    const int d = hot_d_in, nb = d >> 5;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float* res = (float*)g_smem;                  // EPI_SILUMUL: [S][64]
 
-    const int rows0 = a.rows[0], rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
+    const int rows0 = hot_rows0, rows1 = a.n_mats > 1 ? a.rows[1] : 0, rows2 = a.n_mats > 2 ? a.rows[2] : 0;
     const int total = rows0 + rows1 + rows2;
     const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
                                         : (blockIdx.x * NW + wid) * R;
@@ -611,8 +622,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
     for (int j = 0; j < R; j++) {
         int lr = r0 + j;
         const bool ok = lr < total;
-        const uint8_t* qbase = a.qs[0];
-        const uint16_t* dbase = a.ds[0];
+        const uint8_t* qbase = qs0;
+        const uint16_t* dbase = ds0;
         if (lr >= rows0 && rows1 > 0) {
             lr -= rows0; qbase = a.qs[1]; dbase = a.ds[1];
             if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; }
@@ -649,14 +660,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const Gemv8Args a)
     float* lf = (float*)lq;
     if (F16W) {
         if (lds_f) {
-            for (int i = threadIdx.x * 4; i < S * d; i += NT * 4) *(float4*)(lf + i) = *(const float4*)(a.act_f + i);
+            for (int i = threadIdx.x * 4; i < S * d; i += NT * 4) *(float4*)(lf + i) = *(const float4*)(act_f + i);
         }
     } else {
-        for (int i = threadIdx.x * 16; i < S * d; i += NT * 16) *(uint4*)(lq + i) = *(const uint4*)(a.act_q + i);
-        for (int i = threadIdx.x; i < S * nb; i += NT) { ld_[i] = a.act_d[i]; lsum[i] = a.act_sum[i]; }
+        for (int i = threadIdx.x * 16; i < S * d; i += NT * 16) *(uint4*)(lq + i) = *(const uint4*)(act_q + i);
+        for (int i = threadIdx.x; i < S * nb; i += NT) { ld_[i] = act_d[i]; lsum[i] = act_sum[i]; }
     }
     __syncthreads();
-    const float* fsrc = lds_f ? lf : a.act_f;
+    const float* fsrc = lds_f ? lf : act_f;
 
     float acc[R][S];
 #pragma unroll
@@ -795,13 +806,19 @@ typedef int mmv_v4i __attribute__((ext_vector_type(4)));
 // FT = 16-feature tiles per workgroup: 1 for the launches that have about one workgroup per CU anyway (q|k|v, o,
 // down); 4 (Q4) / 2 (Q8) for gate|up and the lm_head at K = 2048, whose 704 / 2001 sixteen-feature workgroups would
 // run in several rounds -- each activation fragment and delta then feeds FT matrix instructions.
+// (leading scalar arguments: preloaded into SGPRs by the command processor, see GemvHot; the second and third
+// matrix of a concatenated launch travel in the struct behind them)
+struct MmvRest { const void* w1; const void* w2; int d_out1, d_out2; };
+
 template <int WT, int RT, int CB, int FT>
-__global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
+__global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq, const float* __restrict__ a_ad, const void* __restrict__ a_w0,
+                                                 float* __restrict__ a_out, const int a_d_in, const int a_d_out0, const int a_out_cols,
+                                                 const int a_S, const int a_n_mats, const MmvRest rest)
 {
     constexpr int SP = 16 * RT;                               // padded row count
     constexpr int FR = 16 * FT;                               // features per workgroup
     constexpr int NPF = MMV_MAXP / FT;                        // 16-byte weight pieces per thread and feature tile
-    const int nb = a.d_in >> 5, nbw = nb >> 3;                // blocks per wave (nb % 8 == 0)
+    const int nb = a_d_in >> 5, nbw = nb >> 3;                // blocks per wave (nb % 8 == 0)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int rowb = nb * (WT == GTEN_Q4 ? 16 : 32);          // weight bytes per feature
     uint8_t* wl = g_smem;                                     // [FR][rowb], 16-byte pieces swizzled: slot = piece ^ (row & 7)
@@ -811,13 +828,13 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
 
     // which matrix (uniform)
     int colw = blockIdx.x * FR, colbase = 0, m = 0;
-    if (a.n_mats > 1 && colw >= a.d_out[0]) {
-        colw -= a.d_out[0]; colbase = a.d_out[0]; m = 1;
-        if (a.n_mats > 2 && colw >= a.d_out[1]) { colw -= a.d_out[1]; colbase += a.d_out[1]; m = 2; }
+    if (a_n_mats > 1 && colw >= a_d_out0) {
+        colw -= a_d_out0; colbase = a_d_out0; m = 1;
+        if (a_n_mats > 2 && colw >= rest.d_out1) { colw -= rest.d_out1; colbase += rest.d_out1; m = 2; }
     }
-    const void* w = (m == 0) ? a.w[0] : (m == 1) ? a.w[1] : a.w[2];
-    const int d_out = (m == 0) ? a.d_out[0] : (m == 1) ? a.d_out[1] : a.d_out[2];
-    const PackedW pw = packed_view(w, WT, d_out, a.d_in);
+    const void* w = (m == 0) ? a_w0 : (m == 1) ? rest.w1 : rest.w2;
+    const int d_out = (m == 0) ? a_d_out0 : (m == 1) ? rest.d_out1 : rest.d_out2;
+    const PackedW pw = packed_view(w, WT, d_out, a_d_in);
 
     // ---- 1. everything this workgroup will read, requested at once (one memory round trip):
     //         the weight slab (32 threads per feature row, pieces c0 + 32 k), its deltas, the delta table of the
@@ -841,9 +858,9 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
     uint4 dap[MMV_MAXD];
 #pragma unroll
     for (int k = 0; k < MMV_MAXD; k++)
-        if (512 * k < ndp) dap[k] = ((const uint4*)a.ad)[min((int)threadIdx.x + 512 * k, ndp - 1)];
+        if (512 * k < ndp) dap[k] = ((const uint4*)a_ad)[min((int)threadIdx.x + 512 * k, ndp - 1)];
     const int b0 = wid * nbw;
-    const int8_t* afr = a.aq + (size_t)lane * 8;              // fragment order: 512 contiguous bytes per (block, row tile)
+    const int8_t* afr = a_aq + (size_t)lane * 8;              // fragment order: 512 contiguous bytes per (block, row tile)
     uint2 araw[RT][CB];
     auto request = [&](int bb) {
 #pragma unroll
@@ -946,7 +963,7 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const MmvArgs a)
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
-            if (r < a.S && colw + 16 * f + c < d_out) a.out[(size_t)r * a.out_cols + colbase + colw + 16 * f + c] = v;
+            if (r < a_S && colw + 16 * f + c < d_out) a_out[(size_t)r * a_out_cols + colbase + colw + 16 * f + c] = v;
         }
     }
 }
@@ -2230,8 +2247,9 @@ template <int WT, int NCH, int R, int S, int NT>
 static int launch_gemvm(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
-    DEC_LAUNCH(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT),
-               gemvm_lds_bytes(WT, S, a.d_in, false), a);
+    const GemvHotWords hw = hot_of<WT, PRO_ACTQ8>(a);
+    DEC_LAUNCH_HOT(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT),
+                   gemvm_lds_bytes(WT, S, a.d_in, false), hw, a);
     return 0;
 }
 
@@ -2303,7 +2321,8 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
         gu.act_q = dc->stg_q; gu.act_d = dc->stg_d; gu.act_sum = dc->stg_sum; gu.act_f = dc->stg_f;
         gu.out_q = dc->act_q; gu.out_d = dc->act_d; gu.out_sum = dc->act_sum; gu.out_f = dc->act_f;
-        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), gemvm_lds_bytes(WT, S, E, true), gu);
+        const GemvHotWords ghw = hot_of<WT, PRO_ACTQ8>(gu);
+        DEC_LAUNCH_HOT(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), gemvm_lds_bytes(WT, S, E, true), ghw, gu);
         Gemv8Args dn = base;
         dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw; dn.raw_stride = E;
         dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum; dn.act_f = dc->act_f;
@@ -2354,14 +2373,17 @@ static int launch_mmv_rt(int tag, const MmvArgs& a)
     const dim3 grid((cols + 16 * ft - 1) / (16 * ft));
     // activation chunks: all of a wave's blocks at once when that is 8 or fewer, else elevens (5632 / 256 = 22);
     // more than 32 rows or several feature tiles: fours (registers)
+    const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2]};
+#define MMV_ARGS a.aq, a.ad, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest
     if (ft > 1)
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, FTW>), grid, dim3(512), smem, a);
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, FTW>), grid, dim3(512), smem, MMV_ARGS);
     else if (RT > 2)
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, 1>), grid, dim3(512), smem, a);
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, 1>), grid, dim3(512), smem, MMV_ARGS);
     else if (nbw > 8 && nbw % 11 == 0)
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 11, 1>), grid, dim3(512), smem, a);
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 11, 1>), grid, dim3(512), smem, MMV_ARGS);
     else
-        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 8, 1>), grid, dim3(512), smem, a);
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 8, 1>), grid, dim3(512), smem, MMV_ARGS);
+#undef MMV_ARGS
     return 0;
 }
 
