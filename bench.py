@@ -71,6 +71,10 @@ def parse_args():
                          "reported separately, `value` stays the single-sequence rate")
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
+    ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
+                    help="how the (untimed) context below the timed window is produced: single-token decode steps "
+                         "(default) or one prompt-processing call -- the latter keeps a rocprofv3 kernel trace to "
+                         "thousands instead of hundreds of thousands of launches")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
     return ap.parse_args()
 
@@ -187,11 +191,14 @@ def main():
     total = K + W
     first = n_of(0, total)
     t_fill = time.time()
-    for n in range(1, first):
-        if fused:
-            model.decode_step(n, use_graph)
-        else:
-            model.logits(toks[:n], n - 1, want=False)
+    if args.fill == "prefill" and first > 1:
+        model.logits(toks[:first - 1], 0, want=False)
+    else:
+        for n in range(1, first):
+            if fused:
+                model.decode_step(n, use_graph)
+            else:
+                model.logits(toks[:n], n - 1, want=False)
     hip.sync()
     t_fill = time.time() - t_fill
     for i in range(W):
@@ -279,7 +286,7 @@ def main():
         "whole_step_hbm": {"achieved": round(whole, 1), "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBPS, 4),
                            "algorithmic_bytes_per_step": int(algorithmic_bytes(args.mode, n_mid))},
         "roofline": roofline,
-        "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1)},
+        "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1), "context_fill": args.fill},
     }
     # secondary: several sequences on this GPU sharing every weight pass (not part of `value`)
     def multi_stream(S, note):
