@@ -249,6 +249,15 @@ def main():
         avg_us, per_replay = bracket_us, launches // P
         if fused:
             avg_us, per_replay = model.time_family(hip.prof_family_index(fam), N_CTX, 20)
+        # the same isolated timing for every family of the step (launches of ONE family replayed back to back)
+        family_us = {}
+        if fused:
+            for f2 in prof:
+                try:
+                    u2, _ = model.time_family(hip.prof_family_index(f2), N_CTX, 20)
+                    family_us[f2] = round(u2, 3)
+                except Exception:
+                    pass
         achieved = (per_launch / (avg_us * 1e-6) / 1e9) if per_launch else None
         step_ms = elapsed / K * 1e3
         roofline = {"bound": "hbm", "kernel": fam, "achieved": round(achieved, 1) if achieved else None,
@@ -256,6 +265,7 @@ def main():
                     "traffic": None, "avg_launch_us": round(avg_us, 3), "launches_per_step": per_replay,
                     "algorithmic_bytes_per_launch": int(per_launch) if per_launch else None,
                     "timing": "HIP events around 20 graph replays of this kernel family alone" if fused else "HIP event pair per launch",
+                    "family_avg_launch_us": family_us,
                     "per_launch_event_bracket_us": {k: round(v[1] * 1e3 / v[0], 2) for k, v in prof.items()},
                     "bracket_share_of_step": {k: round(v[1] / P / step_ms, 3) for k, v in prof.items()}}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -1462,10 +1462,36 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const unsigned long long 
     float acc = 0.f;
     if (ADT == GTEN_Q8) {
         const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+        if (len == DEC_CHUNK) {
+            // a full chunk (every chunk but the last): eight terms per round, the LDS reads of round r + 1 issued
+            // ahead of the arithmetic of round r (software pipeline) -- same terms, same order
+            float pp[2][8];
+            int qv[2][8];
+            unsigned dv[2][8];
+            auto fetch = [&](int r, int slot) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint8_t* row = vb + (size_t)(cg + 4 * (8 * r + u)) * 68;
+                    pp[slot][u] = p[cg + 4 * (8 * r + u)];
+                    qv[slot][u] = (int)(int8_t)row[qoff];
+                    dv[slot][u] = *(const uint16_t*)(row + doff);
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int r = 0; r < DEC_CHUNK / 32; r++) {
+                if (r + 1 < DEC_CHUNK / 32) fetch(r + 1, (r + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += pp[r & 1][u] * ((float)qv[r & 1][u] * h2f((uint16_t)dv[r & 1][u]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll 8
-        for (int cl = cg; cl < len; cl += 4) {
-            const uint8_t* row = vb + (size_t)cl * 68;
-            acc += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
+            for (int cl = cg; cl < len; cl += 4) {
+                const uint8_t* row = vb + (size_t)cl * 68;
+                acc += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
+            }
         }
     } else {
         for (int cl = cg; cl < len; cl += 4) acc += p[cl] * h2f(((const uint16_t*)(vb + (size_t)cl * 128))[e]);
