@@ -121,3 +121,21 @@ def test_full_model_golden_q4_first_steps(oracle):
         assert int(np.argmax(lg)) == int(ids[0]) == int(toks[n])
         assert np.array_equal(lg[g["probe_ids"]], g["q4.avx.probes"][step])
     m.close()
+
+
+def test_div127_markstein():
+    """The HIP Q8 quantizer divides the block absmax by 127 with a 3-instruction Markstein sequence
+    (csrc/gten_dev.h: div127) instead of the IEEE division expansion.  It must be the correctly rounded
+    quotient the reference computes (gten/quants.h:52-58: absmax / 127.0f): exhaustive over every binary32
+    significand of one binade -- binary scaling carries the result to all other binades."""
+    y = np.float32(1.0) / np.float32(127.0)
+    assert float(y).hex() == "0x1.0204080000000p-7"            # the constant in div127
+    a = np.arange(2 ** 23, 2 ** 24, dtype=np.int64).astype(np.float32)
+    ref = a / np.float32(127.0)                                   # IEEE division, correctly rounded
+    # binary64 carries each step exactly (24 x 24-bit products, sums far inside 53 bits); one rounding per cast
+    q0 = (a.astype(np.float64) * np.float64(y)).astype(np.float32)
+    r64 = a.astype(np.float64) - 127.0 * q0.astype(np.float64)    # fma(-127, q0, a)
+    r = r64.astype(np.float32)
+    assert np.array_equal(r.astype(np.float64), r64)              # the remainder is exact
+    q1 = (r.astype(np.float64) * np.float64(y) + q0.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(q1, ref)

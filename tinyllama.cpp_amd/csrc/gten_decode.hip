@@ -476,7 +476,9 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
             }
             // RMSNorm (gten/ops.h:762-778), then the row is written as Q8
             ss = block_sum_tree_n<NW, true>(ss, s.red);             // first use of s.red in this kernel
-            const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);  // see k_rms_norm
+            // (mean of squares: a power-of-two width divides exactly by an exponent shift -- the same bits as ss / d)
+            const float ms = ((d & (d - 1)) == 0) ? __builtin_ldexpf(ss, -__builtin_ctz(d)) : ss / (float)d;
+            const float inv = 1.0f / (sqrtf(ms) + 1e-6f);            // see k_rms_norm
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 const uint16_t hw = (uint16_t)((i & 1) ? (nw[i >> 1] >> 16) : (nw[i >> 1] & 0xffffu));
