@@ -77,6 +77,12 @@ int         gten_hip_prof_enable(int on);
 int         gten_hip_prof_read(int family, int* launches, double* total_ms);
 const char* gten_hip_prof_family_name(int family);   /* NULL past the last family */
 
+/* Self-test of the Q8 quantizer's scale arithmetic (gten/quants.h:52-58: delta = absmax / 127.0f, scale = 1.0f /
+ * delta).  The kernels compute both with short exact sequences (csrc/gten_dev.h: div127, recip_rn) instead of the
+ * compiler's IEEE division expansion; this runs them against that expansion on the device over every binary32
+ * significand of several binades and returns the number of differing results (must be 0). */
+int gten_hip_selftest_q8scale(unsigned long long* mismatches_div127, unsigned long long* mismatches_recip);
+
 /* bytes of one storage row (gten/tensor.h:97-117, gten/tensor.cpp:37-57) */
 size_t gten_hip_row_bytes(int dtype, int cols);
 

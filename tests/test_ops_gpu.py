@@ -234,3 +234,12 @@ def test_qkv_attn_tiled_prefill_equals_row_kernel(hip, oracle, monkeypatch, n, s
     want = np.zeros((n, row_bytes(Q8, H * dh)), np.uint8)
     oracle.qkv_attn(q, k, v, want, Q8, n, H, G, dh, sp)
     compare_rows(outs[1][sp:], want[sp:], Q8, H * dh, "qkv_attn_tiled", min_exact=0.90, steps=2.0, atol=2e-4)
+
+
+def test_q8_scale_arithmetic_is_ieee(hip):
+    """The quantizer's delta = absmax / 127 and scale = 1 / delta run as 3-instruction Markstein sequences
+    (csrc/gten_dev.h); on the device they equal the IEEE division expansion for every binary32 significand of six
+    binades (50 million operands each)."""
+    bad_div, bad_recip = hip.selftest_q8scale()
+    assert bad_div == 0
+    assert bad_recip == 0

@@ -311,7 +311,44 @@ using namespace gtr;
 
 static bool act_dtype_ok(int dt) { return dt == GTEN_F16 || dt == GTEN_Q8; }
 
+// ---- self-test of the quantizer's scale arithmetic (see include/gten_hip.h)
+__global__ __launch_bounds__(256) void k_selftest_q8scale(unsigned long long* __restrict__ bad)
+{
+    const int exps[6] = {-40, -20, -7, 0, 6, 20};                 // binades of the operand
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;           // significand bits, 0 .. 2^23 - 1
+    unsigned bd = 0, br = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const float a = __uint_as_float(((unsigned)(127 + exps[k]) << 23) | m);
+        volatile float av = a;                                    // keep the compiler from folding either side
+        const float ref_d = av / 127.0f, ref_r = 1.0f / av;
+        bd += (__float_as_uint(gtd::div127(a)) != __float_as_uint(ref_d));
+        br += (__float_as_uint(gtd::recip_rn(a)) != __float_as_uint(ref_r));
+    }
+    if (bd) atomicAdd(bad, (unsigned long long)bd);
+    if (br) atomicAdd(bad + 1, (unsigned long long)br);
+}
+
 extern "C" {
+
+int gten_hip_selftest_q8scale(unsigned long long* mismatches_div127, unsigned long long* mismatches_recip)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(mismatches_div127 && mismatches_recip, "selftest_q8scale: null argument");
+    unsigned long long* d = nullptr;
+    GTR_CHECK(hipMalloc((void**)&d, 16));
+    GTR_CHECK(hipMemsetAsync(d, 0, 16, gtr::stream()));
+    hipLaunchKernelGGL(k_selftest_q8scale, dim3((1u << 23) / 256), dim3(256), 0, gtr::stream(), d);
+    GTR_LAUNCHED();
+    unsigned long long h[2] = {0, 0};
+    GTR_CHECK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, gtr::stream()));
+    GTR_CHECK(hipStreamSynchronize(gtr::stream()));
+    GTR_CHECK(hipFree(d));
+    *mismatches_div127 = h[0];
+    *mismatches_recip = h[1];
+    return 0;
+}
+
 
 int gten_hip_pack_weight(const void* src_blocks, int dtype, int rows, int cols, void* dst_packed)
 {

@@ -76,7 +76,7 @@ class GtenHip:
         "gten_hip_device_count", "gten_hip_init", "gten_hip_last_error", "gten_hip_stream", "gten_hip_sync",
         "gten_hip_malloc", "gten_hip_free", "gten_hip_memset", "gten_hip_memcpy_h2d", "gten_hip_memcpy_d2h",
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
-        "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
+        "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
         "gten_hip_add", "gten_hip_qkv_attn",
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
@@ -99,6 +99,7 @@ class GtenHip:
         self._err = _sig(L, "gten_hip_last_error", C.c_char_p, [])
         self._stream = _sig(L, "gten_hip_stream", vp, [])
         self._sync = _sig(L, "gten_hip_sync", ci, [])
+        self._selftest_q8 = _sig(L, "gten_hip_selftest_q8scale", ci, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
         self._malloc = _sig(L, "gten_hip_malloc", ci, [C.POINTER(vp), sz])
         self._free = _sig(L, "gten_hip_free", ci, [vp])
         self._memset = _sig(L, "gten_hip_memset", ci, [vp, ci, sz])
@@ -138,6 +139,12 @@ class GtenHip:
 
     def sync(self):
         self._check(self._sync())
+
+    def selftest_q8scale(self):
+        """(mismatches of div127, mismatches of recip_rn) against the IEEE division expansion, on the device"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self._selftest_q8(C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def stream(self):
         return self._stream()
