@@ -121,6 +121,7 @@ struct Gemv8Args {
     float* act_f;                                               // same for f16 activations: f32 row of exact f16 values
     // multi-sequence decode (EPI_STAGE / k_dec_gemvm): element strides between consecutive sequences
     int raw_stride;               // res_raw / out rows
+    int raw_plane;                // staging launches: floats to the second K-split plane of res_raw (0: a single plane)
     int tok_stride;               // token id rows
     int part_stride;              // att_part
     int best_stride;              // best_val / best_idx
@@ -346,6 +347,10 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
 #pragma unroll
     for (int i = 0; i < EPT; i++) { pin0[i] = 0.f; pin1[i] = 0.f; }
     if (PRO == PRO_RESID) { ldN<EPT>(res_raw + sbase, pin0); ldN<EPT>(res_a + sbase, pin1); }
+    // staging launches of the wide path: the producer (k_dec_mmv) may have split K over two workgroups -- the second
+    // plane of partial sums is requested unconditionally (plane 0: the same row again) and added below
+    float pin0b[(STG && PRO == PRO_RESID) ? EPT : 1];
+    if constexpr (STG && PRO == PRO_RESID) ldN<EPT>(res_raw + a.raw_plane + sbase, pin0b);
     // (norm_w is required for PRO_EMBED / PRO_RESID: a null check here would be a branch whose join
     // makes hipcc wait for every outstanding load BEFORE the weight rows below are even requested)
     unsigned nw[4] = {0, 0, 0, 0};
@@ -456,6 +461,10 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
         } else if (PRO == PRO_RESID) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = pin0[i];
+            if constexpr (STG && PRO == PRO_RESID) {
+#pragma unroll
+                for (int i = 0; i < EPT; i++) v[i] += a.raw_plane ? pin0b[i] : 0.f;
+            }
             act_roundN<WT, EPT>(v);                       // Linear output written in the activation dtype
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = pin1[i] + v[i];
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
             ss = block_sum_tree_n<NW, true>(ss, s.red);             // first use of s.red in this kernel
             // (mean of squares: a power-of-two width divides exactly by an exponent shift -- the same bits as ss / d)
             const float ms = ((d & (d - 1)) == 0) ? __builtin_ldexpf(ss, -__builtin_ctz(d)) : ss / (float)d;
-            const float inv = 1.0f / (sqrtf(ms) + 1e-6f);            // see k_rms_norm
+            const float inv = recip_rn(sqrtf(ms) + 1e-6f);            // == 1.0f / (...) (recip_rn), see k_rms_norm
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 const uint16_t hw = (uint16_t)((i & 1) ? (nw[i >> 1] >> 16) : (nw[i >> 1] & 0xffffu));
@@ -799,6 +808,7 @@ struct MmvArgs {
     const void* w[3]; int d_out[3]; int n_mats;               // concatenated outputs (q|k|v, gate|up): multiples of 16 except the last
     float* out; int out_cols;                                 // raw f32 rows, pitch in floats
     int S, d_in;
+    int ks, plane;                                            // K split: slices (0 / 1 = none) and floats between their output planes
 };
 
 typedef int mmv_v4i __attribute__((ext_vector_type(4)));
@@ -810,7 +820,12 @@ typedef int mmv_v4i __attribute__((ext_vector_type(4)));
 // run in several rounds -- each activation fragment and delta then feeds FT matrix instructions.
 // (leading scalar arguments: preloaded into SGPRs by the command processor, see GemvHot; the second and third
 // matrix of a concatenated launch travel in the struct behind them)
-struct MmvRest { const void* w1; const void* w2; int d_out1, d_out2; };
+// K SPLIT: gridDim.y workgroups share a feature tile, each takes nb / gridDim.y consecutive quant blocks (its eight
+// waves split THAT range) and writes its own plane of partial sums (plane p at out + p * plane floats); the consumer
+// adds the planes in order.  Why: q|k|v, o and down have 128-160 feature tiles -- half the CUs idle, one wave per SIMD
+// with nothing to hide its LDS -> MFMA -> rescale latencies behind, and every workgroup reading ALL of the
+// activations; two slices put two workgroups on a CU and halve each one's chain and activation traffic.
+struct MmvRest { const void* w1; const void* w2; int d_out1, d_out2; int plane; };
 
 template <int WT, int RT, int CB, int FT>
 __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq, const float* __restrict__ a_ad, const void* __restrict__ a_w0,
@@ -820,13 +835,16 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
     constexpr int SP = 16 * RT;                               // padded row count
     constexpr int FR = 16 * FT;                               // features per workgroup
     constexpr int NPF = MMV_MAXP / FT;                        // 16-byte weight pieces per thread and feature tile
-    const int nb = a_d_in >> 5, nbw = nb >> 3;                // blocks per wave (nb % 8 == 0)
+    const int nb = a_d_in >> 5;                               // quant blocks of a row
+    const int nbs = nb / (int)gridDim.y, b_lo = (int)blockIdx.y * nbs;   // this workgroup's slice of them
+    const int nbw = nbs >> 3;                                 // blocks per wave (nbs % 8 == 0)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
-    const int rowb = nb * (WT == GTEN_Q4 ? 16 : 32);          // weight bytes per feature
-    uint8_t* wl = g_smem;                                     // [FR][rowb], 16-byte pieces swizzled: slot = piece ^ (row & 7)
+    const int rowb = nb * (WT == GTEN_Q4 ? 16 : 32);          // weight bytes per feature (in HBM)
+    const int rowl = nbs * (WT == GTEN_Q4 ? 16 : 32);         // ... of this slice (in LDS)
+    uint8_t* wl = g_smem;                                     // [FR][rowl], 16-byte pieces swizzled: slot = piece ^ (row & 7)
     float* red = (float*)g_smem;                              // [8][SP][16] -- over the slab, once the K loop is done
-    uint16_t* dwl = (uint16_t*)(wl + max((size_t)FR * rowb, (size_t)8 * SP * 64));   // [FR][nb] weight deltas
-    float* daT = (float*)(dwl + (size_t)FR * nb);             // [nb][SP] activation deltas
+    uint16_t* dwl = (uint16_t*)(wl + max((size_t)FR * rowl, (size_t)8 * SP * 64));   // [FR][nbs] weight deltas
+    float* daT = (float*)(dwl + (size_t)FR * nbs);            // [nbs][SP] activation deltas
 
     // which matrix (uniform)
     int colw = blockIdx.x * FR, colbase = 0, m = 0;
@@ -841,7 +859,7 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
     // ---- 1. everything this workgroup will read, requested at once (one memory round trip):
     //         the weight slab (32 threads per feature row, pieces c0 + 32 k), its deltas, the delta table of the
     //         activations, and this wave's first chunk of activation fragments
-    const int ppr = rowb >> 4;                                // pieces per feature row (<= 32 * NPF)
+    const int ppr = rowl >> 4;                                // pieces per feature row of the slice (<= 32 * NPF)
     const int sr = threadIdx.x >> 5, c0 = threadIdx.x & 31;
     uint4 wp[FT][NPF];
     unsigned dwv[FT][3];                                      // nb / 2 <= 88 dwords per row
@@ -851,17 +869,22 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
         const uint8_t* srow = pw.qs + frow * rowb;
 #pragma unroll
         for (int k = 0; k < NPF; k++)
-            if (32 * k < ppr) wp[f][k] = *(const uint4*)(srow + (size_t)min(c0 + 32 * k, ppr - 1) * 16);
-        const unsigned* drow = (const unsigned*)(pw.ds + frow * nb);
+            if (32 * k < ppr) {
+                // local piece -> piece of the row in HBM (Q4: one 16-byte piece per block; Q8: two planes of nb pieces)
+                const int lp = min(c0 + 32 * k, ppr - 1);
+                const int gp = (WT == GTEN_Q4) ? b_lo + lp : (lp < nbs ? b_lo + lp : nb + b_lo + (lp - nbs));
+                wp[f][k] = *(const uint4*)(srow + (size_t)gp * 16);
+            }
+        const unsigned* drow = (const unsigned*)(pw.ds + frow * nb + b_lo);
 #pragma unroll
-        for (int k = 0; k < 3; k++) dwv[f][k] = drow[min(c0 + 32 * k, (nb >> 1) - 1)];
+        for (int k = 0; k < 3; k++) dwv[f][k] = drow[min(c0 + 32 * k, (nbs >> 1) - 1)];
     }
-    const int ndp = nb * SP / 4;                              // 16-byte pieces of the [nb][SP] delta table (same layout in LDS)
+    const int ndp = nbs * SP / 4;                             // 16-byte pieces of the slice of the [nb][SP] delta table (same layout in LDS)
     uint4 dap[MMV_MAXD];
 #pragma unroll
     for (int k = 0; k < MMV_MAXD; k++)
-        if (512 * k < ndp) dap[k] = ((const uint4*)a_ad)[min((int)threadIdx.x + 512 * k, ndp - 1)];
-    const int b0 = wid * nbw;
+        if (512 * k < ndp) dap[k] = ((const uint4*)(a_ad + (size_t)b_lo * SP))[min((int)threadIdx.x + 512 * k, ndp - 1)];
+    const int b0 = b_lo + wid * nbw;
     const int8_t* afr = a_aq + (size_t)lane * 8;              // fragment order: 512 contiguous bytes per (block, row tile)
     uint2 araw[RT][CB];
     auto request = [&](int bb) {
@@ -880,12 +903,12 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
             const int c = c0 + 32 * k;
-            if (c < ppr) *(uint4*)(wl + (size_t)r * rowb + (size_t)(c ^ (r & 7)) * 16) = wp[f][k];
+            if (c < ppr) *(uint4*)(wl + (size_t)r * rowl + (size_t)(c ^ (r & 7)) * 16) = wp[f][k];
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int c = c0 + 32 * k;
-            if (c < (nb >> 1)) ((unsigned*)dwl)[r * (nb >> 1) + c] = dwv[f][k];
+            if (c < (nbs >> 1)) ((unsigned*)dwl)[r * (nbs >> 1) + c] = dwv[f][k];
         }
     }
 #pragma unroll
@@ -905,7 +928,7 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
         for (int t = 0; t < RT; t++)
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[f][t][i] = 0.f;
-    const uint8_t* wrow = wl + (size_t)l16 * rowb + (g & 1) * 8;        // feature tile f: + 16 f rows (same swizzle: (16 f + l16) & 7 == l16 & 7)
+    const uint8_t* wrow = wl + (size_t)l16 * rowl + (g & 1) * 8;        // feature tile f: + 16 f rows (same swizzle: (16 f + l16) & 7 == l16 & 7)
     for (int bb = b0; bb < b0 + nbw; bb += CB) {
         uint2 aqv[RT][CB];
 #pragma unroll
@@ -915,14 +938,14 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
         if (bb + CB < b0 + nbw) request(bb + CB);               // next chunk in flight during this one's math
 #pragma unroll
         for (int c = 0; c < CB; c++) {
-            const int b = min(bb + c, nb - 1);
+            const int b = min(bb + c, b_lo + nbs - 1) - b_lo;    // block inside the workgroup's slice (LDS index)
             const bool live = bb + c < b0 + nbw;                 // blocks past this wave's slice (ragged last chunk) are scaled by zero
             long bl[FT];
             float dwf[FT];
 #pragma unroll
             for (int f = 0; f < FT; f++) {
-                dwf[f] = live ? h2f(dwl[(16 * f + l16) * nb + b]) : 0.f;
-                const uint8_t* wr = wrow + (size_t)16 * f * rowb;
+                dwf[f] = live ? h2f(dwl[(16 * f + l16) * nbs + b]) : 0.f;
+                const uint8_t* wr = wrow + (size_t)16 * f * rowl;
                 if (WT == GTEN_Q4) {
                     // nibble - 7 as int8, byte-parallel: (n | 0x80) - 7 never borrows across bytes, ^ 0x80 restores the sign
                     const uint2 by = *(const uint2*)(wr + (size_t)(b ^ (l16 & 7)) * 16);
@@ -931,7 +954,7 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
                     bl[f] = (long)(((unsigned long)y << 32) | x);
                 } else {
                     // Q8 rows are two planes of nb 16-byte pieces: elements 0-15, then 16-31
-                    const int piece = (g >> 1) * nb + b;
+                    const int piece = (g >> 1) * nbs + b;
                     const uint2 by = *(const uint2*)(wr + (size_t)(piece ^ (l16 & 7)) * 16);
                     bl[f] = (long)(((unsigned long)by.y << 32) | by.x);
                 }
@@ -965,7 +988,8 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
-            if (r < a_S && colw + 16 * f + c < d_out) a_out[(size_t)r * a_out_cols + colbase + colw + 16 * f + c] = v;
+            if (r < a_S && colw + 16 * f + c < d_out)
+                a_out[(size_t)blockIdx.y * rest.plane + (size_t)r * a_out_cols + colbase + colw + 16 * f + c] = v;
         }
     }
 }
@@ -1009,6 +1033,7 @@ struct AttnArgs {
     // [seq][layer][k|v], its scratch rows lie `*_stride` elements apart
     const void* const* kv_tab; int layer, n_layers;
     int qkv_stride, scores_stride, stats_stride, part_stride;
+    int qkv_plane;                // grouped kernels: floats to the second K-split plane of qkv_raw (0: a single plane)
 };
 
 // The cache pointers may come out of the device table (multi-sequence), so hipcc only knows them as generic pointers
@@ -1287,7 +1312,12 @@ __global__ __launch_bounds__(256) void k_dec_attn_score64(const unsigned long lo
     const int c = c0 + threadIdx.x;
     const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
     const int roff = (pw == 1) ? a.n_embd + g * dh : (pw == 2) ? a.n_embd + kv_dim + g * dh : h * dh;
-    const float raw = a.qkv_raw[roff + t];
+    float raw = a.qkv_raw[roff + t];
+    if (MULTI) {
+        // second K-split plane of the projections (wide path, k_dec_mmv): requested unconditionally (plane 0: the same word)
+        const float raw2 = a.qkv_raw[a.qkv_plane + roff + t];
+        raw += a.qkv_plane ? raw2 : 0.f;
+    }
     const float2 rot = a.rope_now[t & 31];
     __builtin_amdgcn_sched_barrier(0);            // these two come back first (vmcnt is in order): the head vectors are built while the K rows fly
     const int cs = min(c, a.max_ctx - 1);
@@ -1757,7 +1787,17 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     float qraw[NJ];
 #pragma unroll
     for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
-    const float kvraw = a.qkv_raw[a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+    float kvraw = a.qkv_raw[a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+    {
+        // second K-split plane of the projections (k_dec_mmv): requested unconditionally (plane 0: the same words again)
+        float qraw2[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw2[jj] = a.qkv_raw[a.qkv_plane + (g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+        const float kvraw2 = a.qkv_raw[a.qkv_plane + a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_plane ? qraw2[jj] : 0.f;
+        kvraw += a.qkv_plane ? kvraw2 : 0.f;
+    }
     const float2 rot = a.rope_now[t & 31];
     __builtin_amdgcn_sched_barrier(0);
     const int c = c0 + threadIdx.x;
@@ -2371,9 +2411,9 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
     return 0;
 }
 
-static size_t mmv_lds_bytes(int wt, int rt, int ft, int d_in)
+static size_t mmv_lds_bytes(int wt, int rt, int ft, int d_in, int ks)
 {
-    const size_t nb = (size_t)d_in / 32, sp = 16 * (size_t)rt, fr = 16 * (size_t)ft;
+    const size_t nb = (size_t)d_in / 32 / (size_t)ks, sp = 16 * (size_t)rt, fr = 16 * (size_t)ft;
     return std::max(fr * nb * (wt == GTEN_Q4 ? 16 : 32), 8 * sp * 64) + fr * nb * 2 + nb * sp * 4;
 }
 
@@ -2394,21 +2434,25 @@ static int launch_mmv_rt(int tag, const MmvArgs& a)
 {
     constexpr int FTW = (WT == GTEN_Q4 && RT <= 2) ? 4 : 2;
     const int ft = mmv_feature_tiles<WT, RT>(a);
-    const size_t smem = mmv_lds_bytes(WT, RT, ft, a.d_in);
+    const int ks = a.ks > 1 ? a.ks : 1;
+    GTR_REQUIRE((a.d_in / 32) % (8 * ks) == 0, "decoder: %d K slices do not divide the %d quant blocks into eight waves", ks, a.d_in / 32);
+    const size_t smem = mmv_lds_bytes(WT, RT, ft, a.d_in, ks);
     GTR_REQUIRE(smem <= 150 * 1024, "decoder: the slab and delta table of d_in %d x %d rows do not fit LDS", a.d_in, a.S);
     const int cols = a.d_out[0] + (a.n_mats > 1 ? a.d_out[1] : 0) + (a.n_mats > 2 ? a.d_out[2] : 0);
-    const int nbw = a.d_in / 256;                               // quant blocks per wave
-    const dim3 grid((cols + 16 * ft - 1) / (16 * ft));
+    const int nbw = a.d_in / 256 / ks;                          // quant blocks per wave
+    const dim3 grid((cols + 16 * ft - 1) / (16 * ft), ks);
     // activation chunks: all of a wave's blocks at once when that is 8 or fewer, else elevens (5632 / 256 = 22);
     // more than 32 rows or several feature tiles: fours (registers)
-    const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2]};
+    const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2], a.plane};
 #define MMV_ARGS a.aq, a.ad, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest
     if (ft > 1)
         DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, FTW>), grid, dim3(512), smem, MMV_ARGS);
     else if (RT > 2)
         DEC_LAUNCH(tag, (k_dec_mmv<WT, RT, 4, 1>), grid, dim3(512), smem, MMV_ARGS);
-    else if (nbw > 8 && nbw % 11 == 0)
+    else if (nbw % 11 == 0)
         DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 11, 1>), grid, dim3(512), smem, MMV_ARGS);
+    else if (nbw <= 4)
+        DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 4, 1>), grid, dim3(512), smem, MMV_ARGS);
     else
         DEC_LAUNCH(tag, (k_dec_mmv<WT, (RT > 2 ? 1 : RT), 8, 1>), grid, dim3(512), smem, MMV_ARGS);
 #undef MMV_ARGS
@@ -2422,6 +2466,7 @@ static int mmv_prepare()
     constexpr int FTA = (WT == GTEN_Q4) ? 4 : 2;        // <= 32 rows
 #define MMV_ATTR(RT_, CB_, FT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmv<WT, RT_, CB_, FT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
     MMV_ATTR(1, 8, 1); MMV_ATTR(2, 8, 1); MMV_ATTR(1, 11, 1); MMV_ATTR(2, 11, 1); MMV_ATTR(3, 4, 1); MMV_ATTR(4, 4, 1);
+    MMV_ATTR(1, 4, 1); MMV_ATTR(2, 4, 1);
     MMV_ATTR(1, 4, FTA); MMV_ATTR(2, 4, FTA); MMV_ATTR(3, 4, 2); MMV_ATTR(4, 4, 2);
 #undef MMV_ATTR
     return 0;
@@ -2467,6 +2512,19 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         a.n_mats = w2 ? 3 : (w1 ? 2 : 1); a.out = out; a.out_cols = out_cols; a.S = S; a.d_in = d_in;
         return launch_mmv<WT>(tag, a);
     };
+    // K split of the launches with few feature tiles (q|k|v, o, down): two workgroups per tile, two output planes that
+    // the consumers add (staging launches: raw_plane; grouped score kernel: qkv_plane).  GTEN_HIP_MMV_KSPLIT=1: off.
+    const char* kse = std::getenv("GTEN_HIP_MMV_KSPLIT");
+    const int ksplit = (kse && atoi(kse) == 1) ? 1 : 2;
+    auto mmk = [&](int tag, const int8_t* aq, const float* ad, float* out, int out_cols, int d_in, int ks, const void* w, int d_out,
+                   const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0) -> int {
+        MmvArgs a{};
+        a.aq = aq; a.ad = ad; a.w[0] = w; a.w[1] = w1; a.w[2] = w2; a.d_out[0] = d_out; a.d_out[1] = d1; a.d_out[2] = d2;
+        a.n_mats = w2 ? 3 : (w1 ? 2 : 1); a.out = out; a.out_cols = out_cols; a.S = S; a.d_in = d_in;
+        a.ks = ks; a.plane = S * out_cols;
+        return launch_mmv<WT>(tag, a);
+    };
+    auto ks_of = [&](int d_in) { return (ksplit > 1 && (d_in / 32) % (8 * ksplit) == 0) ? ksplit : 1; };
     for (int l = 0; l < d.n_layers; l++) {
         const gten_hip_layer_ptrs& L = dc->layers[l];
         Gemv8Args st = base;
@@ -2476,12 +2534,13 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
             st.table = d.embed; st.rope = dc->rope; st.rope_now = dc->rope_now; st.rope_half = dh / 2; st.n_vocab = V; st.tokens = dc->tokens;
             rc = launch_stage_frag<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
         } else {
-            st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E;
+            st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E; st.raw_plane = ks_of(F) > 1 ? S * E : 0;
             rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
         }
         if (rc) return rc;
         const int QW = E + 2 * KV;
-        if ((rc = mm(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->stg_sum, dc->qkv_raw, QW, E, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
+        const int ks_qkv = S <= 32 ? ks_of(E) : 1;             // (measured: 160 x 2 workgroups of 4 row tiles run slower than 160)
+        if ((rc = mmk(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->qkv_raw, QW, E, ks_qkv, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
         AttnArgs t{};
         t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
         t.att_part = dc->att_part; t.rope = dc->rope; t.rope_now = dc->rope_now;
@@ -2490,6 +2549,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         t.kv_tab = (const void* const*)dc->kv_tab; t.layer = l; t.n_layers = d.n_layers;
         t.qkv_stride = QW; t.scores_stride = d.n_heads * d.max_ctx; t.stats_stride = d.n_heads * dc->n_chunks * 2;
         t.part_stride = d.n_heads * dc->n_chunks * dh;
+        t.qkv_plane = ks_qkv > 1 ? S * QW : 0;
         const dim3 agrid(d.n_heads, dc->n_chunks, S);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
         if (!grouped_known) { grouped = attention_grouped_ok(t, S); grouped_known = true; }
@@ -2498,18 +2558,20 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
         if ((rc = launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
-        if ((rc = mm(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->stg_sum, dc->proj_raw, E, E, L.wo, E))) return rc;
+        if ((rc = mmk(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->proj_raw, E, E, ks_of(E), L.wo, E))) return rc;
         Gemv8Args sh = base;
         sh.d_in = E; sh.res_a = xbuf; sh.res_raw = dc->proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
+        sh.raw_plane = ks_of(E) > 1 ? S * E : 0;
         sh.norm_w = (const uint16_t*)L.ffn_norm;
         sh.act_q = dc->stg_q; sh.act_d = dc->stg_d; sh.act_sum = dc->stg_sum; sh.act_f = dc->stg_f;
         if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
         if ((rc = mm(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->stg_sum, dc->gu_raw, 2 * F, E, L.wgate, F, L.wup, F))) return rc;
         DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16, dc->act_q, dc->act_d, dc->act_sum);
-        if ((rc = mm(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->act_sum, dc->down_raw, E, F, L.wdown, E))) return rc;
+        if ((rc = mmk(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
     sf.d_in = E; sf.res_a = hbuf; sf.res_raw = dc->down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
+    sf.raw_plane = ks_of(F) > 1 ? S * E : 0;
     sf.act_q = dc->stg_q; sf.act_d = dc->stg_d; sf.act_sum = dc->stg_sum; sf.act_f = dc->stg_f;
     if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
     if ((rc = mm(KT_DEC_GEMV_HEAD, dc->stg_q, dc->stg_d, dc->stg_sum, dc->logits_m, V, E, d.lm_head, V))) return rc;
@@ -2583,9 +2645,10 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     GTR_CHECK(hipMemset(dc->tokens, 0, S * (size_t)(d.max_ctx + 1) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->result, S * (size_t)(d.max_ctx + 2) * 4));
     GTR_CHECK(hipMemset(dc->result, 0, S * (size_t)(d.max_ctx + 2) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, S * (size_t)(E + 2 * KV) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->proj_raw, S * (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->down_raw, S * (size_t)E * 4));
+    const size_t planes = wide ? 2 : 1;                       // k_dec_mmv may split K over two workgroups: one output plane each
+    GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, planes * S * (size_t)(E + 2 * KV) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->proj_raw, planes * S * (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->down_raw, planes * S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->scores, S * (size_t)d.n_heads * d.max_ctx * 4));
     GTR_CHECK(hipMalloc((void**)&dc->stats, (S * (size_t)d.n_heads * dc->n_chunks * 2 + 16) * 4));   // + 8 chunks of slack: the one-launch kernel reads 8 per head
     GTR_CHECK(hipMemset(dc->stats, 0, (S * (size_t)d.n_heads * dc->n_chunks * 2 + 16) * 4));

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x,
     // x / (rms + eps) * w evaluated as x * (1 / (rms + eps)) * w: one correctly
     // rounded reciprocal per row instead of a division per element (<= 1 ulp
     // apart before the row is rounded to the activation dtype)
-    const float inv = 1.0f / (sqrtf(ss / (float)d) + 1e-6f);
+    const float inv = recip_rn(sqrtf(ss / (float)d) + 1e-6f);      // == 1.0f / (...): correctly rounded either way
     for (int i = threadIdx.x; i < d; i += blockDim.x) v[i] = v[i] * inv * h2f(w[i]);
     __syncthreads();
     store_row(v, dtype, d, out + (size_t)r * out_pitch);
