@@ -998,14 +998,16 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
 // from k_dec_mmv as raw f32 rows [gate | up]); written in the fragment-major staging for the down projection.
 // Same chain as the EPI_SILUMUL epilogues above (gten/modules.cpp:238-247).  One thread per element, 32 lanes =
 // one Q8 block.
-__global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restrict__ gu_raw, int n_ffn, int rt,
+__global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restrict__ gu_raw, int n_ffn, int rt, int plane,
                                                           int8_t* __restrict__ out_q, float* __restrict__ out_d, int* __restrict__ out_sum)
 {
     const int q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;         // n_ffn % 256 == 0
     const float* row = gu_raw + (size_t)q * 2 * n_ffn;
-    float g = act_round32(row[e], false);                                  // gate projection written in the activation dtype
+    // (`plane` floats further: the second K-split plane of k_dec_mmv's partial sums; 0 = a single plane)
+    const float g0 = row[e], u0 = row[n_ffn + e], g1 = row[plane + e], u1 = row[plane + n_ffn + e];
+    float g = act_round32(plane ? g0 + g1 : g0, false);                    // gate projection written in the activation dtype
     g = act_round32(g / (1.0f + expf(-g)), false);                         // silu in place
-    const float u = act_round32(row[n_ffn + e], false);                    // up projection written
+    const float u = act_round32(plane ? u0 + u1 : u0, false);              // up projection written
     const float v = g * u;                                                 // mul in place, then written:
     const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
     const int qv = q8_round(v, sc.scale);
@@ -2565,8 +2567,12 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         sh.norm_w = (const uint16_t*)L.ffn_norm;
         sh.act_q = dc->stg_q; sh.act_d = dc->stg_d; sh.act_sum = dc->stg_sum; sh.act_f = dc->stg_f;
         if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
-        if ((rc = mm(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->stg_sum, dc->gu_raw, 2 * F, E, L.wgate, F, L.wup, F))) return rc;
-        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16, dc->act_q, dc->act_d, dc->act_sum);
+        // gate|up has 176-352 workgroups already; the split measured +4 % at 16 sequences, +2 % at 64, -2 % at 32
+        const char* kge = std::getenv("GTEN_HIP_MMV_KSPLIT_GU");
+        const int ks_gu = (kge ? atoi(kge) == 2 : (S + 15) / 16 != 2) ? ks_of(E) : 1;
+        if ((rc = mmk(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
+        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16,
+                   ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum);
         if ((rc = mmk(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
@@ -2674,7 +2680,7 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
         GTR_CHECK(hipMalloc((void**)&dc->stg_f, S * (size_t)E * 4));
         GTR_CHECK(hipMalloc((void**)&dc->logits_m, S * (size_t)d.n_vocab * 4));
         if (wide) {
-            GTR_CHECK(hipMalloc((void**)&dc->gu_raw, S * (size_t)2 * F * 4));
+            GTR_CHECK(hipMalloc((void**)&dc->gu_raw, planes * S * (size_t)2 * F * 4));
             if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) { delete dc; return rc; }
         }
         std::vector<const void*> tab(S * d.n_layers * 2);
