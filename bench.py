@@ -317,9 +317,13 @@ def main():
         ms = dt / K * 1e3
         bytes_step = algorithmic_bytes(args.mode, n_mid) + (S - 1) * (algorithmic_bytes(args.mode, n_mid) - algorithmic_bytes(args.mode, 0))
         fams = {}
-        for fam in ("decode_gemv_qkv", "decode_attn_score", "decode_attn_pv", "decode_gemv_o", "decode_gemv_gateup", "decode_gemv_down"):
-            us, per = batch.time_family(hip.prof_family_index(fam), N_CTX, 20)
-            fams[fam] = {"us": round(us, 2), "launches": per}
+        for fam in ("decode_stage", "decode_gemv_qkv", "decode_attn_score", "decode_attn_pv", "decode_gemv_o", "decode_gemv_gateup",
+                    "decode_gemv_down", "decode_gemv_head"):
+            try:
+                us, per = batch.time_family(hip.prof_family_index(fam), N_CTX, 20)
+                fams[fam] = {"us": round(us, 2), "launches": per}
+            except Exception:
+                pass                                 # a family this path does not launch
         res = {"streams": S, "tok_s": round(S * K / dt, 1), "ms_per_step": round(ms, 4),
                "speedup_vs_single": round(S * K / dt / tok_s, 2),
                "hbm": {"achieved": round(bytes_step / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",

@@ -131,6 +131,7 @@ def test_grouped_attention_is_bit_identical_to_per_head_kernels(hip, monkeypatch
     n_seq, N = 16, 270
     streams = [host.synthetic_tokens(N, seed=40 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
     runs = []
+    monkeypatch.setenv("GTEN_HIP_ATTN_EXACT", "1")     # 16 sequences and up fuse the p.V multiply-add by default
     for per_head in ("1", "0"):
         monkeypatch.setenv("GTEN_HIP_ATTN_PER_HEAD", per_head)
         batch = host.batch(cfg, n_seq)

@@ -1917,7 +1917,11 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     }
 }
 
-template <int GRP>
+// EXACT: every p.V term is rounded as the reference rounds it (multiply, then add: k_dec_attn_pv64's bytes) -- the
+// 8-sequence path, whose sequences are bit-identical to single-sequence decode.  The 16-64-sequence path already adds its
+// W.x block sums in another order (k_dec_mmv), and there the kernel is bound by exactly these two VALU operations per
+// (head, position, element): EXACT = false fuses them (one rounding instead of two: closer to the exact sum, not further).
+template <int GRP, bool EXACT>
 __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 {
     constexpr int dh = 64, NW = 17;
@@ -2011,10 +2015,17 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 #pragma unroll
         for (int j = 0; j < GRP; j++) {
             const float4 pp = *(const float4*)(p + j * DEC_CHUNK + cg * 64 + i);
-            acc[j] += pp.x * v[0];
-            acc[j] += pp.y * v[1];
-            acc[j] += pp.z * v[2];
-            acc[j] += pp.w * v[3];
+            if (EXACT) {
+                acc[j] += pp.x * v[0];
+                acc[j] += pp.y * v[1];
+                acc[j] += pp.z * v[2];
+                acc[j] += pp.w * v[3];
+            } else {
+                acc[j] = __builtin_fmaf(pp.x, v[0], acc[j]);
+                acc[j] = __builtin_fmaf(pp.y, v[1], acc[j]);
+                acc[j] = __builtin_fmaf(pp.z, v[2], acc[j]);
+                acc[j] = __builtin_fmaf(pp.w, v[3], acc[j]);
+            }
         }
     }
 #pragma unroll
@@ -2125,8 +2136,12 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
     const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
     const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4 + (size_t)(16 + 8 * GRP) * 4;
+    // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (GTEN_HIP_ATTN_EXACT=1)
+    const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
+    const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
     DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP>), grid, dim3(256), smem1, t);
-    DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP>), grid, dim3(256), smem2, t);
+    if (exact) DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP, true>), grid, dim3(256), smem2, t);
+    else DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP, false>), grid, dim3(256), smem2, t);
     return 0;
 }
 
