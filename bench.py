@@ -340,9 +340,12 @@ def main():
         if args.streams > 1:
             out["multi_stream"] = multi_stream(args.streams, "GEMV kernels: per sequence bit-identical to the single-sequence decoder "
                                                "(tests/test_multiseq_gpu.py)" if args.streams <= 8 else "W.x on the matrix cores (k_dec_mmv)")
-        if args.wide_streams > 1 and args.mode != "f16":
-            out["multi_stream_wide"] = multi_stream(args.wide_streams, "W.x of the step as int8 MFMA GEMV (k_dec_mmv, rows = sequences), "
-                                                    "GQA-grouped attention; per sequence inside the model band around single-sequence decode, "
+        if args.wide_streams > 1:
+            out["multi_stream_wide"] = multi_stream(args.wide_streams,
+                                                    ("W.x of the step on v_mfma_f32_16x16x32_f16 (k_dec_mmv_f16, rows = sequences), per-head attention; "
+                                                     if args.mode == "f16" else
+                                                     "W.x of the step as int8 MFMA GEMV (k_dec_mmv, rows = sequences), GQA-grouped attention; ") +
+                                                    "per sequence inside the model band around single-sequence decode, "
                                                     "graph == eager bit for bit (tests/test_multiseq_gpu.py)")
         model = host.model(cfg)
         model.load_synthetic(args.seed)

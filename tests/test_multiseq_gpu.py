@@ -70,7 +70,7 @@ def test_multiseq_graph_replay_equals_eager(hip):
     assert res[0] == res[1]
 
 
-@pytest.mark.parametrize("name,wd,ad", [m for m in MODES() if m[0] != "f16"])
+@pytest.mark.parametrize("name,wd,ad", MODES())
 @pytest.mark.parametrize("n_seq", [16, 32])
 def test_wide_batch_on_matrix_cores_tracks_single_sequence_decode(hip, name, wd, ad, n_seq):
     """n_seq >= 16: every W.x of the step is a skinny matrix product on the matrix cores (rows = sequences).  The

@@ -496,7 +496,15 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
         }
         if (F16W) {
             act_roundN<WT, EPT>(v);
-            if (on) stN<EPT>(s.row + base, v);            // staged as f32 (exact f16 values)
+            if (EPI == EPI_STAGE_FRAG) {
+                // wide f16 decode (k_dec_mmv_f16): the row as f16, [sequence][d] -- an MFMA A operand is then one 16-byte load
+                if (on) {
+                    uint16_t* dst = (uint16_t*)a.act_q + (size_t)seq * d + base;
+                    if (EPT == 8) *(uint4*)dst = make_uint4(f2h(v[0]) | ((unsigned)f2h(v[1]) << 16), f2h(v[2]) | ((unsigned)f2h(v[3]) << 16),
+                                                            f2h(v[EPT - 4]) | ((unsigned)f2h(v[EPT - 3]) << 16), f2h(v[EPT - 2]) | ((unsigned)f2h(v[EPT - 1]) << 16));
+                    else *(uint2*)dst = make_uint2(f2h(v[0]) | ((unsigned)f2h(v[1]) << 16), f2h(v[2]) | ((unsigned)f2h(v[3]) << 16));
+                }
+            } else if (on) stN<EPT>(s.row + base, v);     // staged as f32 (exact f16 values)
         } else if (on) {
             if (EPI == EPI_STAGE_FRAG) q8_stage_frag<EPT>(v, blk, sub, ActFrag{a.act_q, a.act_d, a.act_sum, a.frag_rt, seq});
             else q8_stageN<EPT>(v, blk, sub, s.q8);
@@ -1015,6 +1023,94 @@ __global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restric
     const int b = e >> 5, k = e & 31;
     out_q[(((size_t)b * rt + (q >> 4)) * 64 + (k >> 3) * 16 + (q & 15)) * 8 + (k & 7)] = (int8_t)qv;
     if (k == 0) { out_d[(size_t)b * 16 * rt + q] = sc.ddeq; out_sum[(size_t)b * 16 * rt + q] = qs; }
+}
+
+// ---- the same launch shape for f16 weights x f16 activations (wide decode of the f16 configuration): a workgroup owns 16
+// output features for all rows (sequences), its eight waves split the workgroup's K range (gridDim.y K slices, as in
+// k_dec_mmv), one v_mfma_f32_16x16x32_f16 per (row tile, 32 elements of K) accumulating in the matrix core.  No LDS in the
+// K loop: a weight fragment is used once (16 bytes straight from HBM: lane (l16, g) reads feature l16, elements 8 g .. 8 g + 7
+// of the step), an activation fragment is 16 bytes of the staged f16 row (L2).  Requests run CBK steps ahead of the
+// arithmetic.  The eight K ranges are added in wave order, the slices by the consumer: deterministic.
+typedef _Float16 mmv_h8 __attribute__((ext_vector_type(8)));
+typedef float mmv_f4 __attribute__((ext_vector_type(4)));
+
+template <int RT>
+__global__ __launch_bounds__(512) void k_dec_mmv_f16(const uint16_t* __restrict__ a_ah, const void* __restrict__ a_w0, float* __restrict__ a_out,
+                                                     const int a_d_in, const int a_d_out0, const int a_out_cols, const int a_S,
+                                                     const int a_n_mats, const MmvRest rest)
+{
+    constexpr int SP = 16 * RT, CBK = 4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    float* red = (float*)g_smem;                              // [8][SP][16]
+    int colw = blockIdx.x * 16, colbase = 0, m = 0;
+    if (a_n_mats > 1 && colw >= a_d_out0) {
+        colw -= a_d_out0; colbase = a_d_out0; m = 1;
+        if (a_n_mats > 2 && colw >= rest.d_out1) { colw -= rest.d_out1; colbase += rest.d_out1; m = 2; }
+    }
+    const uint16_t* w = (const uint16_t*)((m == 0) ? a_w0 : (m == 1) ? rest.w1 : rest.w2);
+    const int d_out = (m == 0) ? a_d_out0 : (m == 1) ? rest.d_out1 : rest.d_out2;
+    const int ksl = a_d_in / (int)gridDim.y, kw = ksl >> 3;   // K elements of this workgroup / of each wave (kw % 32 == 0)
+    const int k_lo = (int)blockIdx.y * ksl + wid * kw, steps = kw >> 5;
+    const uint16_t* wrow = w + (size_t)min(colw + l16, d_out - 1) * a_d_in + k_lo + 8 * g;
+    const uint16_t* arow = a_ah + (size_t)l16 * a_d_in + k_lo + 8 * g;
+    mmv_f4 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; t++) acc[t] = mmv_f4{0.f, 0.f, 0.f, 0.f};
+    uint4 bw[CBK], aw[CBK][RT];
+    auto request = [&](int s0) {
+#pragma unroll
+        for (int c = 0; c < CBK; c++) {
+            const int st = min(s0 + c, steps - 1);
+            bw[c] = *(const uint4*)(wrow + 32 * st);
+#pragma unroll
+            for (int t = 0; t < RT; t++) aw[c][t] = *(const uint4*)(arow + (size_t)16 * t * a_d_in + 32 * st);
+        }
+    };
+    request(0);
+    for (int s0 = 0; s0 < steps; s0 += CBK) {
+        uint4 bq[CBK], aq[CBK][RT];
+#pragma unroll
+        for (int c = 0; c < CBK; c++) {
+            bq[c] = bw[c];
+#pragma unroll
+            for (int t = 0; t < RT; t++) aq[c][t] = aw[c][t];
+        }
+        if (s0 + CBK < steps) request(s0 + CBK);
+#pragma unroll
+        for (int c = 0; c < CBK; c++) {
+            if (s0 + c < steps) {                             // (uniform) the ragged last chunk
+                const mmv_h8 bh = __builtin_bit_cast(mmv_h8, bq[c]);
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mmv_h8, aq[c][t]), bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[(wid * SP + 16 * t + 4 * g + i) * 16 + l16] = acc[t][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < SP * 16; idx += 512) {
+        const int r = idx >> 4, c = idx & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
+        if (r < a_S && colw + c < d_out) a_out[(size_t)blockIdx.y * rest.plane + (size_t)r * a_out_cols + colbase + colw + c] = v;
+    }
+}
+
+// silu(write(gate)) * write(up) for S rows, f16 activations: element-wise (gten/modules.cpp:238-247), written as the f16
+// rows the down projection's matrix-core launch reads
+__global__ __launch_bounds__(256) void k_dec_silumul_rows_f16(const float* __restrict__ gu_raw, int n_ffn, int plane, uint16_t* __restrict__ out_h)
+{
+    const int q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    const float* row = gu_raw + (size_t)q * 2 * n_ffn;
+    const float g0 = row[e], u0 = row[n_ffn + e], g1 = row[plane + e], u1 = row[plane + n_ffn + e];
+    float g = h2f(f2h(plane ? g0 + g1 : g0));
+    g = h2f(f2h(g / (1.0f + expf(-g))));
+    const float u = h2f(f2h(plane ? u0 + u1 : u0));
+    out_h[(size_t)q * n_ffn + e] = f2h(g * u);
 }
 
 // ------------------------------------------------------------- attention
@@ -2496,18 +2592,40 @@ static int mmv_prepare()
     return 0;
 }
 
+template <int RT>
+static int launch_mmv_f16_rt(int tag, const MmvArgs& a)
+{
+    const int ks = a.ks > 1 ? a.ks : 1;
+    GTR_REQUIRE(a.d_in % (256 * ks) == 0, "decoder: %d K slices x eight waves do not divide d_in %d into 32-element steps", ks, a.d_in);
+    const int cols = a.d_out[0] + (a.n_mats > 1 ? a.d_out[1] : 0) + (a.n_mats > 2 ? a.d_out[2] : 0);
+    const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2], a.plane};
+    DEC_LAUNCH(tag, (k_dec_mmv_f16<RT>), dim3((cols + 15) / 16, ks), dim3(512), (size_t)8 * 16 * RT * 16 * 4,
+               (const uint16_t*)a.aq, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
+    return 0;
+}
+
 template <int WT>
 static int launch_mmv(int tag, const MmvArgs& a)
 {
     GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && a.S <= 64, "decoder: skinny W.x wants d_in %% 256 == 0 and <= 64 rows");
+    if (WT == GTEN_F16) {
+        for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
+        switch ((a.S + 15) / 16) {
+        case 1: return launch_mmv_f16_rt<1>(tag, a);
+        case 2: return launch_mmv_f16_rt<2>(tag, a);
+        case 3: return launch_mmv_f16_rt<3>(tag, a);
+        default: return launch_mmv_f16_rt<4>(tag, a);
+        }
+    }
     GTR_REQUIRE((size_t)16 * (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) <= (size_t)MMV_MAXP * 512 * 16 && (size_t)(a.d_in / 32) * 64 * 4 <= (size_t)MMV_MAXD * 512 * 16,
                 "decoder: d_in %d too long for the weight slab / delta table", a.d_in);
     for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
+    constexpr int WQ = (WT == GTEN_F16) ? GTEN_Q8 : WT;        // (never reached for f16: keeps k_dec_mmv<f16> from being instantiated)
     switch ((a.S + 15) / 16) {
-    case 1: return launch_mmv_rt<WT, 1>(tag, a);
-    case 2: return launch_mmv_rt<WT, 2>(tag, a);
-    case 3: return launch_mmv_rt<WT, 3>(tag, a);
-    default: return launch_mmv_rt<WT, 4>(tag, a);
+    case 1: return launch_mmv_rt<WQ, 1>(tag, a);
+    case 2: return launch_mmv_rt<WQ, 2>(tag, a);
+    case 3: return launch_mmv_rt<WQ, 3>(tag, a);
+    default: return launch_mmv_rt<WQ, 4>(tag, a);
     }
 }
 
@@ -2593,8 +2711,12 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         const char* kge = std::getenv("GTEN_HIP_MMV_KSPLIT_GU");
         const int ks_gu = (kge ? atoi(kge) == 2 : (S + 15) / 16 != 2) ? ks_of(E) : 1;
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
-        DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16,
-                   ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum);
+        if (WT == GTEN_F16)
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows_f16, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F,
+                       ks_gu > 1 ? S * 2 * F : 0, (uint16_t*)dc->act_q);
+        else
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16,
+                       ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum);
         if ((rc = mmk(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
@@ -2616,7 +2738,7 @@ static int enqueue_multi(gten_hip_decoder* dc)
     case 4: return enqueue_step_multi<WT, 4>(dc);
     case 8: return enqueue_step_multi<WT, 8>(dc);
     }
-    if (dc->n_seq >= 16 && WT != GTEN_F16) return enqueue_step_wide<WT>(dc);
+    if (dc->n_seq >= 16) return enqueue_step_wide<WT>(dc);
     return fail(-4, "decoder: n_seq %d not supported for this configuration", dc->n_seq);
 }
 
@@ -2655,8 +2777,8 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     const bool wide = n_seq >= 16;
     GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8 || (wide && n_seq <= 64 && n_seq % 16 == 0),
                 "decoder_create: n_seq %d not in {1, 2, 4, 8, 16, 32, 48, 64}", n_seq);
-    GTR_REQUIRE(!wide || (d.wdtype != GTEN_F16 && d.n_ffn % 256 == 0 && d.n_embd % 256 == 0 && (dh * d.n_kv_heads) % 16 == 0),
-                "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: quantized weights, n_embd and n_ffn %% 256 == 0");
+    GTR_REQUIRE(!wide || (d.n_ffn % 256 == 0 && d.n_embd % 256 == 0 && (dh * d.n_kv_heads) % 16 == 0),
+                "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: n_embd and n_ffn %% 256 == 0");
     GTR_REQUIRE(n_seq == 1 || (kv && dh == 64), "decoder_create: multi-sequence decode needs the cache table and d_head 64");
     GTR_REQUIRE(n_seq > 1 || d.logits, "decoder_create: null logits pointer");
     auto* dc = new gten_hip_decoder;
@@ -2684,7 +2806,10 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     // residual rows between kernels: f32 rows of exact storage values
     GTR_CHECK(hipMalloc((void**)&dc->xbuf, S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->hbuf, S * (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->act_q, S * (size_t)F));
+    // (wide f16 decode keeps its staged rows as f16 matrices of 16-row tiles: 2 bytes per element, rows padded to the tile)
+    const size_t stage_rows = (wide && d.wdtype == GTEN_F16) ? 2 * ((S + 15) / 16 * 16) : S;
+    GTR_CHECK(hipMalloc((void**)&dc->act_q, stage_rows * (size_t)F));
+    GTR_CHECK(hipMemset(dc->act_q, 0, stage_rows * (size_t)F));
     GTR_CHECK(hipMalloc((void**)&dc->act_d, S * (size_t)(F / 32) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->act_sum, S * (size_t)(F / 32) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->act_f, S * (size_t)F * 4));
@@ -2696,14 +2821,16 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     GTR_CHECK(hipMalloc((void**)&dc->best_val, S * (size_t)dc->n_best * 4));
     GTR_CHECK(hipMalloc((void**)&dc->best_idx, S * (size_t)dc->n_best * 4));
     if (n_seq > 1) {
-        GTR_CHECK(hipMalloc((void**)&dc->stg_q, S * (size_t)E));
+        GTR_CHECK(hipMalloc((void**)&dc->stg_q, stage_rows * (size_t)E));
+        GTR_CHECK(hipMemset(dc->stg_q, 0, stage_rows * (size_t)E));
         GTR_CHECK(hipMalloc((void**)&dc->stg_d, S * (size_t)(E / 32) * 4));
         GTR_CHECK(hipMalloc((void**)&dc->stg_sum, S * (size_t)(E / 32) * 4));
         GTR_CHECK(hipMalloc((void**)&dc->stg_f, S * (size_t)E * 4));
         GTR_CHECK(hipMalloc((void**)&dc->logits_m, S * (size_t)d.n_vocab * 4));
         if (wide) {
             GTR_CHECK(hipMalloc((void**)&dc->gu_raw, planes * S * (size_t)2 * F * 4));
-            if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) { delete dc; return rc; }
+            if (d.wdtype != GTEN_F16)
+                if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) { delete dc; return rc; }
         }
         std::vector<const void*> tab(S * d.n_layers * 2);
         for (size_t q = 0; q < S; q++)
