@@ -1861,17 +1861,17 @@ __global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsi
 // reduction order are those of k_dec_attn_score64 / k_dec_attn_pv64: byte-identical scores, statistics and outputs.
 #define DEC_MAXGRP 8
 
-template <int GRP>
+template <int GRP, int ADT>
 __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 {
     // grid = (sequence, chunk, kv head): the workgroups of a SHORT context's few live chunks are consecutive
     // sequence indices, i.e. spread over all XCDs (with the kv head in x they were 4 of every 32 workgroups: half
     // the chip idle at n <= 256)
-    constexpr int dh = 64, nblk = 2, NW = 17;
+    constexpr int dh = 64, nblk = 2, NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice (Q8 blocks | f16)
     const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
     const AttnArgs a = attn_for_seq(a0, blockIdx.x);              // (the cache pointers and the position are requested together)
     const int kv_dim = a.n_kv * dh;
-    const size_t head_bytes = (size_t)nblk * GTEN_Q8_BYTES;
+    const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
 
     float* red = (float*)g_smem;                                  // [2][4][GRP]: maxima, then sums
     float* qd = red + 8 * GRP;                                    // [GRP][2] (+ pad to 4)
@@ -1881,6 +1881,8 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     int8_t* qi8 = (int8_t*)(d16 + 4 * (GRP + 2));                 // [GRP][64]
     int8_t* ki8 = qi8 + GRP * dh;                                 // 64
     int8_t* vi8 = ki8 + dh;                                       // 64
+    float* qfa = (float*)(((uintptr_t)(vi8 + dh) + 15) & ~(uintptr_t)15);   // f16 activations: [GRP][64] q values, then the new k row [64]
+    float* kfa = qfa + GRP * dh;
 
     // ---- requests, none of which needs the context length: the raw projections this wave turns into head vectors
     //      (wave w: query heads w, w + 4; wave 0 also the new k row, wave 1 the new v row), the rotation of the
@@ -1919,14 +1921,23 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 #pragma unroll
     for (int jj = 0; jj < NJ; jj++) {
         const int j = pw + 4 * jj;
-        if (j < GRP) (void)head_prep_cs(qraw[jj], true, true, rot, dh, GTEN_Q8, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+        if (j < GRP) {
+            const float v = head_prep_cs(qraw[jj], true, true, rot, dh, ADT, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+            if (ADT != GTEN_Q8) qfa[j * dh + t] = v;
+        }
     }
     if (pw < 2 && has_new) {
         int8_t* dq = pw ? vi8 : ki8;
-        (void)head_prep_cs(kvraw, true, pw == 0, rot, dh, GTEN_Q8, dq, kd + 4 * pw, d16 + 4 * (GRP + pw));
-        uint8_t* blk = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-        store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
-        if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
+        const float v = head_prep_cs(kvraw, true, pw == 0, rot, dh, ADT, dq, kd + 4 * pw, d16 + 4 * (GRP + pw));
+        uint8_t* row = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+        if (ADT == GTEN_Q8) {
+            uint8_t* blk = row + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+            store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
+            if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
+        } else {
+            if (pw == 0) kfa[t] = v;
+            store_global<uint16_t>((uint16_t*)row + t, f2h(v));
+        }
     }
     __syncthreads();
 
@@ -1935,7 +1946,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     //      from the chip -- uniform control flow, same arithmetic
     const float scale = 1.0f / sqrtf((float)dh);
     float sc[GRP];
-    {
+    if (ADT == GTEN_Q8) {
         const float kd0 = h2f((uint16_t)(kw[0] & 0xffffu)), kd1 = h2f((uint16_t)(kw[8] >> 16));
         int kq[16];
 #pragma unroll
@@ -1957,21 +1968,42 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
             acc += (float)isum * (qd[2 * j + 1] * kd1);
             sc[j] = acc * scale;
         }
+    } else {
+        // f16: the elements in order, as k_dec_attn_score64 adds them; a K element is converted once for all heads
+        float acc[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; j++) acc[j] = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; k++) {
+            const float k0 = h2f((uint16_t)(kw[k] & 0xffffu)), k1 = h2f((uint16_t)(kw[k] >> 16));
+#pragma unroll
+            for (int j = 0; j < GRP; j++) {
+                const float2 q2 = *(const float2*)(qfa + j * dh + 2 * k);
+                acc[j] += q2.x * k0;
+                acc[j] += q2.y * k1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; j++) sc[j] = acc[j] * scale;
     }
     if (has_new) {
         const int* ki = (const int*)ki8;
 #pragma unroll
         for (int j = 0; j < GRP; j++) {
-            const int* qi = (const int*)(qi8 + j * dh);
             float acc = 0.f;
-            int isum = 0;
+            if (ADT == GTEN_Q8) {
+                const int* qi = (const int*)(qi8 + j * dh);
+                int isum = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) isum = dot4(qi[k], ki[k], isum);
-            acc += (float)isum * (qd[2 * j] * kd[0]);
-            isum = 0;
+                for (int k = 0; k < 8; k++) isum = dot4(qi[k], ki[k], isum);
+                acc += (float)isum * (qd[2 * j] * kd[0]);
+                isum = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], ki[8 + k], isum);
-            acc += (float)isum * (qd[2 * j + 1] * kd[1]);
+                for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], ki[8 + k], isum);
+                acc += (float)isum * (qd[2 * j + 1] * kd[1]);
+            } else {
+                for (int e = 0; e < dh; e++) acc += qfa[j * dh + e] * kfa[e];
+            }
             if (c == pos) sc[j] = acc * scale;
         }
     }
@@ -2017,13 +2049,13 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 // 8-sequence path, whose sequences are bit-identical to single-sequence decode.  The 16-64-sequence path already adds its
 // W.x block sums in another order (k_dec_mmv), and there the kernel is bound by exactly these two VALU operations per
 // (head, position, element): EXACT = false fuses them (one rounding instead of two: closer to the exact sum, not further).
-template <int GRP, bool EXACT>
+template <int GRP, bool EXACT, int ADT>
 __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 {
-    constexpr int dh = 64, NW = 17;
+    constexpr int dh = 64, NW = (ADT == GTEN_Q8) ? 17 : 32;           // dwords per kv-head slice (Q8 blocks | f16)
     const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
     const AttnArgs a = attn_for_seq(a0, blockIdx.x);
-    const size_t head_bytes = (size_t)2 * GTEN_Q8_BYTES;
+    const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)2 * GTEN_Q8_BYTES : (size_t)dh * 2;
 
     float* p = (float*)g_smem;                                    // [GRP][4][64]: position c at [c & 3][c >> 2]
     float* part = p + GRP * DEC_CHUNK;                            // [GRP][256]
@@ -2085,8 +2117,14 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 #pragma unroll
     for (int j = 0; j < GRP; j++) {
         const float x = (c < n) ? expf(scv[j] - ms[2 * j]) / ms[2 * j + 1] : 0.f;
-        const Q8Scale qs = q8_scale_from_absmax(max32(fabsf(x)));
-        p[j * DEC_CHUNK + (threadIdx.x & 3) * 64 + (threadIdx.x >> 2)] = (c < n) ? (float)q8_round(x, qs.scale) * qs.ddeq : 0.f;
+        float pr;
+        if (ADT == GTEN_Q8) {
+            const Q8Scale qs = q8_scale_from_absmax(max32(fabsf(x)));
+            pr = (c < n) ? (float)q8_round(x, qs.scale) * qs.ddeq : 0.f;
+        } else {
+            pr = h2f(f2h(x));
+        }
+        p[j * DEC_CHUNK + (threadIdx.x & 3) * 64 + (threadIdx.x >> 2)] = pr;
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
@@ -2105,8 +2143,8 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             // positions past the chunk's end read a valid (clamped) row and meet p = 0
-            const uint8_t* row = vb + (size_t)min(cg + 4 * (i + u), DEC_CHUNK - 1) * 68;
-            v[u] = (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff));
+            const uint8_t* row = vb + (size_t)min(cg + 4 * (i + u), DEC_CHUNK - 1) * (NW * 4);
+            v[u] = (ADT == GTEN_Q8) ? (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)) : h2f(((const uint16_t*)row)[e]);
         }
 #pragma unroll
         for (int j = 0; j < GRP; j++) {
@@ -2223,38 +2261,63 @@ static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
     const bool off = e && e[0] == '1';
     const char* m = std::getenv("GTEN_HIP_ATTN_GROUPED_MIN");   // fewest sequences that take the grouped kernels
     const int min_seq = (m && atoi(m) > 1) ? atoi(m) : 8;        // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
-    return !off && n_seq >= min_seq && t.adtype == GTEN_Q8 && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
-}
-
-template <int GRP>
-static int launch_attention_g(const AttnArgs& t, int n_seq)
-{
-    const dim3 grid(n_seq, t.n_chunks, t.n_kv);
-    const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64;
-    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * 17 * 4 + (size_t)(16 + 8 * GRP) * 4;
-    // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (GTEN_HIP_ATTN_EXACT=1)
-    const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
-    const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
-    DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP>), grid, dim3(256), smem1, t);
-    if (exact) DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP, true>), grid, dim3(256), smem2, t);
-    else DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP, false>), grid, dim3(256), smem2, t);
-    return 0;
-}
-
-static int launch_attention_grouped(const AttnArgs& t, int n_seq)
-{
-    switch (t.n_heads / t.n_kv) {
-    case 8: return launch_attention_g<8>(t, n_seq);
-    case 4: return launch_attention_g<4>(t, n_seq);
-    case 2: return launch_attention_g<2>(t, n_seq);
-    default: return launch_attention_g<1>(t, n_seq);
-    }
+    return !off && n_seq >= min_seq && (t.adtype == GTEN_Q8 || t.adtype == GTEN_F16) && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
 }
 
 static int grp_shift1_of(int n_heads, int n_kv)
 {
     const int grp = n_heads / n_kv;
     return (grp > 0 && (grp & (grp - 1)) == 0) ? __builtin_ctz(grp) + 1 : 0;
+}
+
+template <int GRP, int ADT>
+static int launch_attention_g(const AttnArgs& t, int n_seq)
+{
+    constexpr size_t NW = (ADT == GTEN_Q8) ? 17 : 32;
+    const dim3 grid(n_seq, t.n_chunks, t.n_kv);
+    const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64 +
+                         (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4 + 16);
+    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
+    // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (GTEN_HIP_ATTN_EXACT=1)
+    const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
+    const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
+    if (smem2 > 64 * 1024) {
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, true, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, false, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+    }
+    if (ADT == GTEN_F16) {
+        // f16 scores are 2 VALU operations per (head, position, element) however the heads are grouped (f32 products added in
+        // element order): the per-head kernel spreads them over 8x the workgroups and measured faster (16 / 32 sequences:
+        // 20.7 / 36.1 us against 30.2 / 53.8) -- same scores, statistics and cache rows, so p.V below can still be grouped
+        AttnArgs t1 = t;
+        t1.grp_shift1 = grp_shift1_of(t.n_heads, t.n_kv);
+        const AttnHotWords none{{0, 0, 0, 0, 0, 0, 0}};
+        const size_t smem_s = (size_t)(16 + 3 * 64 + 16) * 4 + 32 + (size_t)3 * 64 + 64;
+        DEC_LAUNCH_HOT(KT_DEC_ATTN_SCORE, (k_dec_attn_score64<GTEN_F16, true>), dim3(t.n_chunks, t.n_heads, n_seq), dim3(256), smem_s, none, t1);
+    } else {
+        DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_g<GRP, ADT>), grid, dim3(256), smem1, t);
+    }
+    if (exact) DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP, true, ADT>), grid, dim3(256), smem2, t);
+    else DEC_LAUNCH(KT_DEC_ATTN_PV, (k_dec_attn_pv_g<GRP, false, ADT>), grid, dim3(256), smem2, t);
+    return 0;
+}
+
+static int launch_attention_grouped(const AttnArgs& t, int n_seq)
+{
+    if (t.adtype == GTEN_Q8) {
+        switch (t.n_heads / t.n_kv) {
+        case 8: return launch_attention_g<8, GTEN_Q8>(t, n_seq);
+        case 4: return launch_attention_g<4, GTEN_Q8>(t, n_seq);
+        case 2: return launch_attention_g<2, GTEN_Q8>(t, n_seq);
+        default: return launch_attention_g<1, GTEN_Q8>(t, n_seq);
+        }
+    }
+    switch (t.n_heads / t.n_kv) {
+    case 8: return launch_attention_g<8, GTEN_F16>(t, n_seq);
+    case 4: return launch_attention_g<4, GTEN_F16>(t, n_seq);
+    case 2: return launch_attention_g<2, GTEN_F16>(t, n_seq);
+    default: return launch_attention_g<1, GTEN_F16>(t, n_seq);
+    }
 }
 
 static int launch_attention(const AttnArgs& t0, dim3 agrid, size_t smem1)
