@@ -119,6 +119,37 @@ def test_wide_batch_on_matrix_cores_tracks_single_sequence_decode(hip, name, wd,
     assert not np.array_equal(runs[0][N][0][1], runs[0][N][1][1])       # independent sequences
 
 
+def test_wide_batch_k_split_planes_agree_with_single_plane(hip, monkeypatch):
+    """k_dec_mmv splits K over two workgroups per feature tile and the consumers add the two planes of partial sums
+    (default); GTEN_HIP_MMV_KSPLIT=1 keeps one workgroup and one plane.  Same block sums, one more f32 association:
+    the logits of both runs agree to summation-order noise and the greedy ids are equal."""
+    from helpers import Q4, Q8
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_embd=512, n_ffn=1024, n_heads=8, n_kv_heads=2, max_ctx=64, n_layers=2))
+    n_seq, N = 16, 24
+    streams = [host.synthetic_tokens(N, seed=900 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
+    runs = []
+    for ks in ("1", "2"):
+        monkeypatch.setenv("GTEN_HIP_MMV_KSPLIT", ks)
+        monkeypatch.setenv("GTEN_HIP_MMV_KSPLIT_GU", ks)
+        batch = host.batch(cfg, n_seq)
+        for i in range(len(cfg.weight_shapes())):
+            batch.set_weight(i, host.synth_weight(cfg, 31, i))
+        for q in range(n_seq):
+            batch.decode_begin(q, streams[q])
+        for n in range(1, N + 1):
+            batch.decode_step(n, True)
+        runs.append([(batch.decode_result(q, N), batch.logits(q).copy()) for q in range(n_seq)])
+        batch.close()
+    for (ra, la), (rb, lb) in zip(*runs):
+        scale = float(np.abs(la).max())
+        assert float(np.abs(la - lb).max()) <= 2e-2 * max(scale, 1.0)
+        top2 = np.sort(la)[-2:]
+        if top2[1] - top2[0] > 0.05 * float(la.std()):
+            assert ra == rb
+
+
 @pytest.mark.parametrize("heads,kv", [(8, 1), (4, 2), (4, 4)])
 def test_grouped_attention_is_bit_identical_to_per_head_kernels(hip, monkeypatch, heads, kv):
     """wide decode serves all query heads of a kv group from one workgroup (k_dec_attn_score_g / _pv_g): the same
