@@ -142,6 +142,39 @@ def test_rowwise_ops(hip, oracle, ad, d):
         assert np.array_equal(out.download(shape=x.shape), want), "add must be bit-exact"
 
 
+@pytest.mark.parametrize("d", [2048, 5632])
+def test_rowwise_ops_many_rows_block_pair_kernel(hip, oracle, d):
+    """prompt-sized calls of silu / mul / add on Q8 rows take the block-pair kernel (k_elementwise_q8x2: 17 dwords per
+    pair of blocks, everything in registers): the same bytes as the oracle for mul and add, silu inside its tolerance,
+    out of place and in place, from a start row"""
+    r = rng(7 * d)
+    n = 24
+    x, _ = act_rows(oracle, r, n, d, Q8)
+    y, _ = act_rows(oracle, r, n, d, Q8)
+    xd, yd = hip.upload(x), hip.upload(y)
+    for sp in (0, 5):
+        want = np.zeros_like(x)
+        out = hip.upload(np.zeros_like(x))
+        oracle.mul(x, y, want, Q8, n, d, sp)
+        hip.mul(xd, yd, out, Q8, n, d, sp)
+        assert np.array_equal(out.download(shape=x.shape), want), "mul must be bit-exact"
+        want = np.zeros_like(x)
+        out.zero()
+        oracle.add(x, y, want, Q8, n, d, sp)
+        hip.add(xd, yd, out, Q8, n, d, sp)
+        assert np.array_equal(out.download(shape=x.shape), want), "add must be bit-exact"
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.add(want, y, want, Q8, n, d, sp)
+        hip.add(buf, yd, buf, Q8, n, d, sp)
+        assert np.array_equal(buf.download(shape=x.shape), want), "add_inplace must be bit-exact"
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.silu(want, want, Q8, n, d, sp)
+        hip.silu(buf, buf, Q8, n, d, sp)
+        compare_rows(buf.download(shape=x.shape), want, Q8, d, "silu_inplace", min_exact=0.995)
+
+
 def test_rope_last_position(hip, oracle):
     """position 2047: the angle table comes from host libm like the reference's"""
     r = rng(13)

@@ -210,6 +210,88 @@ __global__ __launch_bounds__(256) void k_elementwise(const uint8_t* a, const uin
     store_row(v, dtype, d, out + (size_t)r * pitch);
 }
 
+// The same three operators for Q8 rows of many blocks (prompt processing: 2048 rows x 5632 elements per call): one thread
+// per PAIR of adjacent Q8 blocks.  A pair is 68 bytes, always 4-byte aligned, so it travels as 17 dwords each way
+// (the byte-per-lane loads of k_elementwise reach a fifth of the memory rate); dequantize, operate and re-quantize in
+// registers -- the block absmax needs no cross-lane step.  Per element the arithmetic is k_elementwise's: bit-identical.
+template <int OP>
+__global__ __launch_bounds__(256) void k_elementwise_q8x2(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* out,
+                                                          size_t pitch, int pairs_per_row, int start_pos, int total_pairs)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_pairs) return;
+    const int r = start_pos + gid / pairs_per_row, pr = gid % pairs_per_row;
+    const size_t off = (size_t)r * pitch + (size_t)pr * 68;
+    unsigned aw[17], bw[17];
+    const unsigned* ap = (const unsigned*)(a + off);
+#pragma unroll
+    for (int j = 0; j < 17; j++) aw[j] = ap[j];
+    if (OP != EW_SILU) {
+        const unsigned* bp = (const unsigned*)(b + off);
+#pragma unroll
+        for (int j = 0; j < 17; j++) bw[j] = bp[j];
+    }
+    unsigned ow[17];
+    unsigned d16o[2];
+    unsigned pq[2][8];
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        // pair bytes: [d0 | q0 x32 | d1 | q1 x32]; q0 straddles the dwords by 2 bytes
+        const float da = blk ? h2f((uint16_t)(aw[8] >> 16)) : h2f((uint16_t)(aw[0] & 0xffffu));
+        const float db = (OP == EW_SILU) ? 0.f : (blk ? h2f((uint16_t)(bw[8] >> 16)) : h2f((uint16_t)(bw[0] & 0xffffu)));
+        float v[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned qa = blk ? aw[9 + j] : __builtin_amdgcn_alignbit(aw[j + 1], aw[j], 16);
+            const unsigned qb = (OP == EW_SILU) ? 0u : (blk ? bw[9 + j] : __builtin_amdgcn_alignbit(bw[j + 1], bw[j], 16));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float xa = (float)(int)(int8_t)(qa >> (8 * i)) * da;
+                float o;
+                if (OP == EW_SILU) o = xa / (1.0f + expf(-xa));
+                else if (OP == EW_MUL) o = xa * ((float)(int)(int8_t)(qb >> (8 * i)) * db);
+                else o = xa + ((float)(int)(int8_t)(qb >> (8 * i)) * db);
+                v[4 * j + i] = o;
+                amax = fmaxf(amax, fabsf(o));
+            }
+        }
+        const Q8Scale sc = q8_scale_from_absmax(amax);
+        d16o[blk] = sc.d16;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned w = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) w |= ((unsigned)q8_round(v[4 * j + i], sc.scale) & 0xffu) << (8 * i);
+            pq[blk][j] = w;
+        }
+    }
+    ow[0] = d16o[0] | (pq[0][0] << 16);
+#pragma unroll
+    for (int j = 1; j < 8; j++) ow[j] = (pq[0][j - 1] >> 16) | (pq[0][j] << 16);
+    ow[8] = (pq[0][7] >> 16) | (d16o[1] << 16);
+#pragma unroll
+    for (int j = 0; j < 8; j++) ow[9 + j] = pq[1][j];
+    unsigned* op = (unsigned*)(out + off);
+#pragma unroll
+    for (int j = 0; j < 17; j++) op[j] = ow[j];
+}
+
+// rows x blocks big enough for the block-pair kernel, and everything 4-byte aligned
+static bool elementwise_q8x2_ok(const void* a, const void* b, const void* out, int dtype, size_t pitch, int rows, int d)
+{
+    const auto al = [](const void* p) { return ((uintptr_t)p & 3) == 0; };
+    return dtype == GTEN_Q8 && (d / 32) % 2 == 0 && pitch % 4 == 0 && al(a) && al(out) && (!b || al(b)) && (size_t)rows * d >= 32768;
+}
+template <int OP>
+static int launch_elementwise_q8x2(const void* a, const void* b, void* out, size_t pitch, int n, int d, int start_pos)
+{
+    const int ppr = d / 64, total = (n - start_pos) * ppr;
+    GTR_LAUNCH(KT_ELEMWISE, (k_elementwise_q8x2<OP>), dim3((total + 255) / 256), dim3(256), 0,
+               (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, pitch, ppr, start_pos, total);
+    return 0;
+}
+
 // -------------------------------------------------------------- attention
 
 // ops::qkv_attn, gten/ops.h:930-1133.  One workgroup per (head, new row).
@@ -463,6 +545,7 @@ int gten_hip_silu(const void* x, void* out, int dtype, size_t pitch, int n, int 
 {
     GTR_NEED_INIT();
     if (int rc = check_rowwise("silu", x, out, dtype, pitch, n, d, start_pos)) return rc;
+    if (elementwise_q8x2_ok(x, nullptr, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_SILU>(x, nullptr, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_SILU>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)x, (const uint8_t*)nullptr, (uint8_t*)out, dtype, pitch, d, start_pos);
     return 0;
@@ -473,6 +556,7 @@ int gten_hip_mul(const void* a, const void* b, void* out, int dtype, size_t pitc
     GTR_NEED_INIT();
     if (int rc = check_rowwise("mul", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "mul: null pointer");
+    if (elementwise_q8x2_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_MUL>(a, b, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_MUL>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
     return 0;
@@ -483,6 +567,7 @@ int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitc
     GTR_NEED_INIT();
     if (int rc = check_rowwise("add", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "add: null pointer");
+    if (elementwise_q8x2_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_ADD>(a, b, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_ADD>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
     return 0;
