@@ -201,8 +201,12 @@ def test_qkv_attn(hip, oracle, ad, n, sp, H, G, dh):
     hip.qkv_attn(hip.upload(q), hip.upload(k), hip.upload(v), out, ad, n, H, G, dh, sp)
     got = out.download(shape=want.shape)
     assert not got[:sp].any()
-    # two chained roundings (probabilities, then the output row): allow 2 steps
-    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0, atol=2e-4)
+    # two chained roundings (probabilities, then the output row): allow 2 steps.  f16 prompt-sized calls (>= 16 new rows,
+    # 64-wide heads) take the tiled kernel, whose f16 MFMA scores differ from the scalar loop by f32 summation order
+    # (~1e-7): enough to flip the f16 rounding of a probability that sits on a tie -- for a DOMINANT probability (p ~ 1,
+    # ulp 4.9e-4) that moves the whole output row by 4.9e-4 |v|, the spread the reference's own AVX and scalar builds show
+    tiled_f16 = ad == F16 and dh == 64 and n - sp >= 16
+    compare_rows(got[sp:], want[sp:], ad, H * dh, "qkv_attn", min_exact=0.90, steps=2.0, atol=2e-3 if tiled_f16 else 2e-4)
 
 
 def test_errors_are_reported_not_swallowed(hip):

@@ -310,7 +310,227 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
+// ---- the same walk for f16 activations (the f16 configuration: tinyllama.cpp:258-265).  A score is the f16 x f16
+// products of a row pair, exact in f32, added inside the matrix core: two v_mfma_f32_16x16x32_f16 per 16 x 16 scores.
+// The core's order of additions is not the scalar loop's, so unlike the Q8 kernel this one agrees with k_attn to f32
+// summation-order noise, not byte for byte (tests: the oracle tolerance of test_qkv_attn, the f16 goldens).  Probabilities
+// and outputs are rounded to f16 (gten/ops.h:996-997, 73-96); p.V keeps k_attn's four accumulators.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct QFragH {
+    h8 a[2][2];            // [row group][k step of 32]: row = lane % 16, elements 32 s + 8 (lane / 16) ..
+};
+
+__device__ __forceinline__ void tile_scores_f16(const QFragH& q, const uint8_t* __restrict__ kslice, int lq, float (&s)[2][4])
+{
+    const h8 b0 = *(const h8*)(kslice + 16 * lq), b1 = *(const h8*)(kslice + 64 + 16 * lq);
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(q.a[rg][0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(q.a[rg][1], b1, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[rg][i] = acc[i] * 0.125f;     // 1 / sqrt(64)
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_tiled_f16(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
+                                                        const uint8_t* __restrict__ v, uint8_t* __restrict__ out,
+                                                        size_t q_pitch, size_t kv_pitch, size_t out_pitch,
+                                                        int n_heads, int n_kv, int n, int start_pos)
+{
+    __shared__ __attribute__((aligned(16))) float s_p[AT_ROWS * AT_PPITCH];
+    __shared__ __attribute__((aligned(16))) float s_v[AT_VSUB * 64];
+    __shared__ float s_red[4 * AT_ROWS];
+    __shared__ float s_row[AT_ROWS];
+
+    const int h = blockIdx.x;
+    const int rt = gridDim.y - 1 - blockIdx.y;
+    const int r0 = start_pos + rt * AT_ROWS;
+    const int g = h / (n_heads / n_kv);
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lc = l & 15, lq = l >> 4;
+    const int r_last = min(r0 + AT_ROWS, n) - 1;
+    const int ntile = r_last / AT_TILE + 1;
+    const uint8_t* kbase = k + (size_t)g * 128;
+    const uint8_t* vbase = v + (size_t)g * 128;
+
+    QFragH qf;
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++) {
+        const uint8_t* qs = q + (size_t)min(r0 + 16 * rg + lc, n - 1) * q_pitch + (size_t)h * 128;
+        qf.a[rg][0] = *(const h8*)(qs + 16 * lq);
+        qf.a[rg][1] = *(const h8*)(qs + 64 + 16 * lq);
+    }
+    const int row_base = r0 + 4 * lq;
+
+    // ---- pass 0: row maxima
+    float mx[2][4];
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) mx[rg][i] = -INFINITY;
+    for (int t = 0; t < ntile; t++) {
+#pragma unroll
+        for (int cg = 0; cg < 4; cg++) {
+            const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+            if (c - lc > r_last) continue;
+            float s[2][4];
+            tile_scores_f16(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (c <= row_base + 16 * rg + i) mx[rg][i] = fmaxf(mx[rg][i], s[rg][i]);
+        }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            mx[rg][i] = row16_max(mx[rg][i]);
+            if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = mx[rg][i];
+        }
+    __syncthreads();
+    if (threadIdx.x < AT_ROWS)
+        s_row[threadIdx.x] = fmaxf(fmaxf(s_red[threadIdx.x], s_red[AT_ROWS + threadIdx.x]),
+                                   fmaxf(s_red[2 * AT_ROWS + threadIdx.x], s_red[3 * AT_ROWS + threadIdx.x]));
+    __syncthreads();
+#pragma unroll
+    for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) mx[rg][i] = s_row[16 * rg + 4 * lq + i];
+    __syncthreads();
+
+    // ---- pass 1: sums of exponentials (k_attn's 256 running sums per row and its tree, as in the Q8 kernel)
+    float tot[2][4];
+    {
+        float ls[2][4][4];
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) ls[rg][cg][i] = 0.f;
+        for (int t = 0; t < ntile; t++) {
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+                if (c - lc > r_last) continue;
+                float s[2][4];
+                tile_scores_f16(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        ls[rg][cg][i] += (c <= row_base + 16 * rg + i) ? expf(s[rg][i] - mx[rg][i]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float r0s = row16_sum(ls[rg][0][i]), r1s = row16_sum(ls[rg][1][i]);
+                const float r2s = row16_sum(ls[rg][2][i]), r3s = row16_sum(ls[rg][3][i]);
+                const float ws = (r3s + r2s) + (r1s + r0s);
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = ws;
+            }
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS) {
+            float t = 0.f;
+            for (int i = 0; i < 4; i++) t += s_red[i * AT_ROWS + threadIdx.x];
+            s_row[threadIdx.x] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) tot[rg][i] = s_row[16 * rg + 4 * lq + i];
+    }
+
+    // ---- pass 2: probabilities rounded to f16, times V
+    const int ep = threadIdx.x & 31, rq = threadIdx.x >> 5;
+    v2f acc[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[rr][j] = (v2f){0.f, 0.f};
+
+    for (int t = 0; t < ntile; t++) {
+#pragma unroll
+        for (int cg = 0; cg < 4; cg++) {
+            const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+            float s[2][4];
+            const bool any = c - lc <= r_last;
+            if (any) tile_scores_f16(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float pr = (any && c <= row_base + 16 * rg + i) ? expf(s[rg][i] - mx[rg][i]) / tot[rg][i] : 0.f;
+                    s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * cg + lc] = h2f(f2h(pr));
+                }
+        }
+        __syncthreads();
+
+        for (int vs = 0; vs < AT_TILE / AT_VSUB; vs++) {
+            const int c0 = t * AT_TILE + vs * AT_VSUB;
+            if (c0 > r_last) break;
+            {
+                // stage 64 positions of this kv head's V slice as f32: thread = (position, quarter of the 64 elements)
+                const int pos = threadIdx.x >> 2, qtr = threadIdx.x & 3;
+                const uint8_t* vs_ = vbase + (size_t)min(c0 + pos, n - 1) * kv_pitch + 32 * qtr;
+                const uint4 r0w = *(const uint4*)vs_, r1w = *(const uint4*)(vs_ + 16);
+                const unsigned raw[8] = {r0w.x, r0w.y, r0w.z, r0w.w, r1w.x, r1w.y, r1w.z, r1w.w};
+                float* dst = s_v + pos * 64 + 16 * qtr;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    v4f o4;
+                    o4[0] = h2f((uint16_t)(raw[2 * kk] & 0xffffu)); o4[1] = h2f((uint16_t)(raw[2 * kk] >> 16));
+                    o4[2] = h2f((uint16_t)(raw[2 * kk + 1] & 0xffffu)); o4[3] = h2f((uint16_t)(raw[2 * kk + 1] >> 16));
+                    *(v4f*)(dst + 4 * kk) = o4;
+                }
+            }
+            __syncthreads();
+            const int lim = min(AT_VSUB, r_last - c0 + 1);
+#pragma unroll 4
+            for (int c4 = 0; c4 < lim; c4 += 4) {
+                v2f vv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) vv[j] = *(const v2f*)(s_v + (c4 + j) * 64 + 2 * ep);
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const v4f pp = *(const v4f*)(s_p + (4 * rq + rr) * AT_PPITCH + vs * AT_VSUB + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { acc[rr][j].x = acc[rr][j].x + pp[j] * vv[j].x; acc[rr][j].y = acc[rr][j].y + pp[j] * vv[j].y; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- output rows as f16
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        v2f o = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) o += acc[rr][j];
+        const int row = r0 + 4 * rq + rr;
+        if (row < n)
+            *(unsigned*)(out + (size_t)row * out_pitch + (size_t)h * 128 + 4 * ep) = (unsigned)f2h(o.x) | ((unsigned)f2h(o.y) << 16);
+    }
+}
+
 } // namespace
+
+int gten_launch_attn_tiled_f16(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
+                               size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos)
+{
+    const int rows = n - start_pos;
+    const dim3 grid(n_heads, (rows + AT_ROWS - 1) / AT_ROWS);
+    GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_f16, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
+               (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+    return 0;
+}
 
 int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
                            size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos)

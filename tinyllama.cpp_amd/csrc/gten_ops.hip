@@ -592,6 +592,12 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
         if (!(off && off[0] == '1'))
             return gten_launch_attn_tiled(q, k, v, out, q_pitch, kv_pitch, out_pitch, n, n_heads, n_kv_heads, start_pos);
     }
+    if (dtype == GTEN_F16 && d_head == 64 && n - start_pos >= GTEN_ATTN_TILED_MIN_ROWS && q_pitch % 16 == 0 && kv_pitch % 16 == 0 &&
+        ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 4 == 0) && out_pitch % 4 == 0) {
+        const char* off = getenv("GTEN_HIP_NO_TILED_ATTN");
+        if (!(off && off[0] == '1'))
+            return gten_launch_attn_tiled_f16(q, k, v, out, q_pitch, kv_pitch, out_pitch, n, n_heads, n_kv_heads, start_pos);
+    }
     const int p_cap = (n + 31) & ~31;
     const size_t smem = (size_t)(16 + d_head + 8 + d_head + 256 + p_cap) * 4;
     GTR_LAUNCH(KT_ATTN, k_attn, dim3(n_heads, n - start_pos), dim3(256), smem,

@@ -56,6 +56,9 @@ int gten_launch_matmul_mfma(const void* x, int x_dtype, size_t x_pitch, const vo
 #define GTEN_ATTN_TILED_MIN_ROWS 16
 int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
                            size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos);
+// ... and for f16 activations (f16 MFMA scores: agrees with the row kernel to f32 summation order, not byte for byte)
+int gten_launch_attn_tiled_f16(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
+                               size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos);
 
 namespace gtr {
 bool prof_on();
