@@ -2058,8 +2058,10 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)2 * GTEN_Q8_BYTES : (size_t)dh * 2;
 
     float* p = (float*)g_smem;                                    // [GRP][4][64]: position c at [c & 3][c >> 2]
-    float* part = p + GRP * DEC_CHUNK;                            // [GRP][256]
-    unsigned* vl = (unsigned*)(part + GRP * DEC_CHUNK);           // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
+    float* part = p;                                              // [GRP][256]: OVER p -- wave cg reads only p[.][cg][.] and later writes
+                                                                  // only part[.][64 cg + lane], the same words: 8 KB of LDS less per
+                                                                  // workgroup, i.e. 6 instead of 4 resident workgroups per CU
+    unsigned* vl = (unsigned*)(p + GRP * DEC_CHUNK);              // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
     float* ms = (float*)(vl + DEC_CHUNK * NW);                    // [GRP][2]: the row maximum and sum of each head
     float* tl = ms + 16;                                          // [GRP][8]: the heads' chunk terms l_j exp(m_j - M) (16-byte aligned)
 
@@ -2277,7 +2279,7 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
     const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64 +
                          (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4 + 16);
-    const size_t smem2 = (size_t)2 * GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
+    const size_t smem2 = (size_t)GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
     // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (GTEN_HIP_ATTN_EXACT=1)
     const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
     const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
