@@ -2045,6 +2045,173 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     }
 }
 
+// ---- f16 scores of MANY sequences on the matrix cores (16 sequences and up; f16 activations).  An f16 score costs two f32
+// VALU operations per (head, position, element) in the scalar order -- 67 us per launch at 64 sequences, the bound of the
+// f16 wide path.  Here a workgroup (kv head, chunk, sequence) forms Q (the group's heads, padded to 16 rows) x K^T (256
+// positions) with two v_mfma_f32_16x16x32_f16 per 16 positions: f16 products, exact in f32, added inside the matrix core.
+// The core's order of additions is not the scalar loop's: scores agree with k_dec_attn_score64 to f32 summation-order
+// noise (the wide path's tolerance: model band), statistics and cache rows are formed the same way.
+typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
+typedef float att_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float row16_max_f(float v)           // maximum over the 16 lanes of a row; every lane gets it
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    return fmaxf(v, dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum_f(float v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
+template <int GRP>
+__global__ __launch_bounds__(256) void k_dec_attn_score_gm_f16(const AttnArgs a0)
+{
+    constexpr int dh = 64;
+    const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    const AttnArgs a = attn_for_seq(a0, blockIdx.x);
+    const int kv_dim = a.n_kv * dh;
+    const size_t head_bytes = (size_t)dh * 2;
+
+    float* red = (float*)g_smem;                                  // [2][4][16]: per wave and head, maxima then sums
+    float* mxs = red + 128;                                       // [16]
+    uint16_t* d16 = (uint16_t*)(mxs + 16);                        // scratch of head_prep (unused for f16)
+    float* qd = (float*)(d16 + 64);                               // scratch
+    int8_t* qi8 = (int8_t*)(qd + 32);                             // scratch [64]
+    uint16_t* qh = (uint16_t*)(((uintptr_t)(qi8 + 64) + 15) & ~(uintptr_t)15);   // [16][64] f16: the group's q vectors, zero rows beyond
+    uint16_t* kh = qh + 16 * dh;                                  // [64] f16: the new k row
+
+    // ---- requests, none of which needs the context length
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6, lc = t & 15, lq = t >> 4;
+    constexpr int NJ = (GRP + 3) / 4;
+    float qraw[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+    float kvraw = a.qkv_raw[a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+    {
+        float qraw2[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw2[jj] = a.qkv_raw[a.qkv_plane + (g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+        const float kvraw2 = a.qkv_raw[a.qkv_plane + a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_plane ? qraw2[jj] : 0.f;
+        kvraw += a.qkv_plane ? kvraw2 : 0.f;
+    }
+    const float2 rot = a.rope_now[t & 31];
+    __builtin_amdgcn_sched_barrier(0);
+    // K fragments: wave pw owns positions c0 + 64 pw + 16 tt + lc (tt = 0..3); lane (lc, lq) reads elements 32 s + 8 lq ..
+    uint4 kb[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) {
+        const int cs = min(c0 + 64 * pw + 16 * tt + lc, a.max_ctx - 1);
+        const gmem_u32 kp = as_global(a.kcache + (size_t)g * head_bytes) + (unsigned)cs * (unsigned)(a.kv_pitch >> 2) + 4 * lq;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const gmem_u32 kq = kp + 16 * s2;
+            kb[tt][s2] = make_uint4(kq[0], kq[1], kq[2], kq[3]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
+
+    // ---- head vectors (f16), rows beyond the group zeroed
+    const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
+    for (int i = threadIdx.x; i < (16 - GRP) * dh; i += 256) qh[GRP * dh + i] = 0;
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+        const int j = pw + 4 * jj;
+        if (j < GRP) qh[j * dh + t] = f2h(head_prep_cs(qraw[jj], true, true, rot, dh, GTEN_F16, qi8, qd, d16));
+    }
+    if (pw < 2 && has_new) {
+        const float v = head_prep_cs(kvraw, true, pw == 0, rot, dh, GTEN_F16, qi8, qd, d16);
+        uint8_t* row = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+        if (pw == 0) kh[t] = f2h(v);
+        store_global<uint16_t>((uint16_t*)row + t, f2h(v));
+    }
+    __syncthreads();
+
+    // ---- scores: rows = heads (this lane's outputs: heads 4 lq + i), columns = positions
+    att_h8 qa[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) qa[s2] = *(const att_h8*)(qh + lc * dh + 32 * s2 + 8 * lq);
+    float sc[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) {
+        att_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[0], __builtin_bit_cast(att_h8, kb[tt][0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[1], __builtin_bit_cast(att_h8, kb[tt][1]), acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) sc[tt][i] = acc[i] * 0.125f;
+    }
+    if (has_new) {
+        // the new position's row is not in the cache yet for the other workgroups' view: score it from the chip (every column
+        // of this product is the new k row; the lane that owns the position keeps it)
+        att_h8 kn[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) kn[s2] = *(const att_h8*)(kh + 32 * s2 + 8 * lq);
+        att_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[0], kn[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[1], kn[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (c0 + 64 * pw + 16 * tt + lc == pos) sc[tt][i] = acc[i] * 0.125f;
+    }
+    const bool live = 4 * lq < GRP;                               // lanes whose rows are real heads
+    float hm[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+            const int c = c0 + 64 * pw + 16 * tt + lc;
+            if (c < n) {
+                if (live && 4 * lq + i < GRP) a.scores[(size_t)(g * GRP + 4 * lq + i) * a.max_ctx + c] = sc[tt][i];
+                m = fmaxf(m, sc[tt][i]);
+            } else {
+                sc[tt][i] = -INFINITY;
+            }
+        }
+        hm[i] = row16_max_f(m);
+        if (lc == 0) red[pw * 16 + 4 * lq + i] = hm[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int hh = 4 * lq + i;
+        hm[i] = fmaxf(fmaxf(red[hh], red[16 + hh]), fmaxf(red[32 + hh], red[48 + hh]));
+    }
+    float* reds = red + 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float e = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+            const int c = c0 + 64 * pw + 16 * tt + lc;
+            e += (c < n) ? expf(sc[tt][i] - hm[i]) : 0.f;
+        }
+        e = row16_sum_f(e);
+        if (lc == 0) reds[pw * 16 + 4 * lq + i] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < GRP) {
+        const int hh = threadIdx.x;
+        float sm = 0.f;
+        for (int w = 0; w < 4; w++) sm += reds[w * 16 + hh];
+        const float mxh = fmaxf(fmaxf(red[hh], red[16 + hh]), fmaxf(red[32 + hh], red[48 + hh]));
+        a.stats[((size_t)(g * GRP + hh) * a.n_chunks + chunk) * 2 + 0] = mxh;
+        a.stats[((size_t)(g * GRP + hh) * a.n_chunks + chunk) * 2 + 1] = sm;
+    }
+}
+
 // EXACT: every p.V term is rounded as the reference rounds it (multiply, then add: k_dec_attn_pv64's bytes) -- the
 // 8-sequence path, whose sequences are bit-identical to single-sequence decode.  The 16-64-sequence path already adds its
 // W.x block sums in another order (k_dec_mmv), and there the kernel is bound by exactly these two VALU operations per
@@ -2287,7 +2454,12 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, true, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, false, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
     }
-    if (ADT == GTEN_F16) {
+    const char* mse = std::getenv("GTEN_HIP_F16_MFMA_SCORES");
+    if (ADT == GTEN_F16 && n_seq >= 16 && !(mse && mse[0] == '0')) {
+        // 16 sequences and up: the scores of a group as a matrix product on the matrix cores (k_dec_attn_score_gm_f16)
+        const size_t smem_m = (size_t)(128 + 16) * 4 + 128 + 128 + 64 + 16 + (size_t)17 * 64 * 2 + 64;
+        DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_gm_f16<GRP>), grid, dim3(256), smem_m, t);
+    } else if (ADT == GTEN_F16) {
         // f16 scores are 2 VALU operations per (head, position, element) however the heads are grouped (f32 products added in
         // element order): the per-head kernel spreads them over 8x the workgroups and measured faster (16 / 32 sequences:
         // 20.7 / 36.1 us against 30.2 / 53.8) -- same scores, statistics and cache rows, so p.V below can still be grouped
