@@ -70,6 +70,7 @@ def parse_args():
                     help="also measure this many sequences sharing each weight pass on the GPU (0 = skip); "
                          "reported separately, `value` stays the single-sequence rate")
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
+    ap.add_argument("--generate", type=int, default=256, help="also time real greedy generation of this many ids ending at the context limit (0 = skip)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
                     help="how the (untimed) context below the timed window is produced: single-token decode steps "
@@ -365,8 +366,24 @@ def main():
         out["prefill"] = {"prompt_tokens": P, "ms": round(dt * 1e3, 3), "tok_s": round(P / dt, 1),
                           "linear_tflops": round(flops / dt / 1e12, 2),
                           "note": "W.x on v_mfma_f32_16x16x32_f16 (one MFMA = one exact 32-wide quant block; gten_mfma.hip), "
-                                  "attention on gten_attn_tiled.hip (int8 MFMA scores; f16 activations: row kernel), element-wise "
-                                  "ops on the operator kernels; linear_tflops = linear-layer FLOPs / whole prefill time"}
+                                  "attention on gten_attn_tiled.hip (int8 / f16 MFMA scores), element-wise ops on the "
+                                  "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time"}
+    # secondary: real greedy generation (every token is the argmax of the previous step), the reference-style loop
+    # (logits to the host, host argmax, one call per token) against the sampler on the device
+    if world == 1 and fused and args.generate > 0:
+        G = min(args.generate, N_CTX - 16)
+        P0 = N_CTX - G
+        prompt = toks[:P0]
+        t0 = time.perf_counter(); model.logits(prompt, 0, want=True); t_pre = time.perf_counter() - t0
+        res = {}
+        for name, fn in (("host_loop", model.greedy), ("device_sampler", model.generate)):
+            t0 = time.perf_counter()
+            ids = fn(prompt, N_CTX)
+            dt = time.perf_counter() - t0
+            res[name] = {"new_tokens": int(len(ids) - P0), "tok_s": round((len(ids) - P0) / max(dt - t_pre, 1e-9), 1), "last": int(ids[-1])}
+        out["greedy_generation"] = {"prompt_tokens": P0, "prefill_ms": round(t_pre * 1e3, 2), **res,
+                                    "same_ids": res["host_loop"]["last"] == res["device_sampler"]["last"],
+                                    "note": "ids generated up to n = %d; tok/s = new ids / (wall time - prompt processing time)" % N_CTX}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(host, cfg, args.mode, args.seed, args.cpu_steps)

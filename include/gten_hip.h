@@ -178,6 +178,12 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dec, int seq, const int32_
 /* asynchronous: computes row n-1, logits and their argmax.  use_graph != 0
  * replays the captured hipGraph (captured on first use). */
 int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
+/* Greedy generation with the sampler on the device (tinyllama.cpp:395-440 without the 128 KB logits copy and the host
+ * argmax per token): token ids [0, n_first) must be set (gten_hip_decoder_set_tokens) and the caches hold rows
+ * [0, n_first - 1).  Steps n_first, n_first + 1, ... run back to back, each argmax (strict >, first maximum wins) becoming
+ * the next input token on the device, until `max_new` ids are produced, the context is full, or `eos` comes up (not
+ * stored, as in the reference).  The new ids are copied to out_host[0 .. *n_out).  Single-sequence decoders. */
+int gten_hip_decoder_generate(gten_hip_decoder* dec, int n_first, int max_new, int eos, int32_t* out_host, int* n_out);
 /* multi-sequence decoders: sequence q decodes row n_per_seq[q] - 1 (continuous batching: sequences of different
  * lengths share the weight passes); results are read per sequence with gten_hip_decoder_result_seq(dec, q, n_per_seq[q]) */
 int gten_hip_decoder_step_ragged(gten_hip_decoder* dec, const int* n_per_seq, int use_graph);

@@ -52,6 +52,9 @@ int gten_host_model_logits(gten_host_model* m, const int32_t* tokens, int n, int
  * append argmax ids (strict >, first maximum wins) until `max_tokens` total or
  * `eos` is produced (pass eos < 0 to never stop).  Returns the total count. */
 int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos);
+/* the same loop with the sampler on the device (gten_hip_decoder_generate): the prompt as above, every later id from
+ * back-to-back graph replays whose argmax is the next step's input on the device.  Same ids, same return value. */
+int gten_host_model_generate(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos);
 
 /* The fused single-token decode path (include/gten_hip.h) is used by
  * gten_host_model_logits / _greedy whenever exactly one new row is requested;

@@ -87,6 +87,34 @@ def test_greedy_loop_matches_oracle_f16(hip, oracle):
 
 
 @pytest.mark.parametrize("name,wd,ad", MODES())
+def test_generate_on_device_equals_greedy_loop(hip, name, wd, ad):
+    """greedy generation with the sampler on the device (each step's argmax is the next step's input token in HBM, graph
+    replays back to back) produces the ids of the reference-style loop (logits to the host, host argmax, one call per
+    token): short and chunk-crossing lengths, a prompt long enough for the matrix-core prefill, and an early stop at eos"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    gm = host.model(cfg)
+    for i in range(gm.n_weights()):
+        gm.set_weight(i, host.synth_weight(cfg, 2024, i))
+    for n_prompt, total in ((5, 12), (3, 80), (40, 300), (7, 320)):
+        prompt = list(host.synthetic_tokens(n_prompt, seed=50 + n_prompt, n_vocab=cfg.n_vocab))
+        want = gm.greedy(prompt, total)
+        got = gm.generate(prompt, total)
+        assert got.tolist() == want.tolist(), (name, n_prompt, total)
+        assert len(got) == total
+    # eos: stop where the loop stops (the eos id itself is not stored, tinyllama.cpp:425)
+    prompt = list(host.synthetic_tokens(5, seed=55, n_vocab=cfg.n_vocab))
+    full = gm.greedy(prompt, 60)
+    eos = int(full[40])
+    first = next(i for i in range(5, 60) if int(full[i]) == eos)
+    want = gm.greedy(prompt, 60, eos)
+    got = gm.generate(prompt, 60, eos)
+    assert len(want) == first and got.tolist() == want.tolist()
+    gm.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
 def test_long_prompt_prefill_uses_matrix_cores(hip, oracle, name, wd, ad):
     """a 40-id prompt: every W.x of the prefill runs on the MFMA kernel; then 3 fused decode steps"""
     pkg = load_package()

@@ -26,6 +26,7 @@
 #include "gten_rt.h"
 
 #include <vector>
+#include <algorithm>
 
 using namespace gtd;
 
@@ -48,7 +49,8 @@ static int g_only_family = -1;
 
 struct DecStep {
     int n;                        // context length of this step; the new row is n-1
-    int advance;                  // argmax kernel bumps n afterwards (free-running replay)
+    int advance;                  // bit 0: the argmax kernel bumps n afterwards (free-running replay);
+                                  // bit 1: ... and stores its argmax as the NEXT input token (greedy generation without the host)
 };
 
 // ---------------------------------------------------------------- LDS stage
@@ -2346,7 +2348,8 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
 // Works on (value, index) candidates: either the logits themselves (idx == null)
 // or the per-wave winners the lm_head kernel left behind.
 __global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ vals0, const int* __restrict__ idxs0, int count,
-                                                     DecStep* step0, int32_t* __restrict__ result0, int cand_stride, int result_stride)
+                                                     DecStep* step0, int32_t* __restrict__ result0, int cand_stride, int result_stride,
+                                                     int32_t* __restrict__ tokens0, int tok_stride)
 {
     // one workgroup per sequence
     const float* vals = vals0 + (size_t)blockIdx.x * cand_stride;
@@ -2377,7 +2380,9 @@ __global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ v
         if (idx == 0x7fffffff) idx = 0;
         const int n = step->n;
         result[n] = idx;                       // argmax of the step that computed row n-1
-        if (step->advance) step->n = n + 1;    // free-running replay: the next launch decodes row n
+        const int adv = step->advance;
+        if (adv & 2) tokens0[(size_t)blockIdx.x * tok_stride + n] = idx;   // greedy generation: the next step embeds it (tinyllama.cpp:426)
+        if (adv & 1) step->n = n + 1;          // free-running replay: the next launch decodes row n
     }
 }
 
@@ -2638,7 +2643,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
     if ((rc = launch_gemv8<WT, PRO_RESID, NE, F16W ? 4 : 8, 512, 1>(KT_DEC_GEMV_HEAD, hd, d.n_vocab))) return rc;
     DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(1), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
-               dc->n_best, dc->step, dc->result, 0, 0);
+               dc->n_best, dc->step, dc->result, 0, 0, dc->tokens, d.max_ctx + 1);
     return 0;
 }
 
@@ -2764,7 +2769,7 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
     hd.best_val = dc->best_val; hd.best_idx = dc->best_idx;
     if ((rc = launch_gemvm<WT, NE, RH, S, 512>(KT_DEC_GEMV_HEAD, hd, V))) return rc;
     DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)dc->best_val, (const int*)dc->best_idx,
-               dc->n_best, dc->step, dc->result, dc->n_best, d.max_ctx + 2);
+               dc->n_best, dc->step, dc->result, dc->n_best, d.max_ctx + 2, dc->tokens, d.max_ctx + 1);
     return 0;
 }
 
@@ -2963,7 +2968,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
     if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
     if ((rc = mm(KT_DEC_GEMV_HEAD, dc->stg_q, dc->stg_d, dc->stg_sum, dc->logits_m, V, E, d.lm_head, V))) return rc;
     DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)dc->logits_m, (const int*)nullptr,
-               V, dc->step, dc->result, V, d.max_ctx + 2);
+               V, dc->step, dc->result, V, d.max_ctx + 2, dc->tokens, d.max_ctx + 1);
     return 0;
 }
 
@@ -3195,6 +3200,42 @@ int gten_hip_decoder_step_ragged(gten_hip_decoder* dc, const int* n_per_seq, int
     for (int& v : dc->dev_ns) v += 1;                 // the argmax kernel advances every sequence
     dc->dev_n = -1;
     return run_step(dc, use_graph);
+}
+
+// Greedy generation without the host in the loop (single-sequence decoders): steps n_first, n_first + 1, ... replay the
+// graph back to back, each one's argmax written on the device as the next step's input token; the host reads the ids in
+// slices of `GEN_SLICE` steps and stops at `eos` (the steps queued past it only touched rows that no longer matter).
+int gten_hip_decoder_generate(gten_hip_decoder* dc, int n_first, int max_new, int eos, int32_t* out_host, int* n_out)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && out_host && n_out && dc->n_seq == 1, "decoder_generate: bad arguments (single-sequence decoders)");
+    GTR_REQUIRE(n_first >= 1 && n_first <= dc->d.max_ctx && max_new >= 0, "decoder_generate: n_first=%d outside [1, %d]", n_first, dc->d.max_ctx);
+    GTR_REQUIRE(!prof_on(), "decoder_generate: switch the per-launch profiler off first");
+    constexpr int GEN_SLICE = 32;
+    const int last = std::min(dc->d.max_ctx, n_first + max_new - 1);           // last step that may run
+    const DecStep st{n_first, 3};
+    GTR_CHECK(hipMemcpyAsync(dc->step, &st, sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    dc->dev_n = -1;
+    dc->dev_ns.clear();
+    int got = 0;
+    std::vector<int32_t> ids(GEN_SLICE);
+    for (int n = n_first; n <= last;) {
+        const int cnt = std::min(GEN_SLICE, last - n + 1);
+        for (int i = 0; i < cnt; i++)
+            if (int rc = run_step(dc, 1)) return rc;
+        GTR_CHECK(hipMemcpyAsync(ids.data(), dc->result + n, (size_t)cnt * 4, hipMemcpyDeviceToHost, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));
+        bool stop = false;
+        for (int i = 0; i < cnt; i++) {
+            if (ids[i] == eos) { stop = true; break; }
+            out_host[got++] = ids[i];
+        }
+        if (stop) break;
+        n += cnt;
+    }
+    *n_out = got;
+    return 0;
 }
 
 int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int reps, double* avg_us, int* launches_per_replay)

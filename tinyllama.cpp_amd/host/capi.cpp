@@ -105,6 +105,15 @@ int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, in
     return total;
 }
 
+int gten_host_model_generate(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos)
+{
+    std::vector<int32_t> t(tokens, tokens + n_prompt);
+    t.reserve((size_t)max_tokens);
+    const int total = greedy_generate(*m->model, t, max_tokens, eos);
+    std::memcpy(tokens, t.data(), (size_t)total * sizeof(int32_t));
+    return total;
+}
+
 int gten_host_model_set_fast_decode(gten_host_model* m, int on)
 {
     m->model->set_fast_decode(on != 0);

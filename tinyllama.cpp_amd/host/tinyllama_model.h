@@ -133,6 +133,16 @@ public:
         GTEN_HIP_OK(gten_hip_decoder_result(dec_, n, &tok));
         return tok;
     }
+    // greedy generation with the sampler on the device (gten_hip_decoder_generate): ids [0, n_first) are known, the
+    // caches hold rows [0, n_first - 1); returns the number of new ids written to `out`
+    int decode_generate(const int32_t* ids, int n_first, int max_new, int eos, int32_t* out)
+    {
+        decode_set_tokens(ids, 0, n_first);
+        int got = 0;
+        GTEN_HIP_OK(gten_hip_decoder_generate(dec_, n_first, max_new, eos, out, &got));
+        (void)lm_head_.acv.device_ptr_mut();          // the steps wrote logits in HBM: host mirror is stale
+        return got;
+    }
 
     ~TinyLlama()
     {
@@ -397,6 +407,33 @@ inline int greedy_sample(TinyLlama& model, std::vector<int32_t>& tokens, const i
         if (best_i == eos) break;
         tokens.push_back(best_i);
     }
+    return (int)tokens.size();
+}
+
+// The same loop with the sampler on the device: the prompt is processed as in the reference (iteration 0 above, host
+// argmax of its logits), every later token comes from back-to-back graph replays whose argmax feeds the next step on the
+// device -- no logits copy, no host argmax, no host round trip per token.  Same ids as greedy_sample (tested).
+inline int greedy_generate(TinyLlama& model, std::vector<int32_t>& tokens, const int n_predict, const int eos)
+{
+    if ((int)tokens.size() >= n_predict) return (int)tokens.size();
+    {
+        Tensor input{tokens.data(), {(int)tokens.size()}, kInt32};
+        Tensor logits = model.logits(input, 0);
+        const int n = logits.numel();
+        const float* p = const_cast<const Tensor&>(logits).data_ptr<float>();
+        float best = -std::numeric_limits<float>::infinity();
+        int best_i = 0;
+        for (int j = 0; j < n; j++)
+            if (p[j] > best) { best = p[j]; best_i = j; }
+        if (best_i == eos) return (int)tokens.size();
+        tokens.push_back(best_i);
+    }
+    const int n_first = (int)tokens.size();
+    const int max_new = n_predict - n_first;
+    if (max_new <= 0) return n_first;
+    std::vector<int32_t> out((size_t)max_new);
+    const int got = model.decode_generate(tokens.data(), n_first, max_new, eos, out.data());
+    tokens.insert(tokens.end(), out.begin(), out.begin() + got);
     return (int)tokens.size();
 }
 

@@ -33,7 +33,7 @@ class GtenHost:
     SYMBOLS = [
         "gten_host_default_config", "gten_host_model_create", "gten_host_model_free", "gten_host_model_n_weights",
         "gten_host_model_weight_bytes", "gten_host_model_set_weight", "gten_host_model_load_gten",
-        "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy",
+        "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy", "gten_host_model_generate",
         "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
         "gten_host_model_decode_result", "gten_host_model_time_family",
@@ -60,6 +60,7 @@ class GtenHost:
         self._loads = _sig(L, "gten_host_model_load_synthetic", ci, [vp, C.c_uint64])
         self._logits = _sig(L, "gten_host_model_logits", ci, [vp, vp, ci, ci, vp])
         self._greedy = _sig(L, "gten_host_model_greedy", ci, [vp, vp, ci, ci, ci])
+        self._generate = _sig(L, "gten_host_model_generate", ci, [vp, vp, ci, ci, ci])
         self._setfast = _sig(L, "gten_host_model_set_fast_decode", ci, [vp, ci])
         self._dbegin = _sig(L, "gten_host_model_decode_begin", ci, [vp, vp, ci])
         self._dstep = _sig(L, "gten_host_model_decode_step", ci, [vp, ci, ci])
@@ -184,6 +185,13 @@ class HostModel:
         buf = np.zeros(max_tokens, np.int32)
         buf[: len(prompt)] = prompt
         total = self.host._greedy(self.h, buf.ctypes.data_as(C.c_void_p), len(prompt), max_tokens, eos)
+        return buf[:total].copy()
+
+    def generate(self, prompt, max_tokens, eos=-1):
+        """greedy ids with the sampler on the device (gten_host_model_generate): same ids as greedy()"""
+        buf = np.zeros(max_tokens, np.int32)
+        buf[: len(prompt)] = prompt
+        total = self.host._generate(self.h, buf.ctypes.data_as(C.c_void_p), len(prompt), max_tokens, eos)
         return buf[:total].copy()
 
     def close(self):
