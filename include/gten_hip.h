@@ -184,6 +184,10 @@ int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
  * the next input token on the device, until `max_new` ids are produced, the context is full, or `eos` comes up (not
  * stored, as in the reference).  The new ids are copied to out_host[0 .. *n_out).  Single-sequence decoders. */
 int gten_hip_decoder_generate(gten_hip_decoder* dec, int n_first, int max_new, int eos, int32_t* out_host, int* n_out);
+/* ... and for every sequence of a multi-sequence decoder, sequence q from step n_first[q] (its ids [0, n_first[q]) set,
+ * its caches holding rows [0, n_first[q] - 1)): finished sequences are parked while the others go on.
+ * out_host is [n_seq][max_new], n_out [n_seq]. */
+int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, int max_new, int eos, int32_t* out_host, int* n_out);
 /* multi-sequence decoders: sequence q decodes row n_per_seq[q] - 1 (continuous batching: sequences of different
  * lengths share the weight passes); results are read per sequence with gten_hip_decoder_result_seq(dec, q, n_per_seq[q]) */
 int gten_hip_decoder_step_ragged(gten_hip_decoder* dec, const int* n_per_seq, int use_graph);

@@ -81,6 +81,11 @@ int  gten_host_batch_load_synthetic(gten_host_batch* b, uint64_t seed);
 int  gten_host_batch_set_weight(gten_host_batch* b, int idx, const void* bytes, size_t nbytes);  /* idx ascending */
 /* prompt of sequence `seq` through the operator path (fills its caches); logits_out may be NULL */
 int  gten_host_batch_prefill(gten_host_batch* b, int seq, const int32_t* tokens, int n, float* logits_out);
+/* greedy generation of every sequence with the sampler on the device: prompts is [n_seq][max_prompt] (sequence q uses its
+ * first n_prompt[q] ids), each prompt is processed on its own caches, then all sequences generate together, each from its
+ * own position, until `max_tokens` total ids or `eos`.  out is [n_seq][max_tokens] (prompt + new ids), n_total [n_seq]. */
+int  gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int max_prompt, int max_tokens, int eos,
+                              int32_t* out, int32_t* n_total);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
 int  gten_host_batch_decode_step_ragged(gten_host_batch* b, const int32_t* n_per_seq, int use_graph);   /* sequence q at its own n */

@@ -119,6 +119,33 @@ def test_wide_batch_on_matrix_cores_tracks_single_sequence_decode(hip, name, wd,
     assert not np.array_equal(runs[0][N][0][1], runs[0][N][1][1])       # independent sequences
 
 
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_batch_generation_on_device_equals_single_sequence_generation(hip, name, wd, ad):
+    """four sequences with prompts of different lengths generate together (sampler on the device, each sequence at its own
+    position, finished sequences parked): every sequence's ids are those of generating it alone -- including one that
+    stops early at eos and one that fills the context"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    prompts = [list(host.synthetic_tokens(n, seed=70 + n, n_vocab=cfg.n_vocab)) for n in (5, 40, 9, 17)]
+    total = 300
+    m = host.model(cfg)
+    for i in range(len(cfg.weight_shapes())):
+        m.set_weight(i, host.synth_weight(cfg, 99, i))
+    alone = [m.generate(p, total) for p in prompts]
+    eos = int(alone[2][60])                                     # sequence 2 will stop here (or earlier); the others may too
+    want = [m.generate(p, total, eos) for p in prompts]
+    m.close()
+    b = host.batch(cfg, 4)
+    for i in range(len(cfg.weight_shapes())):
+        b.set_weight(i, host.synth_weight(cfg, 99, i))
+    got = b.generate(prompts, total, eos)
+    b.close()
+    assert any(len(w) < total for w in want) and any(len(w) > 100 for w in want)
+    for q in range(4):
+        assert got[q].tolist() == want[q].tolist(), (name, q, len(got[q]), len(want[q]))
+
+
 def test_wide_batch_k_split_planes_agree_with_single_plane(hip, monkeypatch):
     """k_dec_mmv splits K over two workgroups per feature tile and the consumers add the two planes of partial sums
     (default); GTEN_HIP_MMV_KSPLIT=1 keeps one workgroup and one plane.  Same block sums, one more f32 association:

@@ -3238,6 +3238,60 @@ int gten_hip_decoder_generate(gten_hip_decoder* dc, int n_first, int max_new, in
     return 0;
 }
 
+// The same for the sequences of a multi-sequence decoder, each from its own position (continuous batching): sequence q
+// starts at step n_first[q]; one that produced `eos`, its max_new ids or a full context is PARKED (its step word stops
+// advancing: it recomputes the same row, which changes nothing) while the others go on.  out_host is [n_seq][max_new].
+int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, int max_new, int eos, int32_t* out_host, int* n_out)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && n_first && out_host && n_out && max_new >= 0, "decoder_generate_multi: bad arguments");
+    GTR_REQUIRE(!prof_on(), "decoder_generate_multi: switch the per-launch profiler off first");
+    const int S = dc->n_seq, ctx = dc->d.max_ctx;
+    for (int q = 0; q < S; q++) GTR_REQUIRE(n_first[q] >= 1 && n_first[q] <= ctx, "decoder_generate_multi: n_first[%d]=%d outside [1, %d]", q, n_first[q], ctx);
+    constexpr int GEN_SLICE = 32;
+    std::vector<DecStep> st((size_t)S);
+    std::vector<int> cur(n_first, n_first + S), last((size_t)S);
+    std::vector<char> live((size_t)S, 1);
+    int n_live = 0;
+    for (int q = 0; q < S; q++) {
+        last[q] = std::min(ctx, n_first[q] + max_new - 1);
+        live[q] = last[q] >= n_first[q];
+        st[q] = DecStep{n_first[q], live[q] ? 3 : 0};
+        n_out[q] = 0;
+        n_live += live[q];
+    }
+    GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    dc->dev_n = -1;
+    dc->dev_ns.clear();
+    std::vector<int32_t> ids((size_t)GEN_SLICE);
+    while (n_live > 0) {
+        int cnt = GEN_SLICE;
+        for (int q = 0; q < S; q++) if (live[q]) cnt = std::min(cnt, last[q] - cur[q] + 1);   // nobody runs past its last step
+        for (int i = 0; i < cnt; i++)
+            if (int rc = run_step(dc, 1)) return rc;
+        GTR_CHECK(hipStreamSynchronize(stream()));
+        bool parked = false;
+        for (int q = 0; q < S; q++) {
+            if (!live[q]) continue;
+            GTR_CHECK(hipMemcpy(ids.data(), dc->result + (size_t)q * (ctx + 2) + cur[q], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+            bool stop = false;
+            for (int i = 0; i < cnt && !stop; i++) {
+                if (ids[i] == eos) stop = true;
+                else out_host[(size_t)q * max_new + n_out[q]++] = ids[i];
+            }
+            cur[q] += cnt;
+            if (stop || cur[q] > last[q]) {
+                live[q] = 0; n_live--; parked = true;
+                st[q] = DecStep{std::min(cur[q], ctx), 0};
+                GTR_CHECK(hipMemcpy(dc->step + q, &st[q], sizeof(DecStep), hipMemcpyHostToDevice));
+            }
+        }
+        (void)parked;
+    }
+    return 0;
+}
+
 int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int reps, double* avg_us, int* launches_per_replay)
 {
     GTR_NEED_INIT();

@@ -1,3 +1,4 @@
+#include <algorithm>
 // capi.cpp -- flat C exports of the model-level host code (include/gten_host.h).
 #include "../../include/gten_host.h"
 
@@ -212,6 +213,48 @@ int gten_host_batch_decode_step_ragged(gten_host_batch* b, const int32_t* n_per_
     for (int q = 0; q < b->batch->n_seq(); q++)
         if (n_per_seq[q] < 1 || n_per_seq[q] > b->cfg.max_ctx) return -1;
     b->batch->decode_step_ragged(n_per_seq, use_graph != 0);
+    return 0;
+}
+
+// prompts [n_seq][max_prompt] (sequence q uses its first n_prompt[q] ids): each prompt is processed on its sequence's
+// own caches (the reference's logits() call, host argmax of the first new id), then all sequences generate together
+// with the sampler on the device.  out is [n_seq][max_tokens]: prompt + new ids; n_total [n_seq].
+int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int max_prompt, int max_tokens, int eos,
+                             int32_t* out, int32_t* n_total)
+{
+    if (!prompts || !n_prompt || !out || !n_total || max_tokens <= 0) return -1;
+    const int S = b->batch->n_seq();
+    std::vector<int> n_first((size_t)S);
+    int max_new = 0;
+    for (int q = 0; q < S; q++) {
+        const int P = n_prompt[q];
+        if (P <= 0 || P > max_prompt || P >= max_tokens || P >= b->cfg.max_ctx) return -1;
+        int32_t* row = out + (size_t)q * max_tokens;
+        std::memcpy(row, prompts + (size_t)q * max_prompt, (size_t)P * sizeof(int32_t));
+        Tensor tk(row, {P}, kInt32);
+        const Tensor lg = b->batch->seq(q).logits(tk, 0);
+        const float* p = lg.data_ptr<float>();
+        int best_i = 0;
+        float best = -std::numeric_limits<float>::infinity();
+        for (int j = 0; j < lg.numel(); j++)
+            if (p[j] > best) { best = p[j]; best_i = j; }
+        row[P] = best_i;                                          // (an eos here ends the sequence below)
+        n_first[q] = P + 1;
+        b->batch->decode_set_tokens(q, row, 0, P + 1);
+        max_new = std::max(max_new, max_tokens - (P + 1));
+    }
+    std::vector<int32_t> gen((size_t)S * (size_t)std::max(max_new, 1));
+    std::vector<int> n_out((size_t)S, 0);
+    b->batch->decode_generate(n_first.data(), max_new, eos, gen.data(), n_out.data());
+    for (int q = 0; q < S; q++) {
+        int32_t* row = out + (size_t)q * max_tokens;
+        int total = n_first[q];
+        if (row[total - 1] == eos) { n_total[q] = total - 1; continue; }
+        const int room = max_tokens - total;
+        const int take = std::min(n_out[q], room);
+        std::memcpy(row + total, gen.data() + (size_t)q * max_new, (size_t)take * sizeof(int32_t));
+        n_total[q] = total + take;
+    }
     return 0;
 }
 

@@ -38,7 +38,7 @@ class GtenHost:
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
-        "gten_host_batch_prefill", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
+        "gten_host_batch_prefill", "gten_host_batch_generate", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
         "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
     ]
 
@@ -74,6 +74,7 @@ class GtenHost:
         self._bbegin = _sig(L, "gten_host_batch_decode_begin", ci, [vp, ci, vp, ci])
         self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
         self._bstepr = _sig(L, "gten_host_batch_decode_step_ragged", ci, [vp, vp, ci])
+        self._bgen = _sig(L, "gten_host_batch_generate", ci, [vp, vp, vp, ci, ci, ci, vp, vp])
         self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
         self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
         self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
@@ -247,6 +248,21 @@ class HostBatch:
         ns = np.ascontiguousarray(ns, dtype=np.int32)
         assert len(ns) == self.n_seq
         self._ck(self.host._bstepr(self.h, ns.ctypes.data_as(C.c_void_p), 1 if use_graph else 0), "batch_decode_step_ragged")
+
+    def generate(self, prompts, max_tokens, eos=-1):
+        """greedy generation of every sequence (sampler on the device): list of id arrays, one per sequence, prompt included"""
+        assert len(prompts) == self.n_seq
+        mp = max(len(p) for p in prompts)
+        pr = np.zeros((self.n_seq, mp), np.int32)
+        npr = np.zeros(self.n_seq, np.int32)
+        for q, p in enumerate(prompts):
+            pr[q, : len(p)] = p
+            npr[q] = len(p)
+        out = np.zeros((self.n_seq, max_tokens), np.int32)
+        tot = np.zeros(self.n_seq, np.int32)
+        self._ck(self.host._bgen(self.h, pr.ctypes.data_as(C.c_void_p), npr.ctypes.data_as(C.c_void_p), mp, max_tokens, eos,
+                                 out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p)), "batch_generate")
+        return [out[q, : tot[q]].copy() for q in range(self.n_seq)]
 
     def decode_result(self, seq, n):
         out = C.c_int32(-1)
