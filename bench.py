@@ -350,6 +350,25 @@ def main():
                                                     "graph == eager bit for bit (tests/test_multiseq_gpu.py)")
         model = host.model(cfg)
         model.load_synthetic(args.seed)
+    # secondary: real greedy generation of a whole batch (sampler on the device, every sequence its own prompt)
+    if world == 1 and fused and args.generate > 0 and args.wide_streams > 1:
+        S = args.wide_streams
+        G = min(args.generate, N_CTX - 16)
+        P0 = N_CTX - G
+        batch = host.batch(cfg, S)
+        batch.load_synthetic(args.seed)
+        prompts = [host.synthetic_tokens(P0, seed=rep_seed(777, q)) for q in range(S)]
+        t0 = time.perf_counter(); batch.prefill(0, prompts[0]); hip.sync(); t_pre = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ids = batch.generate(prompts, N_CTX)
+        dt = time.perf_counter() - t0
+        new = sum(len(x) - P0 for x in ids)
+        out["batch_generation"] = {"streams": S, "prompt_tokens_each": P0, "new_tokens": int(new), "wall_s": round(dt, 3),
+                                   "prefill_s_estimate": round(S * t_pre, 3),
+                                   "tok_s": round(new / max(dt - S * t_pre, 1e-9), 1),
+                                   "note": "greedy ids generated up to n = %d for every sequence; tok/s = new ids / (wall time - "
+                                           "n_seq x one prompt's processing time)" % N_CTX}
+        batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if world == 1 and args.prefill > 0:
         P = min(args.prefill, N_CTX)
