@@ -56,6 +56,17 @@ int gten_host_model_greedy(gten_host_model* m, int32_t* tokens, int n_prompt, in
  * back-to-back graph replays whose argmax is the next step's input on the device.  Same ids, same return value. */
 int gten_host_model_generate(gten_host_model* m, int32_t* tokens, int n_prompt, int max_tokens, int eos);
 
+/* ---- tokenizer + chat template (tokenizer.h:22-283 of the reference, on its vocabulary file tokenizer.bin).
+ * encode: chat_template != 0 gives Tokenizer::encode (tokenizer.h:135-170: [1, 32001] + bpe("user\n" + prompt) +
+ * [32002, 29871, 13, 32001, 20255, 13]); 0 gives the plain BPE ids (encode_internal, 172-283).  Returns the id count,
+ * or -(count) when `cap` is too small.  decode: Tokenizer::decode (94-110), the piece of `token` after `prev_token`.
+ * create returns NULL when the file cannot be opened. */
+typedef struct gten_host_tokenizer gten_host_tokenizer;
+gten_host_tokenizer* gten_host_tokenizer_create(const char* path, int vocab_size);
+void        gten_host_tokenizer_free(gten_host_tokenizer* t);
+int         gten_host_tokenizer_encode(gten_host_tokenizer* t, const char* prompt, int chat_template, int32_t* ids_out, int cap);
+const char* gten_host_tokenizer_decode(gten_host_tokenizer* t, int prev_token, int token);
+
 /* The fused single-token decode path (include/gten_hip.h) is used by
  * gten_host_model_logits / _greedy whenever exactly one new row is requested;
  * this switch forces the operator-by-operator path instead (on = 0). */

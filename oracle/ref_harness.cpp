@@ -288,4 +288,18 @@ void ref_tl_logits(ref_tinyllama* t, const int32_t* tokens, int n, int start_pos
     std::memcpy(out, lg.data_ptr<float>(), (size_t)lg.numel() * sizeof(float));
 }
 
+// ---- the reference's own Tokenizer (tokenizer.h, included by tinyllama.cpp): pins for host/tokenizer.h
+struct ref_tokenizer { Tokenizer tok; ref_tokenizer(const char* path, int vocab) : tok(path, vocab) {} };
+ref_tokenizer* ref_tok_create(const char* path, int vocab_size) { return new ref_tokenizer(path, vocab_size); }
+void ref_tok_free(ref_tokenizer* t) { delete t; }
+int ref_tok_encode(ref_tokenizer* t, const char* prompt, int32_t* ids_out, int cap)
+{
+    std::string p(prompt);
+    const std::vector<int> ids = t->tok.encode(p);
+    if ((int)ids.size() > cap) return -(int)ids.size();
+    for (size_t i = 0; i < ids.size(); i++) ids_out[i] = ids[i];
+    return (int)ids.size();
+}
+const char* ref_tok_decode(ref_tokenizer* t, int prev_token, int token) { return t->tok.decode(prev_token, token); }
+
 } // extern "C"

@@ -6,6 +6,7 @@
 #include <memory>
 
 #include "tinyllama_model.h"
+#include "tokenizer.h"
 
 using namespace gten;
 
@@ -113,6 +114,32 @@ int gten_host_model_generate(gten_host_model* m, int32_t* tokens, int n_prompt, 
     const int total = greedy_generate(*m->model, t, max_tokens, eos);
     std::memcpy(tokens, t.data(), (size_t)total * sizeof(int32_t));
     return total;
+}
+
+// ---- tokenizer (host/tokenizer.h): ids and pieces of the reference's tokenizer.h on the same vocabulary file
+struct gten_host_tokenizer { Tokenizer tok; gten_host_tokenizer(const char* path, int vocab) : tok(path, vocab) {} };
+
+gten_host_tokenizer* gten_host_tokenizer_create(const char* path, int vocab_size)
+{
+    if (!path || vocab_size <= 0) return nullptr;
+    FILE* f = std::fopen(path, "rb");              // (the class exits the process on a missing file, as the reference does)
+    if (!f) return nullptr;
+    std::fclose(f);
+    return new gten_host_tokenizer(path, vocab_size);
+}
+void gten_host_tokenizer_free(gten_host_tokenizer* t) { delete t; }
+int gten_host_tokenizer_encode(gten_host_tokenizer* t, const char* prompt, int chat_template, int32_t* ids_out, int cap)
+{
+    if (!t || !prompt || !ids_out) return -1;
+    std::string p(prompt);
+    const std::vector<int> ids = chat_template ? t->tok.encode(p) : t->tok.encode_plain(p);
+    if ((int)ids.size() > cap) return -(int)ids.size();
+    for (size_t i = 0; i < ids.size(); i++) ids_out[i] = ids[i];
+    return (int)ids.size();
+}
+const char* gten_host_tokenizer_decode(gten_host_tokenizer* t, int prev_token, int token)
+{
+    return t ? t->tok.decode(prev_token, token) : "";
 }
 
 int gten_host_model_set_fast_decode(gten_host_model* m, int on)

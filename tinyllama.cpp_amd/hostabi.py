@@ -34,6 +34,7 @@ class GtenHost:
         "gten_host_default_config", "gten_host_model_create", "gten_host_model_free", "gten_host_model_n_weights",
         "gten_host_model_weight_bytes", "gten_host_model_set_weight", "gten_host_model_load_gten",
         "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy", "gten_host_model_generate",
+        "gten_host_tokenizer_create", "gten_host_tokenizer_free", "gten_host_tokenizer_encode", "gten_host_tokenizer_decode",
         "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
         "gten_host_model_decode_result", "gten_host_model_time_family",
@@ -61,6 +62,10 @@ class GtenHost:
         self._logits = _sig(L, "gten_host_model_logits", ci, [vp, vp, ci, ci, vp])
         self._greedy = _sig(L, "gten_host_model_greedy", ci, [vp, vp, ci, ci, ci])
         self._generate = _sig(L, "gten_host_model_generate", ci, [vp, vp, ci, ci, ci])
+        self._tok_create = _sig(L, "gten_host_tokenizer_create", vp, [C.c_char_p, ci])
+        self._tok_free = _sig(L, "gten_host_tokenizer_free", None, [vp])
+        self._tok_encode = _sig(L, "gten_host_tokenizer_encode", ci, [vp, C.c_char_p, ci, vp, ci])
+        self._tok_decode = _sig(L, "gten_host_tokenizer_decode", C.c_char_p, [vp, ci, ci])
         self._setfast = _sig(L, "gten_host_model_set_fast_decode", ci, [vp, ci])
         self._dbegin = _sig(L, "gten_host_model_decode_begin", ci, [vp, vp, ci])
         self._dstep = _sig(L, "gten_host_model_decode_step", ci, [vp, ci, ci])
@@ -110,6 +115,41 @@ class GtenHost:
 
     def batch(self, cfg, n_seq):
         return HostBatch(self, cfg, n_seq)
+
+    def tokenizer(self, path, vocab_size=32000):
+        """host/tokenizer.h on a vocabulary file (host only: no GPU needed)"""
+        return HostTokenizer(self, path, vocab_size)
+
+
+class HostTokenizer:
+    def __init__(self, host, path, vocab_size):
+        self.host = host
+        self.h = host._tok_create(str(path).encode(), vocab_size)
+        if not self.h:
+            raise GtenHipError(f"tokenizer: cannot open {path}")
+
+    def encode(self, prompt, chat_template=True):
+        data = prompt if isinstance(prompt, bytes) else prompt.encode("utf-8")
+        cap = 16 + 2 * len(data)
+        buf = np.zeros(cap, np.int32)
+        n = self.host._tok_encode(self.h, data, 1 if chat_template else 0, buf.ctypes.data_as(C.c_void_p), cap)
+        if n < 0:
+            raise GtenHipError(f"tokenizer_encode rc={n}")
+        return buf[:n].tolist()
+
+    def decode(self, prev_token, token):
+        return self.host._tok_decode(self.h, prev_token, token)        # bytes
+
+    def close(self):
+        if self.h:
+            self.host._tok_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HostModel:
