@@ -77,14 +77,22 @@ def build_hip(force=False):
     return HIP_LIB
 
 
+HOST_CLI = os.path.join(HOST, "tinyllama_cli")
+CLI_SRC = os.path.join(HOST, "tinyllama_cli.cpp")
+
+
 def build_host(force=False):
-    srcs = _sources(HOST, (".cpp",))
+    srcs = [s for s in _sources(HOST, (".cpp",)) if s != CLI_SRC]
     if not srcs:
         return None
     deps = srcs + _sources(HOST, (".h",)) + _sources(os.path.join(PKG, "gten"), (".h",)) + _sources(INCLUDE, (".h",))
     if force or _newer(HOST_LIB, deps) or _newer(HOST_LIB, [HIP_LIB]):
         subprocess.run(["g++"] + CXX_FLAGS + ["-o", HOST_LIB] + srcs +
                        ["-L" + CSRC, "-lgten_hip", "-Wl,-rpath,$ORIGIN/../csrc"], check=True)
+    # the command line program (host/tinyllama_cli.cpp): the reference's main() on this repository's gten API
+    if os.path.exists(CLI_SRC) and (force or _newer(HOST_CLI, deps + [CLI_SRC]) or _newer(HOST_CLI, [HIP_LIB])):
+        cli_flags = [f for f in CXX_FLAGS if f not in ("-shared", "-fPIC")]
+        subprocess.run(["g++"] + cli_flags + ["-o", HOST_CLI, CLI_SRC, "-L" + CSRC, "-lgten_hip", "-Wl,-rpath,$ORIGIN/../csrc"], check=True)
     return HOST_LIB
 
 
