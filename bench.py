@@ -303,10 +303,15 @@ def main():
     def multi_stream(S, note):
         batch = host.batch(cfg, S)
         batch.load_synthetic(args.seed)
+        seqs = [host.synthetic_tokens(N_CTX, seed=rep_seed(12345, 1000 + q)) for q in range(S)]
+        if args.fill == "prefill" and first > 1:
+            for q in range(S):
+                batch.prefill(q, seqs[q][:first - 1], want=False)      # each sequence's prompt on its own caches
         for q in range(S):
-            batch.decode_begin(q, host.synthetic_tokens(N_CTX, seed=rep_seed(12345, 1000 + q)))
-        for n in range(1, first):
-            batch.decode_step(n, use_graph)
+            batch.decode_begin(q, seqs[q])
+        if not (args.fill == "prefill" and first > 1):
+            for n in range(1, first):
+                batch.decode_step(n, use_graph)
         for i in range(W):
             batch.decode_step(n_of(i, total), use_graph)
         hip.sync()
