@@ -134,6 +134,40 @@ __global__ __launch_bounds__(256) void k_act_to_f16(const uint8_t* __restrict__ 
     da[idx] = h2f(blk[0]);
 }
 
+// The same, one thread per PAIR of adjacent blocks: a pair is 68 bytes, always 4-byte aligned, i.e. 17 dwords instead of
+// 2 x 17 two-byte loads (rows of an even number of blocks at a 4-byte aligned pitch: every activation width of the model).
+__global__ __launch_bounds__(256) void k_act_to_f16_x2(const uint8_t* __restrict__ x, size_t x_pitch, int rows, int nb, int start_pos,
+                                                       uint4* __restrict__ a16, float* __restrict__ da)
+{
+    const int np = nb >> 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * np) return;
+    const int r = idx / np, pr = idx - r * np;
+    const unsigned* pw = (const unsigned*)(x + (size_t)(start_pos + r) * x_pitch + (size_t)pr * 68);
+    unsigned w[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) w[i] = pw[i];
+    unsigned q[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        q[0][i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], 16);      // block 0's quants straddle the dwords by 2 bytes
+        q[1][i] = w[9 + i];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const size_t bi = (size_t)r * nb + 2 * pr + b;
+        uint4* dst = a16 + bi * 4;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            unsigned f[4];
+            int8x4_to_f16(q[b][i], f[0], f[1]);
+            int8x4_to_f16(q[b][i + 1], f[2], f[3]);
+            dst[i >> 1] = make_uint4(f[0], f[1], f[2], f[3]);
+        }
+        da[bi] = h2f((uint16_t)(b ? (w[8] >> 16) : (w[0] & 0xffffu)));
+    }
+}
+
 // (2 waves per SIMD = a 256-VGPR budget: the block sums then come back in VGPRs instead of AGPRs, which
 //  would cost four v_accvgpr_read per MFMA in a loop that is bound by VALU issue)
 // a16: f16 activation rows of the NEW rows (row 0 = start_pos), pitch d_in * 2 (quantized) or x itself (f16 weights)
@@ -404,8 +438,12 @@ static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, i
     if (C::QUANT) {
         uint8_t* buf = nullptr;
         if (int rc = act_scratch((size_t)rows * d_in * 2, (size_t)rows * nb * 4, &buf, &da)) return rc;
-        GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16, dim3((rows * nb + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos,
-                   (uint4*)buf, da);
+        if (nb % 2 == 0 && x_pitch % 4 == 0 && ((uintptr_t)x % 4) == 0)
+            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16_x2, dim3((rows * (nb / 2) + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb,
+                       start_pos, (uint4*)buf, da);
+        else
+            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16, dim3((rows * nb + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos,
+                       (uint4*)buf, da);
         a16 = buf; a_pitch = (size_t)d_in * 2;
     }
     const dim3 grid((d_out + C::BN - 1) / C::BN, (rows + C::BM - 1) / C::BM), block(256);
