@@ -307,11 +307,20 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
 {
     // (rebuilt word by word, through the global address space: a pointer made from an integer would otherwise be
     // a generic one and every load through it a FLAT load)
+    // k_dec_gemv8's words: p0 | p1 | p2 | quants of matrix 0 | of matrix 1 | d_in, rows0, rows1, rows2 (16 bits each) |
+    // step word -- or, for PRO_RESID (which never needs the position), the quants of matrix 2.  The deltas of a matrix
+    // follow its quants in the packed layout (include/gten_hip.h), so the weight requests of q|k|v and gate|up need
+    // nothing from the argument struct either.
     GemvHot hot;
     hot.p0 = from_word<void>(h0); hot.p1 = from_word<void>(h1); hot.p2 = from_word<void>(h2);
-    hot.qs0 = from_word<uint8_t>(h3); hot.ds0 = from_word<uint16_t>(h4);
-    hot.d_in = (int)(unsigned)(h5 & 0xffffffffull); hot.rows0 = (int)(unsigned)(h5 >> 32);
-    hot.step = from_word<DecStep>(h6);
+    hot.qs0 = from_word<uint8_t>(h3);
+    const uint8_t* hot_qs1 = from_word<uint8_t>(h4);
+    hot.d_in = (int)(h5 & 0xffffu); hot.rows0 = (int)((h5 >> 16) & 0xffffu);
+    const int hot_rows1 = (int)((h5 >> 32) & 0xffffu), hot_rows2 = (int)(h5 >> 48);
+    const uint8_t* hot_qs2 = (PRO == PRO_RESID) ? from_word<uint8_t>(h6) : a.qs[2];
+    hot.step = (PRO == PRO_RESID) ? nullptr : from_word<DecStep>(h6);
+    constexpr int WBYTES = (WT == GTEN_Q4) ? 16 : 32;                       // quant bytes per block (unused for f16 weights)
+    hot.ds0 = (const uint16_t*)(hot.qs0 + (size_t)hot.rows0 * (hot.d_in >> 5) * WBYTES);
     constexpr int EPT = 2048 / NT;                // prologue elements per thread (d <= 2048 unless PRO_ACTQ8)
     constexpr int LPB = 32 / EPT;                 // lanes per Q8 block
     constexpr int NW = NT / 64;
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     // HBM for the multi-sequence W.x kernel (k_dec_gemvm), which then needs no prologue of its own
     constexpr bool STG = (EPI == EPI_STAGE || EPI == EPI_STAGE_FRAG);
     const int seq = STG ? blockIdx.x : 0;
-    const int n = hot.step[seq].n;
+    const int n = (PRO == PRO_RESID) ? 0 : hot.step[seq].n;      // (PRO_RESID never uses the position)
     const float* res_raw = (const float*)hot.p0 + (size_t)seq * a.raw_stride;     // PRO_RESID only
     const float* res_a = (const float*)hot.p1 + (size_t)seq * d;
     float* x_out = a.x_out ? a.x_out + (size_t)seq * d : nullptr;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     }
 
     // ---- 2. request this wave's weight rows; they stay in flight during the prologue
-    const int rows0 = hot.rows0, rows1 = (NM != 1 && a.n_mats > 1) ? a.rows[1] : 0, rows2 = (NM != 1 && a.n_mats > 2) ? a.rows[2] : 0;
+    const int rows0 = hot.rows0, rows1 = (NM != 1) ? hot_rows1 : 0, rows2 = (NM != 1) ? hot_rows2 : 0;
     const int total = rows0 + rows1 + rows2;
     const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
                                         : (blockIdx.x * NW + wid) * R;
@@ -412,8 +421,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
         const uint8_t* qbase = hot.qs0;
         const uint16_t* dbase = hot.ds0;
         if (lr >= rows0 && rows1 > 0) {
-            lr -= rows0; qbase = a.qs[1]; dbase = a.ds[1];
-            if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; }
+            lr -= rows0; qbase = hot_qs1; dbase = (const uint16_t*)(hot_qs1 + (size_t)rows1 * nb * WBYTES);
+            if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = hot_qs2; dbase = (const uint16_t*)(hot_qs2 + (size_t)rows2 * nb * WBYTES); }
         }
         if (!ok) lr = 0;                          // clamp: always a valid row, result discarded
         const uint16_t* drow = dbase + (size_t)lr * nb;
@@ -2545,12 +2554,24 @@ static GemvHotWords hot_of(const Gemv8Args& a)
     return hw;
 }
 
+// ... and in k_dec_gemv8's own layout (see the kernel): matrices 1 and 2 and all row counts ride along
+template <int WT, int PRO>
+static GemvHotWords hot_of_gemv8(const Gemv8Args& a)
+{
+    GemvHotWords hw = hot_of<WT, PRO>(a);
+    const unsigned long long r1 = a.n_mats > 1 ? (unsigned)a.rows[1] : 0u, r2 = a.n_mats > 2 ? (unsigned)a.rows[2] : 0u;
+    hw.w[4] = (unsigned long long)(uintptr_t)(a.n_mats > 1 ? a.qs[1] : nullptr);
+    hw.w[5] = (unsigned long long)(unsigned)a.d_in | ((unsigned long long)(unsigned)a.rows[0] << 16) | (r1 << 32) | (r2 << 48);
+    hw.w[6] = (PRO == PRO_RESID) ? (unsigned long long)(uintptr_t)(a.n_mats > 2 ? a.qs[2] : nullptr) : (unsigned long long)(uintptr_t)a.step;
+    return hw;
+}
+
 template <int WT, int PRO, int NCH, int R, int NT, int NM = 0>
 static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
     const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
-    const GemvHotWords hw = hot_of<WT, PRO>(a);
+    const GemvHotWords hw = hot_of_gemv8<WT, PRO>(a);
     DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT, NM>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), hw, a);
     return 0;
 }
@@ -2560,7 +2581,7 @@ template <int WT>
 static int launch_gateup8(const Gemv8Args& a, int n_ffn)
 {
     const dim3 grid(n_ffn / 32), block(512);
-    const GemvHotWords hw = hot_of<WT, PRO_RESID>(a);
+    const GemvHotWords hw = hot_of_gemv8<WT, PRO_RESID>(a);
     DEC_LAUNCH_HOT(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), hw, a);
     return 0;
 }
@@ -2651,7 +2672,7 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
 template <int WT, int PRO>
 static int launch_stage(int tag, Gemv8Args a, int n_seq)
 {
-    const GemvHotWords hw = hot_of<WT, PRO>(a);
+    const GemvHotWords hw = hot_of_gemv8<WT, PRO>(a);
     DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), hw, a);
     return 0;
 }
@@ -2660,7 +2681,7 @@ template <int WT, int PRO>
 static int launch_stage_frag(int tag, Gemv8Args a, int n_seq)
 {
     a.frag_rt = (n_seq + 15) / 16;
-    const GemvHotWords hw = hot_of<WT, PRO>(a);
+    const GemvHotWords hw = hot_of_gemv8<WT, PRO>(a);
     DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, 1, 1, EPI_STAGE_FRAG, 512>), dim3(n_seq), dim3(512), stage_bytes(a.d_in), hw, a);
     return 0;
 }
@@ -3012,6 +3033,7 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     const int dh = d.n_embd / d.n_heads;
     GTR_REQUIRE(dh == 32 || dh == 64, "decoder_create: fast path supports d_head 32 or 64 (got %d)", dh);
     GTR_REQUIRE(d.n_embd % 32 == 0 && d.n_ffn % 32 == 0 && d.n_embd <= 2048 && d.n_ffn <= 6144, "decoder_create: unsupported widths (n_embd <= 2048, n_ffn <= 6144)");
+    GTR_REQUIRE(d.n_vocab > 0 && d.n_vocab <= 65535, "decoder_create: n_vocab %d outside [1, 65535] (row counts travel as 16-bit fields of the preloaded arguments)", d.n_vocab);
     GTR_REQUIRE(d.max_ctx > 0 && d.max_ctx <= GTEN_ROPE_MAX_POS, "decoder_create: max_ctx %d beyond the RoPE table", d.max_ctx);
     const bool pair_ok = (d.wdtype == GTEN_F16 && d.adtype == GTEN_F16) || ((d.wdtype == GTEN_Q8 || d.wdtype == GTEN_Q4) && d.adtype == GTEN_Q8);
     GTR_REQUIRE(pair_ok, "decoder_create: unsupported dtype pair (%d,%d) (tinyllama.cpp:258-265)", d.wdtype, d.adtype);
