@@ -413,18 +413,20 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
                                         : (blockIdx.x * NW + wid) * R;
     uint4 wq[R][NCH], wq1[R][NCH];
     uint16_t wd[R][NCH];
+    // the wave's R rows are consecutive rows of ONE matrix (the launchers require the row counts of concatenated
+    // matrices to be multiples of R): the matrix is chosen once per wave, not once per row -- the requests of the
+    // gate|up launch (8 rows per wave) used to trickle out over ~300 instructions of per-row pointer selection
+    int lr0 = r0, rows_m = rows0;
+    const uint8_t* qbase = hot.qs0;
+    if (lr0 >= rows0 && rows1 > 0) {
+        lr0 -= rows0; qbase = hot_qs1; rows_m = rows1;
+        if (lr0 >= rows1 && rows2 > 0) { lr0 -= rows1; qbase = hot_qs2; rows_m = rows2; }
+    }
+    const uint16_t* dbase = (const uint16_t*)(qbase + (size_t)rows_m * nb * WBYTES);
 #pragma unroll
     for (int j = 0; j < R; j++) {
         if (STG) break;                           // no W.x in a staging launch
-        int lr = r0 + j;
-        const bool ok = lr < total;
-        const uint8_t* qbase = hot.qs0;
-        const uint16_t* dbase = hot.ds0;
-        if (lr >= rows0 && rows1 > 0) {
-            lr -= rows0; qbase = hot_qs1; dbase = (const uint16_t*)(hot_qs1 + (size_t)rows1 * nb * WBYTES);
-            if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = hot_qs2; dbase = (const uint16_t*)(hot_qs2 + (size_t)rows2 * nb * WBYTES); }
-        }
-        if (!ok) lr = 0;                          // clamp: always a valid row, result discarded
+        const int lr = min(lr0 + j, rows_m - 1);  // clamp: always a valid row, the result of a row past the end is discarded
         const uint16_t* drow = dbase + (size_t)lr * nb;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -2571,6 +2573,7 @@ static int launch_gemv8(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
     const dim3 grid((total_rows + rows_per_wg - 1) / rows_per_wg), block(NT);
+    for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.rows[k] % R == 0, "decoder: concatenated matrices must hold a multiple of %d rows", R);
     const GemvHotWords hw = hot_of_gemv8<WT, PRO>(a);
     DEC_LAUNCH_HOT(tag, (k_dec_gemv8<WT, PRO, NCH, R, EPI_RAW, NT, NM>), grid, block, stage_bytes((PRO == PRO_ACTQ8 && WT != GTEN_F16) ? 32 : a.d_in), hw, a);
     return 0;
@@ -2581,6 +2584,7 @@ template <int WT>
 static int launch_gateup8(const Gemv8Args& a, int n_ffn)
 {
     const dim3 grid(n_ffn / 32), block(512);
+    GTR_REQUIRE(n_ffn % 32 == 0, "decoder: n_ffn %d is not a multiple of 32", n_ffn);
     const GemvHotWords hw = hot_of_gemv8<WT, PRO_RESID>(a);
     DEC_LAUNCH_HOT(KT_DEC_GEMV_GATEUP, (k_dec_gemv8<WT, PRO_RESID, (WT == GTEN_F16 ? 4 : 1), 8, EPI_SILUMUL, 512>), grid, block, stage_bytes(a.d_in), hw, a);
     return 0;
