@@ -650,17 +650,17 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
                                         : (blockIdx.x * NW + wid) * R;
     uint4 wq[R][NCH], wq1[R][NCH];
     uint16_t wd[R][NCH];
+    // (one matrix per wave: the row counts of concatenated matrices are multiples of R -- see k_dec_gemv8)
+    int lr0 = r0, rows_m = rows0;
+    const uint8_t* qbase = qs0;
+    const uint16_t* dbase = ds0;
+    if (lr0 >= rows0 && rows1 > 0) {
+        lr0 -= rows0; qbase = a.qs[1]; dbase = a.ds[1]; rows_m = rows1;
+        if (lr0 >= rows1 && rows2 > 0) { lr0 -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; rows_m = rows2; }
+    }
 #pragma unroll
     for (int j = 0; j < R; j++) {
-        int lr = r0 + j;
-        const bool ok = lr < total;
-        const uint8_t* qbase = qs0;
-        const uint16_t* dbase = ds0;
-        if (lr >= rows0 && rows1 > 0) {
-            lr -= rows0; qbase = a.qs[1]; dbase = a.ds[1];
-            if (lr >= rows1 && rows2 > 0) { lr -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; }
-        }
-        if (!ok) lr = 0;
+        const int lr = min(lr0 + j, rows_m - 1);
         const uint16_t* drow = dbase + (size_t)lr * nb;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -2702,6 +2702,7 @@ template <int WT, int NCH, int R, int S, int NT>
 static int launch_gemvm(int tag, const Gemv8Args& a, int total_rows)
 {
     const int rows_per_wg = (NT / 64) * R;
+    for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.rows[k] % R == 0, "decoder: concatenated matrices must hold a multiple of %d rows", R);
     const GemvHotWords hw = hot_of<WT, PRO_ACTQ8>(a);
     DEC_LAUNCH_HOT(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT),
                    gemvm_lds_bytes(WT, S, a.d_in, false), hw, a);
