@@ -402,6 +402,7 @@ def main():
         G = min(args.generate, N_CTX - 16)
         P0 = N_CTX - G
         prompt = toks[:P0]
+        model.set_fast_decode(True)                  # (the prefill leg above switches the fused single-row path off)
         t0 = time.perf_counter(); model.logits(prompt, 0, want=True); t_pre = time.perf_counter() - t0
         res = {}
         for name, fn in (("host_loop", model.greedy), ("device_sampler", model.generate)):
