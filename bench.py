@@ -299,6 +299,17 @@ def main():
         "roofline": roofline,
         "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1), "context_fill": args.fill},
     }
+    # secondary: the short-context window n in [16, 80) of the same single-sequence decode path
+    if world == 1 and fused:
+        for n in range(1, 80):
+            model.decode_step(n, use_graph)
+        hip.sync()
+        t0 = time.perf_counter()
+        for n in range(16, 80):
+            model.decode_step(n, use_graph)
+        hip.sync()
+        dts = time.perf_counter() - t0
+        out["short_ctx"] = {"window": "n in [16, 80)", "steps": 64, "ms_per_step": round(dts / 64 * 1e3, 4), "tok_s": round(64 / dts, 1)}
     # secondary: several sequences on this GPU sharing every weight pass (not part of `value`)
     def multi_stream(S, note):
         batch = host.batch(cfg, S)
