@@ -3298,7 +3298,6 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, in
         for (int i = 0; i < cnt; i++)
             if (int rc = run_step(dc, 1)) return rc;
         GTR_CHECK(hipStreamSynchronize(stream()));
-        bool parked = false;
         for (int q = 0; q < S; q++) {
             if (!live[q]) continue;
             GTR_CHECK(hipMemcpy(ids.data(), dc->result + (size_t)q * (ctx + 2) + cur[q], (size_t)cnt * 4, hipMemcpyDeviceToHost));
@@ -3309,12 +3308,11 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, in
             }
             cur[q] += cnt;
             if (stop || cur[q] > last[q]) {
-                live[q] = 0; n_live--; parked = true;
+                live[q] = 0; n_live--;
                 st[q] = DecStep{std::min(cur[q], ctx), 0};
                 GTR_CHECK(hipMemcpy(dc->step + q, &st[q], sizeof(DecStep), hipMemcpyHostToDevice));
             }
         }
-        (void)parked;
     }
     return 0;
 }
