@@ -299,6 +299,20 @@ def main():
         "roofline": roofline,
         "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1), "context_fill": args.fill},
     }
+    # secondary (median and mean per step): the same K steps again with a synchronise after each one,
+    # i.e. the latency a caller that waits for every token sees (`value` above queues the K steps back to back)
+    if world == 1 and fused:
+        per = []
+        for i in range(K):
+            n = n_of(W + i, total)
+            hip.sync()
+            t0 = time.perf_counter()
+            model.decode_step(n, use_graph)
+            hip.sync()
+            per.append(time.perf_counter() - t0)
+        med = float(np.median(per))
+        out["per_step_synced"] = {"steps": K, "median_ms": round(med * 1e3, 4), "mean_ms": round(float(np.mean(per)) * 1e3, 4),
+                                  "tok_s_from_median": round(1.0 / med, 1)}
     # secondary: the short-context window n in [16, 80) of the same single-sequence decode path
     if world == 1 and fused:
         for n in range(1, 80):
