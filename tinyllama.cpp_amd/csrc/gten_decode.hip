@@ -2066,6 +2066,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
 // noise (the wide path's tolerance: model band), statistics and cache rows are formed the same way.
 typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
 typedef float att_f4 __attribute__((ext_vector_type(4)));
+typedef float att_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float row16_max_f(float v)           // maximum over the 16 lanes of a row; every lane gets it
 {
@@ -2237,11 +2238,12 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     const AttnArgs a = attn_for_seq(a0, blockIdx.x);
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)2 * GTEN_Q8_BYTES : (size_t)dh * 2;
 
-    float* p = (float*)g_smem;                                    // [GRP][4][64]: position c at [c & 3][c >> 2]
-    float* part = p;                                              // [GRP][256]: OVER p -- wave cg reads only p[.][cg][.] and later writes
-                                                                  // only part[.][64 cg + lane], the same words: 8 KB of LDS less per
+    constexpr int GP = (GRP + 1) / 2;                             // head pairs: the p.V terms of two heads are ONE packed f32 operation
+    float* p = (float*)g_smem;                                    // [GP][4][64][2]: position c of heads 2 jj, 2 jj + 1 at [jj][c & 3][c >> 2][.]
+    float* part = p;                                              // [GP][4][2][64]: OVER p -- wave cg reads only p[.][cg][.][.] and later writes
+                                                                  // only part[.][cg][.][lane], the same words: 8 KB of LDS less per
                                                                   // workgroup, i.e. 6 instead of 4 resident workgroups per CU
-    unsigned* vl = (unsigned*)(p + GRP * DEC_CHUNK);              // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
+    unsigned* vl = (unsigned*)(p + 2 * GP * DEC_CHUNK);           // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
     float* ms = (float*)(vl + DEC_CHUNK * NW);                    // [GRP][2]: the row maximum and sum of each head
     float* tl = ms + 16;                                          // [GRP][8]: the heads' chunk terms l_j exp(m_j - M) (16-byte aligned)
 
@@ -2306,8 +2308,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
         } else {
             pr = h2f(f2h(x));
         }
-        p[j * DEC_CHUNK + (threadIdx.x & 3) * 64 + (threadIdx.x >> 2)] = pr;
+        p[((((j >> 1) * 4 + (threadIdx.x & 3)) * 64 + (threadIdx.x >> 2)) << 1) + (j & 1)] = pr;
     }
+    if (GRP & 1) p[((((GRP >> 1) * 4 + (threadIdx.x & 3)) * 64 + (threadIdx.x >> 2)) << 1) + 1] = 0.f;
 #pragma unroll
     for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
     __syncthreads();
@@ -2317,40 +2320,44 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const uint8_t* vb = (const uint8_t*)vl;
     const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
-    float acc[GRP];
+    // (multiply and add of two heads in one v_pk_mul_f32 / v_pk_add_f32, or one v_pk_fma_f32: per head the same operations,
+    //  the same roundings, the same order)
+    att_f2 acc[GP];
 #pragma unroll
-    for (int j = 0; j < GRP; j++) acc[j] = 0.f;
+    for (int jj = 0; jj < GP; jj++) acc[jj] = att_f2{0.f, 0.f};
     for (int i = 0; cg + 4 * i < len; i += 4) {
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            // positions past the chunk's end read a valid (clamped) row and meet p = 0
-            const uint8_t* row = vb + (size_t)min(cg + 4 * (i + u), DEC_CHUNK - 1) * (NW * 4);
+            // positions past the context's end are rows of the chunk all the same (i + u <= 63) and meet p = 0
+            const uint8_t* row = vb + (size_t)(cg + 4 * (i + u)) * (NW * 4);
             v[u] = (ADT == GTEN_Q8) ? (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)) : h2f(((const uint16_t*)row)[e]);
         }
 #pragma unroll
-        for (int j = 0; j < GRP; j++) {
-            const float4 pp = *(const float4*)(p + j * DEC_CHUNK + cg * 64 + i);
+        for (int jj = 0; jj < GP; jj++) {
+            const float* pj = p + (((jj * 4 + cg) * 64 + i) << 1);
+            const float4 pa = *(const float4*)pj, pb = *(const float4*)(pj + 4);
+            const att_f2 p0{pa.x, pa.y}, p1{pa.z, pa.w}, p2{pb.x, pb.y}, p3{pb.z, pb.w};
             if (EXACT) {
-                acc[j] += pp.x * v[0];
-                acc[j] += pp.y * v[1];
-                acc[j] += pp.z * v[2];
-                acc[j] += pp.w * v[3];
+                acc[jj] += p0 * att_f2{v[0], v[0]};
+                acc[jj] += p1 * att_f2{v[1], v[1]};
+                acc[jj] += p2 * att_f2{v[2], v[2]};
+                acc[jj] += p3 * att_f2{v[3], v[3]};
             } else {
-                acc[j] = __builtin_fmaf(pp.x, v[0], acc[j]);
-                acc[j] = __builtin_fmaf(pp.y, v[1], acc[j]);
-                acc[j] = __builtin_fmaf(pp.z, v[2], acc[j]);
-                acc[j] = __builtin_fmaf(pp.w, v[3], acc[j]);
+                acc[jj] = __builtin_elementwise_fma(p0, att_f2{v[0], v[0]}, acc[jj]);
+                acc[jj] = __builtin_elementwise_fma(p1, att_f2{v[1], v[1]}, acc[jj]);
+                acc[jj] = __builtin_elementwise_fma(p2, att_f2{v[2], v[2]}, acc[jj]);
+                acc[jj] = __builtin_elementwise_fma(p3, att_f2{v[3], v[3]}, acc[jj]);
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < GRP; j++) part[j * DEC_CHUNK + threadIdx.x] = acc[j];
+    for (int j = 0; j < GRP; j++) part[(((j >> 1) * 4 + cg) * 2 + (j & 1)) * 64 + e] = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
     __syncthreads();
     for (int idx = threadIdx.x; idx < GRP * dh; idx += 256) {
         const int j = idx >> 6, ee = idx & 63;
         float o = 0.f;
-        for (int gi = 0; gi < 4; gi++) o += part[j * DEC_CHUNK + gi * dh + ee];
+        for (int gi = 0; gi < 4; gi++) o += part[(((j >> 1) * 4 + gi) * 2 + (j & 1)) * 64 + ee];
         a.att_part[((size_t)(g * GRP + j) * a.n_chunks + chunk) * dh + ee] = o;
     }
 }
@@ -2462,7 +2469,7 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
     const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64 +
                          (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4 + 16);
-    const size_t smem2 = (size_t)GRP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
+    const size_t smem2 = (size_t)((GRP + 1) / 2 * 2) * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
     // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (GTEN_HIP_ATTN_EXACT=1)
     const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
     const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
