@@ -373,10 +373,12 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     // stale but readable data and are dropped by a select below; decoder_create: n_chunks <= DEC_ATT_MAXCH)
     float apart[PRO == PRO_ATT ? DEC_ATT_MAXCH : 1][EPT];
     if (PRO == PRO_ATT) {
-        const int h = sbase >> att_shift, e = sbase & (att_dh - 1);
+        // (32-bit index arithmetic, the head width as a shift: one integer multiply ahead of the eight requests, not seventeen)
+        const unsigned h = (unsigned)sbase >> att_shift, e = (unsigned)sbase & (unsigned)(att_dh - 1);
+        const unsigned row0 = h * (unsigned)att_chunks;
 #pragma unroll
         for (int j = 0; j < DEC_ATT_MAXCH; j++)
-            ldN<EPT>(att_part + ((size_t)h * att_chunks + min(j, att_chunks - 1)) * att_dh + e, apart[j]);
+            ldN<EPT>(att_part + (((row0 + (unsigned)min(j, att_chunks - 1)) << att_shift) + e), apart[j]);
     }
     unsigned emb[4] = {0, 0, 0, 0};
     float emb_delta = 0.f;
