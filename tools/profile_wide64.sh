@@ -1,0 +1,9 @@
+# rocprofv3 kernel trace of the 64-sequence decode leg (run on the GPU box: gpurun -- bash tools/profile_wide64.sh)
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+( while sleep 40; do echo tick; done ) & HB=$!
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_w64b -- python3 $R/bench.py --no-cpu-baseline --streams 0 --wide-streams 64 --prefill 0 --generate 0 --fill prefill --steps 32 --warmup 8 > $R/gpurun_out/w64b_bench.json 2> $R/gpurun_out/w64b.err
+rc=$?
+kill $HB
+echo rc=$rc
+ls $R/gpurun_out/prof_w64b/*/ | head
