@@ -10,9 +10,16 @@ K timed steps bracketed by barrier + device synchronise.  Synthetic weights
 (seeded generator, quantized with the reference converter's rules) and
 teacher-forced synthetic token ids: there is no network for checkpoints.
 
-N > 1 (`torch.distributed.run`, one rank per GPU): independent replicas, one
-prompt stream per GPU, no collective on the data path; `value`
-is the sum over ranks of tokens decoded / the slowest rank's time.
+N > 1: independent replicas, one process and one prompt stream per GPU, no
+collective on the data path; `value` is the sum over ranks of
+tokens decoded / the slowest rank's time.  Either launcher works:
+  python bench.py --gpus N ...                          (this file starts N workers itself:
+                                                         tinyllama.cpp_amd/replicas.py launch())
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+The N > 1 line also carries every rank's own rate, rank 0's rate measured alone
+in the same run (the other GPUs idle) and efficiency = value / (N x that rate);
+`--curve` (own launcher only) first runs the smaller power-of-two replica counts
+and adds their values as `scaling_curve`.
 
 Output: ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event
 timed on the library's stream) and `cpu_baseline` (the reference's own
@@ -53,7 +60,7 @@ def linear_shapes():
             ("gate", 5632, 2048, 22), ("up", 5632, 2048, 22), ("down", 2048, 5632, 22), ("lm_head", 32003, 2048, 1)]
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -77,7 +84,49 @@ def parse_args():
                          "(default) or one prompt-processing call -- the latter keeps a rocprofv3 kernel trace to "
                          "thousands instead of hundreds of thousands of launches")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
-    return ap.parse_args()
+    ap.add_argument("--brief", action="store_true", help="only the metric line: no secondary legs, no CPU baseline")
+    ap.add_argument("--curve", action="store_true",
+                    help="with --gpus N > 1 under this file's own launcher: first run 1, 2, 4, ... < N replicas (brief) and "
+                         "report their values as `scaling_curve` in the N-replica line")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="own launcher: seconds before the workers are ended")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a one-GPU box: every replica decodes on GPU 0 and the bookkeeping runs on gloo "
+                         "(RCCL refuses two ranks on one device); the line says so -- not a scaling measurement")
+    ap.add_argument("--engine", choices=["hip", "stub"], default="hip",
+                    help="stub: NO GPU work at all -- a sleeping stand-in for the decoder, used only by the CPU tests of the "
+                         "launcher / rendezvous / JSON assembly (tests/test_bench_launcher_cpu.py); its line says so")
+    return ap.parse_args(argv)
+
+
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources the in-tree libgten_hip.so is built from: what ties
+    profiles/traffic.json (PMC counters collected by tools/collect_traffic.sh) to the kernels being benched --
+    the GPU box has no .git, so a source hash rather than a commit id"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tinyllama.cpp_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(mode, family):
+    """HBM bytes per launch of `family` from the rocprofv3 PMC passes, or (None, why) when the committed counters
+    were not collected on these kernel sources"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/traffic.json absent"
+    try:
+        t = json.load(open(tpath))
+    except Exception as e:
+        return None, "profiles/traffic.json unreadable: %r" % (e,)
+    if t.get("csrc_sha256_16") != csrc_fingerprint():
+        return None, "profiles/traffic.json was collected on other kernel sources (%s, now %s): stale, not reported" % (
+            t.get("csrc_sha256_16"), csrc_fingerprint())
+    v = t.get(mode, {}).get(family)
+    return v, (t.get("source") if v is not None else "no counters for %s / %s in profiles/traffic.json" % (mode, family))
 
 
 def cpu_baseline(host, cfg, mode, seed, n_steps):
@@ -112,7 +161,11 @@ def cpu_baseline(host, cfg, mode, seed, n_steps):
     gomp = ctypes.CDLL("libgomp.so.1")
     hw = os.cpu_count() or 1
     tried = {}
-    for threads in sorted({8, 16, 32, 64, hw} & set(range(1, hw + 1))):
+    for threads in sorted(t for t in {8, 16, 32, 64, min(hw, 64)} if t <= hw):
+        # team sizes up to 64 only (all 256 hardware threads of the GPU box: 19.5 s per step, round 1), and stop
+        # once a larger team has become clearly slower than the best one seen
+        if tried and threads > 16 and tried[max(tried)] > 1.5 * min(tried.values()):
+            break
         gomp.omp_set_num_threads(threads)
         times = []
         for i in range(n_steps):
@@ -131,44 +184,149 @@ def cpu_baseline(host, cfg, mode, seed, n_steps):
             "ms_per_step": round(med * 1e3, 2), "setup_s": round(t_build, 1)}
 
 
-def main():
-    args = parse_args()
+class StubDecoder:
+    """NOT a decoder: no GPU, no arithmetic.  A stand-in with the decode_step interface whose step sleeps, so that the
+    CPU tests can drive this file's launcher, the torch.distributed rendezvous (gloo) and the JSON assembly without a
+    GPU (--engine stub; tests/test_bench_launcher_cpu.py).  The line it produces is labelled as such."""
+    step_s = 0.002
+
+    def decode_begin(self, toks):
+        self.toks = toks
+
+    def decode_step(self, n, use_graph=True):
+        time.sleep(self.step_s * (1.0 + 0.25 * int(os.environ.get("RANK", "0"))))     # higher ranks are the slow replicas
+        if os.environ.get("GTEN_BENCH_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise SystemExit(3)
+
+    def decode_result(self, n):
+        return int(self.toks[n - 1])
+
+    def close(self):
+        pass
+
+
+def load_replicas():
+    """tinyllama.cpp_amd/replicas.py by path: the launcher parent must not import anything that could touch the GPU"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gten_replicas", os.path.join(ROOT, "tinyllama.cpp_amd", "replicas.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            return json.loads(line)
+    return None
+
+
+def launcher(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N workers, relay rank 0's line.
+    This process never initialises the GPU (counting devices reads sysfs) and never exec()s."""
+    rep = load_replicas()
+    n = args.gpus
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--curve"]
+    curve = []
+    if args.curve:
+        m = 1
+        while m < n:
+            sub = [a for a in cmd]
+            gi = sub.index("--gpus")
+            sub[gi + 1] = str(m)
+            rc, out0 = rep.launch(m, sub + ["--brief"], timeout=args.launch_timeout)
+            line = last_json_line(out0)
+            if rc != 0 or line is None:
+                print(f"bench.py: the {m}-replica run of --curve failed (exit {rc})", file=sys.stderr)
+                return rc or 1
+            curve.append({"n_gpus": m, "value": line["value"], "ms_per_step": line["ms_per_step"]})
+            m *= 2
+    t0 = time.time()
+    rc, out0 = rep.launch(n, cmd, timeout=args.launch_timeout)
+    line = last_json_line(out0)
+    if rc != 0 or line is None:
+        sys.stdout.write(out0)
+        print(f"bench.py: a replica failed (exit {rc})" if rc else "bench.py: rank 0 printed no result line", file=sys.stderr)
+        return rc or 1
+    line["launcher"] = {"kind": "bench.py (subprocess per GPU; tinyllama.cpp_amd/replicas.py launch())", "wall_s": round(time.time() - t0, 1)}
+    if curve:
+        one = curve[0]["value"]
+        line["scaling_curve"] = curve + [{"n_gpus": n, "value": line["value"], "ms_per_step": line["ms_per_step"]}]
+        for c in line["scaling_curve"]:
+            c["efficiency_vs_1gpu_run"] = round(c["value"] / (c["n_gpus"] * one), 4)
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if "--gpus" not in argv:                       # --gpus=N form: normalise for the workers' command line
+            argv = [a for a in argv if not a.startswith("--gpus=")] + ["--gpus", str(args.gpus)]
+        return launcher(args, argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
+    if args.rehearse_one_gpu:
+        local_rank = 0
+        os.environ["GTEN_HIP_DEVICE"] = "0"
     os.environ.setdefault("GTEN_HIP_DEVICE", str(local_rank))
     # weight synthesis is OpenMP code on the host: share the cores between the ranks of this node
     os.environ.setdefault("OMP_NUM_THREADS", str(max(4, (os.cpu_count() or 8) // max(world, 1))))
+    stub = args.engine == "stub"
 
-    import numpy as np
     import torch
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # launched by torch.distributed.run: one rank per GPU
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # one rank per GPU (torch.distributed.run or launcher() above)
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if stub or args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    try:
+        return worker(args, rank, local_rank, world, dist)
+    finally:
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
 
-    from __graft_entry__ import load_package
-    pkg = load_package()
-    rep_seed = importlib.import_module(pkg.__name__ + ".replicas").prompt_seed
-    hip = pkg.hipabi.load(local_rank)
-    host = pkg.load_host()
 
-    wd, ad = MODES[args.mode]
-    cfg = host.default_config(wd, ad)
-    model = host.model(cfg)
-    t0 = time.time()
-    model.load_synthetic(args.seed)
-    load_s = time.time() - t0
-
+def worker(args, rank, local_rank, world, dist):
+    import numpy as np
+    import torch
+    stub = args.engine == "stub"
+    rep = load_replicas()
+    rep_seed = rep.prompt_seed
     K, W = args.steps, args.warmup
     global N_CTX
     N_CTX = args.ctx
     use_graph = not args.no_graph
-    toks = host.synthetic_tokens(N_CTX, seed=rep_seed(12345, rank))
-    fused = hasattr(model, "decode_step") and args.path in ("auto", "fused")
-    if args.path == "fused" and not fused:
-        raise SystemExit("fused decode path requested but not built")
+    wd, ad = MODES[args.mode]
+    if stub:
+        hip = host = cfg = None
+        model = StubDecoder()
+        load_s = 0.0
+        rng = np.random.default_rng(rep_seed(12345, rank))
+        toks = rng.integers(3, 31993, N_CTX).astype(np.int32)
+        fused = True
+    else:
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        hip = pkg.hipabi.load(local_rank)
+        host = pkg.load_host()
+        cfg = host.default_config(wd, ad)
+        model = host.model(cfg)
+        t0 = time.time()
+        model.load_synthetic(args.seed)
+        load_s = time.time() - t0
+        toks = host.synthetic_tokens(N_CTX, seed=rep_seed(12345, rank))
+        fused = hasattr(model, "decode_step") and args.path in ("auto", "fused")
+        if args.path == "fused" and not fused:
+            raise SystemExit("fused decode path requested but not built")
 
     window = 64                                  # timed steps cycle over n in (N_CTX-window, N_CTX]
     def n_of(i, total):
@@ -192,7 +350,9 @@ def main():
     total = K + W
     first = n_of(0, total)
     t_fill = time.time()
-    if args.fill == "prefill" and first > 1:
+    if stub:
+        pass                                     # nothing to fill
+    elif args.fill == "prefill" and first > 1:
         model.logits(toks[:first - 1], 0, want=False)
     else:
         for n in range(1, first):
@@ -200,28 +360,46 @@ def main():
                 model.decode_step(n, use_graph)
             else:
                 model.logits(toks[:n], n - 1, want=False)
-    hip.sync()
+
+    def sync():
+        if not stub:
+            hip.sync()
+            torch.cuda.synchronize()
+
+    sync()
     t_fill = time.time() - t_fill
     for i in range(W):
         step(n_of(i, total))
-
-    def sync():
-        hip.sync()
-        torch.cuda.synchronize()
 
     def run_steps():
         for i in range(W, W + K):
             step(n_of(i, total))
         return K
 
+    ddev = None if (dist is None or stub or args.rehearse_one_gpu) else "cuda"
+    # N > 1: rank 0's rate with the other GPUs idle (they wait at the barrier), the denominator of `efficiency`
+    solo = None
+    if dist is not None:
+        dist.barrier()
+        if rank == 0:
+            solo_dt, solo_tokens = rep.timed_region(run_steps, sync)
+            solo = solo_tokens / solo_dt
+        dist.barrier()
     # barrier + synchronise on both sides of exactly K steps; MAX elapsed over ranks
-    rep = importlib.import_module(pkg.__name__ + ".replicas")
-    elapsed, total_tokens = rep.timed_region(run_steps, sync, dist=dist, device="cuda" if dist is not None else None)
+    elapsed, total_tokens, per_rank = rep.timed_region(run_steps, sync, dist=dist, device=ddev, per_rank=True)
     last = model.decode_result(n_of(W + K - 1, total)) if fused else step(n_of(W + K - 1, total))
+    # the replicas are done with each other: every rank leaves the process group here (rank 0 goes on alone with the
+    # roofline / CPU-baseline legs, the others exit and free their host cores)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        model.close()
+        return 0
 
     # ---- roofline of the dominant kernel: HIP events on the library's stream
     roofline = None
-    if rank == 0:
+    if not stub:
         P = min(16, K)
         hip.prof_enable(True)
         for i in range(P):
@@ -269,21 +447,15 @@ def main():
                     "family_avg_launch_us": family_us,
                     "per_launch_event_bracket_us": {k: round(v[1] * 1e3 / v[0], 2) for k, v in prof.items()},
                     "bracket_share_of_step": {k: round(v[1] / P / step_ms, 3) for k, v in prof.items()}}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                roofline["traffic"] = json.load(open(tpath)).get(args.mode, {}).get(fam)
-            except Exception:
-                pass
+        roofline["traffic"], roofline["traffic_source"] = measured_traffic(args.mode, fam)
+        roofline["csrc_sha256_16"] = csrc_fingerprint()
 
-    if rank != 0:
-        return
     tok_s = total_tokens / elapsed
     ms_step = elapsed / K * 1e3
     n_mid = N_CTX - K // 2 if total <= N_CTX - 1 else N_CTX - window // 2
     whole = algorithmic_bytes(args.mode, n_mid) / (ms_step * 1e-3) / 1e9
     out = {
-        "metric": f"decode tok/s TinyLlama-1.1B {args.mode} ctx=2048, 1 GPU; achieved HBM GB/s vs peak",
+        "metric": f"decode tok/s TinyLlama-1.1B {args.mode} ctx=2048, {world} GPU{'s' if world > 1 else ''}; achieved HBM GB/s vs peak",
         "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"q4": "q4 weights x q8 activations (int8 dot, f32 accumulate)", "q8": "q8 x q8 (int8 dot, f32 accumulate)",
@@ -299,9 +471,24 @@ def main():
         "roofline": roofline,
         "setup": {"weights_s": round(load_s, 1), "context_fill_s": round(t_fill, 1), "context_fill": args.fill},
     }
+    if world > 1:
+        out["per_rank"] = [{"rank": r, "tok_s": round(k / e, 2), "ms_per_step": round(e / max(k, 1) * 1e3, 4)}
+                           for r, (e, k) in enumerate(per_rank)]
+        out["solo_rank0_tok_s"] = round(solo, 2)
+        out["efficiency"] = round(tok_s / (world * solo), 4)
+        out["efficiency_note"] = ("value / (n_gpus x rank 0's rate over the same K steps while the other GPUs idle at a "
+                                  "barrier, same run); value = tokens of all ranks / the slowest rank's time")
+    if args.rehearse_one_gpu and world > 1:
+        out["metric"] = "REHEARSAL (all %d replicas share GPU 0): " % world + out["metric"]
+    if stub:
+        out["whole_step_hbm"] = None
+        out["metric"] = "STUB (no GPU work): " + out["metric"]
+        out["data"] = "none: --engine stub sleeps instead of decoding (launcher / rendezvous test only)"
+        out["config"]["path"] = "stub"
+    secondary = world == 1 and not args.brief and not stub
     # secondary (median and mean per step): the same K steps again with a synchronise after each one,
     # i.e. the latency a caller that waits for every token sees (`value` above queues the K steps back to back)
-    if world == 1 and fused:
+    if secondary and fused:
         per = []
         for i in range(K):
             n = n_of(W + i, total)
@@ -314,7 +501,7 @@ def main():
         out["per_step_synced"] = {"steps": K, "median_ms": round(med * 1e3, 4), "mean_ms": round(float(np.mean(per)) * 1e3, 4),
                                   "tok_s_from_median": round(1.0 / med, 1)}
     # secondary: the short-context window n in [16, 80) of the same single-sequence decode path
-    if world == 1 and fused:
+    if secondary and fused:
         for n in range(1, 80):
             model.decode_step(n, use_graph)
         hip.sync()
@@ -366,7 +553,7 @@ def main():
         batch.close()
         return res
 
-    if world == 1 and fused and (args.streams > 1 or args.wide_streams > 1):
+    if secondary and fused and (args.streams > 1 or args.wide_streams > 1):
         model.close()
         if args.streams > 1:
             out["multi_stream"] = multi_stream(args.streams, "GEMV kernels: per sequence bit-identical to the single-sequence decoder "
@@ -381,7 +568,7 @@ def main():
         model = host.model(cfg)
         model.load_synthetic(args.seed)
     # secondary: real greedy generation of a whole batch (sampler on the device, every sequence its own prompt)
-    if world == 1 and fused and args.generate > 0 and args.wide_streams > 1:
+    if secondary and fused and args.generate > 0 and args.wide_streams > 1:
         S = args.wide_streams
         G = min(args.generate, N_CTX - 16)
         P0 = N_CTX - G
@@ -404,7 +591,7 @@ def main():
                                            "n_seq x one prompt's processing time)" % N_CTX}
         batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
-    if world == 1 and args.prefill > 0:
+    if secondary and args.prefill > 0:
         P = min(args.prefill, N_CTX)
         model.set_fast_decode(False)
         model.logits(toks[:P], 0, want=False)
@@ -423,7 +610,7 @@ def main():
                                   "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time"}
     # secondary: real greedy generation (every token is the argmax of the previous step), the reference-style loop
     # (logits to the host, host argmax, one call per token) against the sampler on the device
-    if world == 1 and fused and args.generate > 0:
+    if secondary and fused and args.generate > 0:
         G = min(args.generate, N_CTX - 16)
         P0 = N_CTX - G
         prompt = toks[:P0]
@@ -438,15 +625,15 @@ def main():
         out["greedy_generation"] = {"prompt_tokens": P0, "prefill_ms": round(t_pre * 1e3, 2), **res,
                                     "same_ids": res["host_loop"]["last"] == res["device_sampler"]["last"],
                                     "note": "ids generated up to n = %d; tok/s = new ids / (wall time - prompt processing time)" % N_CTX}
-    if not args.no_cpu_baseline and world == 1:
+    # the CPU path beside it: once per run, on rank 0, after the other ranks have exited
+    if not args.no_cpu_baseline and not args.brief and not stub:
         try:
             out["cpu_baseline"] = cpu_baseline(host, cfg, args.mode, args.seed, args.cpu_steps)
         except Exception as e:                      # the baseline is a reported extra, never the product path
             out["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
