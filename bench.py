@@ -129,6 +129,40 @@ def measured_traffic(mode, family):
     return v, (t.get("source") if v is not None else "no counters for %s / %s in profiles/traffic.json" % (mode, family))
 
 
+def dropin_leg(host, cfg, args, toks):
+    """greedy generation to n = 2048 through oracle/_ref/libdropin.so = the reference's translation unit on this
+    repository's gten API (what a user of the reference gets by swapping the gten/ directory)"""
+    from oracle import orc
+    lib = orc.load_dropin()
+    if lib is None:
+        raise RuntimeError("oracle/_ref/libdropin.so not built (needs /root/reference at build time)")
+    wd, ad = MODES[args.mode]
+    path = f"/tmp/gten_bench_{args.mode}_{args.seed}.gten"
+    if not os.path.exists(path) or os.path.getsize(path) < 1000:
+        host.write_gten(cfg, args.seed, path + ".tmp")
+        os.replace(path + ".tmp", path)
+    G = min(args.generate, N_CTX - 16)
+    P0 = N_CTX - G
+    res = {}
+    for name, fused_rows in (("fused_rows", True), ("operators", False)):
+        lib.set_fused_rows(fused_rows)
+        m = lib.tinyllama(N_CTX, wd, ad)
+        m.load(path)
+        new = G if fused_rows else min(G, 32)                 # the operator-by-operator loop is ~15x slower: a short sample
+        t0 = time.perf_counter(); m.logits(toks[:P0], 0); t_pre = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ids = m.greedy(toks[:P0], P0 + new)
+        dt = time.perf_counter() - t0
+        res[name] = {"new_tokens": int(len(ids) - P0), "tok_s": round((len(ids) - P0) / max(dt - t_pre, 1e-9), 1),
+                     "ids_head": [int(x) for x in ids[P0:P0 + 8]]}
+        m.close()
+    lib.set_fused_rows(True)
+    return {"prompt_tokens": P0, "tok_s": res["fused_rows"]["tok_s"], **res,
+            "same_ids": res["fused_rows"]["ids_head"] == res["operators"]["ids_head"],
+            "note": "reference's unmodified TinyLlama::logits + host argmax per token on this repository's gten/ headers "
+                    "(libdropin.so); ids generated up to n = %d; tok/s = new ids / (wall - prompt processing)" % N_CTX}
+
+
 def cpu_baseline(host, cfg, mode, seed, n_steps):
     """Time the CPU path on this box's host cores on a bounded sample of the same
     workload: single-token decode steps ending at n = 2048.  The K/V history below
@@ -625,6 +659,15 @@ def worker(args, rank, local_rank, world, dist):
         out["greedy_generation"] = {"prompt_tokens": P0, "prefill_ms": round(t_pre * 1e3, 2), **res,
                                     "same_ids": res["host_loop"]["last"] == res["device_sampler"]["last"],
                                     "note": "ids generated up to n = %d; tok/s = new ids / (wall time - prompt processing time)" % N_CTX}
+    # secondary: the reference's OWN caller on this path -- its unmodified tinyllama.cpp (TinyLlama::logits per token,
+    # logits read on the host, host argmax: tinyllama.cpp:395-440) compiled against this repository's gten headers
+    # (oracle/Makefile `dropin`, built where /root/reference exists; the .so travels).  gten/modules.h records the
+    # single-row module calls and runs them as one fused decoder step.
+    if secondary and fused and args.generate > 0 and args.mode == "q4":
+        try:
+            out["dropin"] = dropin_leg(host, cfg, args, toks)
+        except Exception as e:
+            out["dropin"] = {"tok_s": None, "note": "drop-in leg unavailable: %r" % (e,)}
     # the CPU path beside it: once per run, on rank 0, after the other ranks have exited
     if not args.no_cpu_baseline and not args.brief and not stub:
         try:

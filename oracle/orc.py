@@ -222,6 +222,14 @@ class CpuModel:
         self.lib._mlogits(self.h, _p(tokens), len(tokens), start_pos, _p(out))
         return out
 
+    def partial_row(self, tokens, start_pos, n_blocks):
+        """drop-in build only: embedding + the first n_blocks blocks, then a host read of the last activation row"""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.zeros(1 << 16, np.uint8)
+        got = self.lib._mpartial(self.h, _p(tokens), len(tokens), start_pos, n_blocks, _p(out), out.size)
+        assert got > 0
+        return out[:got].copy()
+
     def close(self):
         if self.h:
             self.lib._mfree(self.h)
@@ -252,6 +260,13 @@ class RefTinyLlama:
         out = np.zeros(self.N_VOCAB, dtype=np.float32)
         self.lib._tl_logits(self.h, _p(tokens), len(tokens), start_pos, _p(out))
         return out
+
+    def greedy(self, prompt, max_tokens, eos=-1):
+        """drop-in build only: the reference's greedy loop (logits() per token, host argmax) on token ids"""
+        buf = np.zeros(max_tokens, np.int32)
+        buf[: len(prompt)] = prompt
+        total = self.lib._tl_greedy(self.h, _p(buf), len(prompt), max_tokens, eos)
+        return buf[:total].copy()
 
     def close(self):
         if self.h:
@@ -310,7 +325,14 @@ class DropinLib:
         self._tl_free = sig("tl_free", None, [vp])
         self._tl_load = sig("tl_load", ci, [vp, C.c_char_p])
         self._tl_logits = sig("tl_logits", None, [vp, vp, ci, ci, vp])
+        self._tl_greedy = sig("tl_greedy", ci, [vp, vp, ci, ci, ci])
+        self._mpartial = sig("model_partial_row", sz, [vp, vp, ci, ci, ci, vp, sz])
+        self._set_fused = sig("set_fused_rows", None, [ci])
         self.prefix = "ref_"
+
+    def set_fused_rows(self, on):
+        """single-row recording of gten/modules.h (fused decoder behind the unmodified module calls) on / off"""
+        self._set_fused(1 if on else 0)
 
     def model(self, cfg):
         return CpuModel(self, cfg)

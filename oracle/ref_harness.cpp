@@ -266,6 +266,21 @@ void ref_model_logits(ref_model* m, const int32_t* tokens, int n, int start_pos,
     std::memcpy(out, t.data_ptr<float>(), (size_t)m->c.n_vocab * sizeof(float));
 }
 
+// The first `n_blocks` blocks only, then the caller LOOKS at the activation row (host read): with the drop-in
+// headers this interrupts a recorded single-row forward half way (gten/modules.h), which must then produce what
+// the operators produce.  Copies the last row's storage bytes to `out`; returns their count.
+size_t ref_model_partial_row(ref_model* m, const int32_t* tokens, int n, int start_pos, int n_blocks, void* out, size_t cap)
+{
+    Tensor tk(tokens, {n}, gten::kInt32);
+    Tensor t = m->emb.forward(tk, start_pos);
+    for (int i = 0; i < n_blocks; i++) t = m->blocks[(size_t)i].forward(t, start_pos);
+    const size_t pitch = (size_t)t.bstride(0);
+    if (pitch > cap) return 0;
+    const Tensor& ct = t;
+    std::memcpy(out, ct.data_ptr<char>() + (size_t)(n - 1) * pitch, pitch);
+    return pitch;
+}
+
 // ---- the reference's own TinyLlama class (full-size, tinyllama.cpp:23-76)
 struct ref_tinyllama { TinyLlama model; ref_tinyllama(int n_ctx, gten::ModuleDtype md) : model(n_ctx, md) {} };
 
@@ -287,6 +302,36 @@ void ref_tl_logits(ref_tinyllama* t, const int32_t* tokens, int n, int start_pos
     Tensor lg = t->model.logits(tk, start_pos);
     std::memcpy(out, lg.data_ptr<float>(), (size_t)lg.numel() * sizeof(float));
 }
+
+#ifdef GTEN_DROPIN
+// drop-in build only: the single-row recording of this repository's gten/modules.h on / off (tests compare both)
+void ref_set_fused_rows(int on) { gten::detail::fused_rows_enabled() = on != 0; }
+
+// The reference's greedy loop (tinyllama.cpp:395-440) on token ids -- its TinyLlama::logits() per token, the
+// logits read through data_ptr<float>() and the argmax on the host, exactly as upstream; only the tokenizer and
+// the printing are left out.  Returns the total number of ids in `tokens` (capacity n_predict).
+int ref_tl_greedy(ref_tinyllama* t, int32_t* tokens, int n_prompt, int n_predict, int eos)
+{
+    int n = n_prompt;
+    const int max_iters = n_predict - n_prompt;
+    for (int i = 0; i < max_iters; i++) {
+        Tensor input{tokens, {n}, gten::kInt32};
+        const int start_pos = (i == 0) ? 0 : input.numel() - 1;
+        Tensor logits = t->model.logits(input, start_pos);
+        const int logits_size = logits.numel();
+        const float* logits_data = logits.data_ptr<float>();
+        float max_prob = -std::numeric_limits<float>::infinity();
+        int max_index = 0;
+        for (int j = 0; j < logits_size; ++j) {
+            const float val = logits_data[j];
+            if (val > max_prob) { max_prob = val; max_index = j; }
+        }
+        if (max_index == eos) break;
+        tokens[n++] = max_index;
+    }
+    return n;
+}
+#endif
 
 // ---- the reference's own Tokenizer (tokenizer.h, included by tinyllama.cpp): pins for host/tokenizer.h
 struct ref_tokenizer { Tokenizer tok; ref_tokenizer(const char* path, int vocab) : tok(path, vocab) {} };

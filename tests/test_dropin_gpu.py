@@ -73,3 +73,87 @@ def test_reference_tinyllama_class_loads_gten_and_decodes(dropin, tmp_path):
         ref_vals = np.concatenate([g["q4.avx.top_logits"][step], g["q4.avx.probes"][step]])
         band("q4", np.concatenate([lg[ids], lg[probe]]) - ref_vals, float(g["q4.avx.stats"][step][1]))
     m.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_single_row_calls_run_as_one_fused_decoder_step(dropin, name, wd, ad):
+    """the reference's unmodified module calls (Embedding -> AttentionBlock x L -> RMSNorm -> EmbeddingLinear with one
+    new row, tinyllama.cpp:45-61) are recorded by gten/modules.h and run as ONE fused decoder step.  Against the same
+    calls with the recording switched off (operator by operator): the same bytes while the context fits one attention
+    chunk (n <= 256), the model band beyond (chunked softmax: f32 summation order)."""
+    from test_model_gpu import check_logits
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2)
+    cfg = pkg.HostConfig(**{k: getattr(ocfg, k) for k, _ in ocfg._fields_})
+    toks = host.synthetic_tokens(300, seed=91, n_vocab=cfg.n_vocab)
+    runs = []
+    for fused in (True, False):
+        dropin.set_fused_rows(fused)
+        m = dropin.model(ocfg)
+        for i in range(m.n_weights()):
+            m.set_weight(i, host.synth_weight(cfg, 606, i))
+        out = {9: m.logits(toks[:9], 0)}                      # prompt: several rows, operator path either way
+        for n in range(10, 301):
+            lg = m.logits(toks[:n], n - 1)
+            if n in (10, 11, 40, 255, 256, 257, 300):
+                out[n] = lg
+        runs.append(out)
+        m.close()
+    dropin.set_fused_rows(True)
+    for n, a in runs[0].items():
+        b = runs[1][n]
+        if n <= 256:
+            assert np.array_equal(a, b), (name, n, float(np.abs(a - b).max()))
+        else:
+            check_logits(name, a, b, float(b.std()))
+    assert not np.array_equal(runs[0][10], runs[0][11])
+
+
+def test_interrupted_single_row_forward_settles_through_the_operators(dropin):
+    """a caller that stops after k blocks and reads the activation row (or starts another forward) gets exactly what
+    the operator path computes: the recorded calls are settled, never dropped"""
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=64, n_layers=2)
+    cfg = pkg.HostConfig(**{k: getattr(ocfg, k) for k, _ in ocfg._fields_})
+    toks = host.synthetic_tokens(24, seed=5, n_vocab=cfg.n_vocab)
+    rows = []
+    for fused in (True, False):
+        dropin.set_fused_rows(fused)
+        m = dropin.model(ocfg)
+        for i in range(m.n_weights()):
+            m.set_weight(i, host.synth_weight(cfg, 17, i))
+        got = [m.logits(toks[:9], 0)]
+        got.append(m.partial_row(toks[:10], 9, 0))            # embedding row only
+        got.append(m.partial_row(toks[:10], 9, 1))            # + first block (writes K/V row 9 of block 0 again)
+        got.append(m.logits(toks[:10], 9))                    # the whole row
+        got.append(m.partial_row(toks[:11], 10, 2))           # both blocks, no head
+        got.append(m.logits(toks[:11], 10))
+        got.append(m.logits(toks[:14], 11))                   # three new rows: operators
+        got.append(m.logits(toks[:15], 14))
+        rows.append(got)
+        m.close()
+    dropin.set_fused_rows(True)
+    for i, (a, b) in enumerate(zip(*rows)):
+        assert np.array_equal(a, b), i
+
+
+def test_reference_greedy_loop_on_the_fused_rows(dropin, tmp_path):
+    """the reference's TinyLlama class + its greedy loop (logits() per token, host argmax), full-size q4: the ids with
+    the single-row recording on equal the ids operator by operator"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host.default_config(Q4, Q8)
+    gten_path = str(tmp_path / "tinyllama.q4.gten")
+    host.write_gten(cfg, 1234, gten_path)
+    prompt = host.synthetic_tokens(15, seed=12345)
+    ids = []
+    for fused in (True, False):
+        dropin.set_fused_rows(fused)
+        m = dropin.tinyllama(64, Q4, Q8)
+        m.load(gten_path)
+        ids.append(m.greedy(prompt, 40).tolist())
+        m.close()
+    dropin.set_fused_rows(True)
+    assert len(ids[0]) == 40 and ids[0] == ids[1]

@@ -11,6 +11,18 @@
 // value projections (`attn.key.acv`, `attn.value.acv`: [max_ctx][kv_dim] in the
 // activation dtype; rows below start_pos persist between calls).
 //
+// One new row (decode): when forward() is called with exactly one new row on Embedding, then on each
+// AttentionBlock with the previous module's output, then on RMSNorm and EmbeddingLinear -- the sequence of
+// TinyLlama::logits (tinyllama.cpp:45-61) -- the calls are RECORDED and the whole row runs as one fused decoder
+// step (include/gten_hip.h "single-token decode fast path": 6 launches per block from one hipGraph instead of
+// ~16 operator launches), on the same HBM tensors: weights, K/V caches (= attn.key.acv / attn.value.acv) and the
+// logits buffer (= EmbeddingLinear::acv).  Same bytes as the operator path for contexts up to 256 rows, f32
+// summation-order noise of the chunked softmax beyond (tests/test_dropin_gpu.py).  Any other use -- a different
+// call order, several new rows, someone reading an intermediate tensor, a configuration the decoder does not
+// cover -- settles the recorded calls operator by operator first, so results are never skipped; the only
+// observable difference is that after a fused row the intermediate activation tensors (emb_acv, residuals, ...)
+// keep their previous contents.  GTEN_HIP_FAST_DECODE=0 switches the recording off.
+//
 // Timer semantics: kernel launches are asynchronous, so by default exec_time
 // accumulates host launch time only.  Set GTEN_HIP_SYNC_TIMERS=1 to make every
 // Timer wait for the GPU before it stops (debug / print_perf use).
@@ -18,7 +30,11 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <iostream>
+#include <map>
+#include <vector>
 
 #include "ops.h"
 #include "tensor.h"
@@ -54,6 +70,63 @@ private:
     bool stopped_ = false;
 };
 
+class Embedding;
+class RMSNorm;
+class AttentionBlock;
+class EmbeddingLinear;
+
+namespace detail {
+
+// The recorded single-row forward (see the header comment).  `tail` is the storage the next module of the chain
+// must be handed; `replay` re-runs what has been recorded through the operators.
+struct PendingRow {
+    bool active = false;
+    Embedding* emb = nullptr;
+    std::vector<AttentionBlock*> blocks;
+    RMSNorm* norm = nullptr;
+    int n = 0;                               // rows in the context; the new row is n - 1
+    int32_t token = 0;                       // id of the new row
+    const void* tail = nullptr;
+    std::vector<std::function<void()>> replay;
+};
+
+inline PendingRow& pending_row()
+{
+    static PendingRow p;
+    return p;
+}
+
+inline bool& fused_rows_enabled()
+{
+    static bool on = [] { const char* e = std::getenv("GTEN_HIP_FAST_DECODE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// materialise the recorded calls operator by operator (hook of tensor.h's settle_pending)
+inline void settle_row()
+{
+    PendingRow& p = pending_row();
+    g_pending_settle = nullptr;
+    if (!p.active) return;
+    p.active = false;
+    std::vector<std::function<void()>> todo;
+    todo.swap(p.replay);
+    p.blocks.clear();
+    p.norm = nullptr;
+    for (auto& f : todo) f();
+}
+
+inline void record(PendingRow& p, const void* new_tail, std::function<void()> replay)
+{
+    p.tail = new_tail;
+    p.replay.push_back(std::move(replay));
+}
+
+inline bool run_fused_row(PendingRow& p, EmbeddingLinear* head);     // defined below the module classes
+inline void forget_decoder(const EmbeddingLinear* head);
+
+} // namespace detail
+
 /// Embedding table lookup, tokens (n_ctx,) -> (n_ctx, d_embed).  gten/modules.cpp:11-26
 class Embedding {
 public:
@@ -63,6 +136,35 @@ public:
     {
     }
     Tensor forward(const Tensor& tokens, const int start_pos = 0)
+    {
+        detail::settle_pending();
+        const int n = tokens.numel();
+        if (detail::fused_rows_enabled() && n - start_pos == 1 && tokens.is_host_external() && tokens.dtype() == kInt32) {
+            // one new row: start recording (header comment).  The id is copied now; the caller's buffer is not
+            // needed again.
+            detail::PendingRow& p = detail::pending_row();
+            p.emb = this;
+            p.n = n;
+            p.token = static_cast<const int32_t*>(tokens.host_external_ptr())[n - 1];
+            p.blocks.clear();
+            p.norm = nullptr;
+            p.replay.clear();
+            emb_acv.resize({n, weight.dimsize(1)});
+            const int32_t id = p.token;
+            detail::record(p, emb_acv.storage_id(), [this, n, id, start_pos] {
+                std::vector<int32_t> ids((size_t)n, 0);
+                ids[(size_t)n - 1] = id;                       // ops::token_embed reads rows [start_pos, n) only
+                forward_now(Tensor(ids.data(), {n}, kInt32), start_pos);
+            });
+            p.active = true;
+            detail::g_pending_settle = &detail::settle_row;
+            return emb_acv;
+        }
+        return forward_now(tokens, start_pos);
+    }
+
+private:
+    Tensor forward_now(const Tensor& tokens, const int start_pos)
     {
         Timer timer{&exec_time};
         emb_acv.resize({tokens.numel(), weight.dimsize(1)});
@@ -84,6 +186,21 @@ public:
     {
     }
     Tensor forward(const Tensor& inp, const int start_pos = 0)
+    {
+        detail::PendingRow& p = detail::pending_row();
+        if (p.active && !p.norm && !p.blocks.empty() && inp.storage_id() == p.tail && inp.dimsize(0) == p.n && start_pos == p.n - 1) {
+            p.norm = this;                                     // the final norm of the recorded row
+            acv.resize({inp.dimsize(0), inp.dimsize(1)});
+            Tensor in = inp;
+            detail::record(p, acv.storage_id(), [this, in, start_pos] { forward_now(in, start_pos); });
+            return acv;
+        }
+        detail::settle_pending();
+        return forward_now(inp, start_pos);
+    }
+
+private:
+    Tensor forward_now(const Tensor& inp, const int start_pos)
     {
         Timer timer{&exec_time};
         acv.resize({inp.dimsize(0), inp.dimsize(1)});
@@ -131,6 +248,8 @@ public:
         return acv;
     }
 
+    int max_ctx() const { return max_ctx_; }
+
 public:
     Tensor weight;
     Tensor acv;
@@ -149,8 +268,18 @@ public:
         : weight{Tensor({n_vocab, n_embd}, dtype.wdtype)}, acv{Tensor({n_vocab}, kFloat32)}
     {
     }
+    EmbeddingLinear(const EmbeddingLinear&) = default;
+    EmbeddingLinear& operator=(const EmbeddingLinear&) = default;
+    ~EmbeddingLinear() { detail::forget_decoder(this); }
+
     Tensor forward(const Tensor& inp)
     {
+        detail::PendingRow& p = detail::pending_row();
+        if (p.active && p.norm && inp.storage_id() == p.tail && inp.dimsize(0) == p.n) {
+            Timer timer{&exec_time};
+            if (detail::run_fused_row(p, this)) return acv;    // the whole row as one decoder step
+        }
+        detail::settle_pending();
         Timer timer{&exec_time};
         ops::matmul_2d(inp, weight, acv, inp.dimsize(0) - 1);
         return acv;
@@ -278,6 +407,9 @@ public:
     RotaryEmbedding k_rope;
     int64_t exec_time_attn{0};
 
+    int n_heads() const { return n_heads_; }
+    int max_ctx() const { return max_ctx_; }
+
 private:
     int32_t n_heads_;
     int max_ctx_;
@@ -322,6 +454,21 @@ public:
 
     Tensor forward(Tensor& inp, const int start_pos)
     {
+        detail::PendingRow& p = detail::pending_row();
+        if (p.active && !p.norm && inp.storage_id() == p.tail && inp.dimsize(0) == p.n && start_pos == p.n - 1) {
+            p.blocks.push_back(this);                          // next block of the recorded row
+            attn_res.acv.resize({inp.dimsize(0), inp.dimsize(1)});
+            Tensor in = inp;
+            detail::record(p, attn_res.acv.storage_id(), [this, in, start_pos]() mutable { forward_now(in, start_pos); });
+            return attn_res.acv;
+        }
+        detail::settle_pending();
+        return forward_now(inp, start_pos);
+    }
+
+private:
+    Tensor forward_now(Tensor& inp, const int start_pos)
+    {
         Tensor h = inp_res.forward(inp, attn.forward(attn_norm.forward(inp, start_pos), start_pos), start_pos);
         return attn_res.forward(h, ffn_forward(ffn_norm.forward(h, start_pos), start_pos), start_pos);
     }
@@ -338,5 +485,123 @@ public:
     Multiply ffn_mul;
     SiLU ffn_silu;
 };
+
+namespace detail {
+
+// One fused decoder per lm_head module, valid for exactly the device tensors it was built on.
+struct RowDecoder {
+    gten_hip_decoder* dec = nullptr;
+    gten_hip_decoder_desc desc{};
+    std::vector<gten_hip_layer_ptrs> layers;
+    bool unsupported = false;                // the decoder refused this configuration: keep to the operators
+};
+
+inline std::map<const EmbeddingLinear*, RowDecoder>& row_decoders()
+{
+    static auto* m = new std::map<const EmbeddingLinear*, RowDecoder>();     // never destroyed: outlives the HIP runtime's users
+    return *m;
+}
+
+inline void forget_decoder(const EmbeddingLinear* head)
+{
+    auto& m = row_decoders();
+    auto it = m.find(head);
+    if (it == m.end()) return;
+    if (it->second.dec) gten_hip_decoder_destroy(it->second.dec);
+    m.erase(it);
+}
+
+// Every device pointer the decoder works on, from the recorded modules (what TinyLlama::describe collects in
+// host/tinyllama_model.h).  Returns false when the chain is not a model the decoder computes.
+inline bool describe_row(const PendingRow& p, EmbeddingLinear* head, gten_hip_decoder_desc* d, std::vector<gten_hip_layer_ptrs>* L)
+{
+    const Tensor& ew = p.emb->weight;
+    AttentionBlock& b0 = *p.blocks[0];
+    if (!ew.is_2d() || !head->weight.is_2d()) return false;
+    const int E = ew.dimsize(1), V = ew.dimsize(0);
+    const int H = b0.attn.n_heads(), max_ctx = b0.attn.max_ctx();
+    if (H <= 0 || E % H != 0) return false;
+    const int dh = E / H;
+    const Dtype wdt = b0.attn.query.weight.dtype(), adt = b0.attn.key.acv.dtype();
+    *d = gten_hip_decoder_desc{};
+    d->n_vocab = V; d->max_ctx = max_ctx; d->n_embd = E; d->n_ffn = b0.ffn_gate_proj.weight.dimsize(0);
+    d->n_layers = (int)p.blocks.size(); d->n_heads = H; d->n_kv_heads = b0.attn.key.weight.dimsize(0) / dh;
+    d->wdtype = dtype_code(wdt); d->adtype = dtype_code(adt);
+    if (ew.dtype() != wdt || head->weight.dtype() != wdt || head->weight.dimsize(0) != V || head->weight.dimsize(1) != E) return false;
+    if (p.emb->emb_acv.dtype() != adt || p.norm->acv.dtype() != adt || p.norm->weight.numel() != E) return false;
+    if (head->acv.dtype() != kFloat32 || head->acv.numel() != V) return false;
+    for (AttentionBlock* b : p.blocks) {
+        const bool same = b->attn.n_heads() == H && b->attn.max_ctx() == max_ctx && b->attn.query.weight.dtype() == wdt &&
+                          b->attn.key.acv.dtype() == adt && b->attn.query.weight.shape_eq({E, E}) &&
+                          b->attn.key.weight.shape_eq({d->n_kv_heads * dh, E}) && b->attn.value.weight.shape_eq({d->n_kv_heads * dh, E}) &&
+                          b->attn.qkv_proj.weight.shape_eq({E, E}) && b->ffn_gate_proj.weight.shape_eq({d->n_ffn, E}) &&
+                          b->ffn_up_proj.weight.shape_eq({d->n_ffn, E}) && b->ffn_down_proj.weight.shape_eq({E, d->n_ffn}) &&
+                          b->attn.key.max_ctx() == max_ctx && b->attn.value.max_ctx() == max_ctx;
+        if (!same) return false;
+    }
+    d->embed = ew.device_weight();
+    d->final_norm = p.norm->weight.device_weight();
+    d->lm_head = head->weight.device_weight();
+    d->logits = static_cast<float*>(head->acv.device_ptr_mut());
+    L->assign(p.blocks.size(), gten_hip_layer_ptrs{});
+    for (size_t i = 0; i < p.blocks.size(); i++) {
+        AttentionBlock& b = *p.blocks[i];
+        gten_hip_layer_ptrs& l = (*L)[i];
+        l.wq = b.attn.query.weight.device_weight();
+        l.wk = b.attn.key.weight.device_weight();
+        l.wv = b.attn.value.weight.device_weight();
+        l.wo = b.attn.qkv_proj.weight.device_weight();
+        l.wgate = b.ffn_gate_proj.weight.device_weight();
+        l.wup = b.ffn_up_proj.weight.device_weight();
+        l.wdown = b.ffn_down_proj.weight.device_weight();
+        l.attn_norm = b.attn_norm.weight.device_weight();
+        l.ffn_norm = b.ffn_norm.weight.device_weight();
+        l.kcache = b.attn.key.acv.device_ptr_mut();          // the K/V caches ARE these activation tensors; the step
+        l.vcache = b.attn.value.acv.device_ptr_mut();        // writes row n-1 (marks the device copy as the newer one)
+    }
+    return true;
+}
+
+// The recorded row is complete (embedding, blocks, final norm, and now lm_head): run it as one decoder step.
+// Returns false -- with the recorded calls settled through the operators -- when the decoder does not cover it.
+inline bool run_fused_row(PendingRow& p, EmbeddingLinear* head)
+{
+    // from here on device pointers are fetched for the decoder itself: nothing is pending any more
+    g_pending_settle = nullptr;
+    p.active = false;
+    std::vector<std::function<void()>> recorded;
+    recorded.swap(p.replay);
+    auto give_up = [&] {
+        for (auto& f : recorded) f();
+        p.blocks.clear();
+        p.norm = nullptr;
+        return false;
+    };
+    RowDecoder& rd = row_decoders()[head];
+    if (rd.unsupported) return give_up();
+    gten_hip_decoder_desc d;
+    std::vector<gten_hip_layer_ptrs> L;
+    if (!describe_row(p, head, &d, &L)) return give_up();
+    const bool same = rd.dec && std::memcmp(&d, &rd.desc, sizeof(d)) == 0 && L.size() == rd.layers.size() &&
+                      std::memcmp(L.data(), rd.layers.data(), L.size() * sizeof(gten_hip_layer_ptrs)) == 0;
+    if (!same) {
+        if (rd.dec) gten_hip_decoder_destroy(rd.dec);
+        rd.dec = nullptr;
+        if (gten_hip_decoder_create(&d, L.data(), &rd.dec) != 0) {     // e.g. a head width the fused kernels do not have
+            rd.dec = nullptr;
+            rd.unsupported = true;
+            return give_up();
+        }
+        rd.desc = d;
+        rd.layers = L;
+    }
+    GTEN_HIP_OK(gten_hip_decoder_set_tokens(rd.dec, &p.token, p.n - 1, 1));
+    GTEN_HIP_OK(gten_hip_decoder_step(rd.dec, p.n, /*use_graph=*/1));
+    p.blocks.clear();
+    p.norm = nullptr;
+    return true;
+}
+
+} // namespace detail
 
 } // namespace gten

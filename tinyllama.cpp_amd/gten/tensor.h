@@ -53,6 +53,16 @@ inline void ensure_runtime()
     ready = true;
 }
 
+// Deferred work (gten/modules.h: a single-row forward is recorded module by module and runs as ONE fused
+// decoder step when lm_head is reached).  Anything that looks at tensor bytes -- a host view, a device pointer
+// for another operator -- first lets the recorder materialise what it holds, operator by operator, so a caller
+// that stops half way or inspects an intermediate tensor sees exactly what the reference would have computed.
+inline void (*g_pending_settle)() = nullptr;
+inline void settle_pending()
+{
+    if (g_pending_settle) g_pending_settle();
+}
+
 struct Storage {
     void* dev = nullptr;          // HBM, owned
     uint8_t* host = nullptr;      // host mirror (owned) or caller memory (external)
@@ -86,6 +96,7 @@ struct Storage {
     }
     uint8_t* host_view(bool will_write)
     {
+        settle_pending();
         GTEN_ASSERTM(!packed, "host access to a weight that has already been repacked into HBM is not supported");
         need_host();
         if (dev_newer) {
@@ -97,6 +108,7 @@ struct Storage {
     }
     void* dev_view(bool will_write)
     {
+        settle_pending();
         need_dev();
         if (host_newer) {
             GTEN_HIP_OK(gten_hip_memcpy_h2d(dev, host, nbytes));
@@ -112,6 +124,7 @@ struct Storage {
     // packed planes in HBM, once; the host copy is dropped afterwards.
     void* dev_weight(int dtype_code_, int rows, int cols)
     {
+        settle_pending();
         if (packed) return dev;
         need_dev();
         GTEN_ASSERTM(host && host_newer, "weight tensor was never filled from the host");
@@ -199,6 +212,8 @@ public:
         return store_->dev_view(false);
     }
     bool is_host_external() const { return store_ && store_->external; }
+    // identity of the storage this handle aliases (shallow copies share it, gten/tensor.h:24-29)
+    const void* storage_id() const { return store_.get(); }
     const void* host_external_ptr() const { return store_->host; }
 
     Dtype dtype() const { return dtype_; }

@@ -67,6 +67,13 @@ public:
             (void)lm_head_.acv.device_ptr_mut();      // the step wrote the logits in HBM: host mirror is stale
             return lm_head_.acv;
         }
+        // operator by operator (this class drives its own decoder above; with the fast path switched off the
+        // modules must not record the row for theirs either -- gten/modules.h)
+        struct OpsOnly {
+            bool was = detail::fused_rows_enabled();
+            OpsOnly() { detail::fused_rows_enabled() = false; }
+            ~OpsOnly() { detail::fused_rows_enabled() = was; }
+        } ops_only;
         Tensor x = tok_emb_.forward(tokens, start_pos);
         for (auto& block : blocks_) x = block.forward(x, start_pos);
         x = norm_.forward(x, start_pos);
