@@ -149,18 +149,23 @@ def dropin_leg(host, cfg, args, toks):
         m = lib.tinyllama(N_CTX, wd, ad)
         m.load(path)
         new = G if fused_rows else min(G, 32)                 # the operator-by-operator loop is ~15x slower: a short sample
+        m.logits(toks[:P0], 0)                                 # warm-up: first-use allocations, weight repack
+        m.logits(toks[:P0 + 1], P0)                            # ... and the decoder / its graph
         t0 = time.perf_counter(); m.logits(toks[:P0], 0); t_pre = time.perf_counter() - t0
         t0 = time.perf_counter()
         ids = m.greedy(toks[:P0], P0 + new)
         dt = time.perf_counter() - t0
         res[name] = {"new_tokens": int(len(ids) - P0), "tok_s": round((len(ids) - P0) / max(dt - t_pre, 1e-9), 1),
-                     "ids_head": [int(x) for x in ids[P0:P0 + 8]]}
+                     "prefill_ms": round(t_pre * 1e3, 2), "wall_ms": round(dt * 1e3, 2), "ids_head": [int(x) for x in ids[P0:P0 + 8]]}
         m.close()
     lib.set_fused_rows(True)
+    a, b = res["fused_rows"]["ids_head"], res["operators"]["ids_head"]
     return {"prompt_tokens": P0, "tok_s": res["fused_rows"]["tok_s"], **res,
-            "same_ids": res["fused_rows"]["ids_head"] == res["operators"]["ids_head"],
+            "first_ids_agree": next((i for i in range(8) if a[i] != b[i]), 8),
             "note": "reference's unmodified TinyLlama::logits + host argmax per token on this repository's gten/ headers "
-                    "(libdropin.so); ids generated up to n = %d; tok/s = new ids / (wall - prompt processing)" % N_CTX}
+                    "(libdropin.so); ids generated up to n = %d; tok/s = new ids / (wall - prompt processing); first_ids_agree = how many of "
+                    "the first 8 greedy ids the fused rows and the operator-by-operator run share (at n ~ 1800 they differ by f32 "
+                    "summation order of the chunked softmax, so near-ties may flip; tests hold both to the reference band)" % N_CTX}
 
 
 def cpu_baseline(host, cfg, mode, seed, n_steps):

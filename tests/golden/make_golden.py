@@ -190,6 +190,63 @@ def add_long_probe(host, refs, out):
     out["long.q4.ns"] = np.array(ns, np.int32)
 
 
+def make_full_extra_golden(host, refs):
+    """full_extra_golden.npz (round 2): what full_model_golden.npz does not hold --
+      * PROMPT PROCESSING at full size: a 96-id prompt (>= 16 rows: the matrix-core W.x of gten_mfma.hip and the
+        tiled attention at 2048 / 5632 widths) and three teacher-forced decode steps after it, f16 / q8 / q4, the
+        reference's AVX build and (the yardstick: its own spread) its scalar build; max_ctx 256 >= 2 n (stride quirk);
+      * long-context probes for f16 and q8 like long.q4 (single-token steps from n = 1 to 2048, both builds)."""
+    probe_ids = np.concatenate([PROBE_IDS, np.arange(0, 32003, 32, dtype=np.int32)])
+    out = {"probe_ids": probe_ids, "seed": np.array([1234]), "token_seed": np.array([12345]), "prompt_seed": np.array([4242])}
+    P = 96
+    prompt = list(host.synthetic_tokens(P, seed=4242))
+    for name, wd, ad in MODES():
+        cfg = host.default_config(wd, ad)
+        path = f"/tmp/gten_golden_{name}.gten"
+        if not os.path.exists(path):
+            host.write_gten(cfg, 1234, path)
+        for kind in ("avx", "scalar"):
+            t0 = time.time()
+            m = refs[kind].tinyllama(256, wd, ad)
+            m.load(path)
+            toks = list(prompt)
+            forced = out.get(f"prefill.{name}.avx.tokens") if kind == "scalar" else None
+            tops, vals, stats, probes = [], [], [], []
+            for step in range(4):
+                lg = m.logits(toks, 0 if step == 0 else len(toks) - 1)
+                t, v, s, p = summarize(lg)
+                tops.append(t); vals.append(v); stats.append(s); probes.append(p)
+                toks.append(int(forced[len(toks)]) if forced is not None else int(t[0]))
+            m.close()
+            out[f"prefill.{name}.{kind}.tokens"] = np.array(toks, np.int32)
+            out[f"prefill.{name}.{kind}.top_ids"] = np.stack(tops)
+            out[f"prefill.{name}.{kind}.top_logits"] = np.stack(vals)
+            out[f"prefill.{name}.{kind}.stats"] = np.stack(stats)
+            out[f"prefill.{name}.{kind}.probes"] = np.stack(probes)
+            print(f"prefill {name}/{kind}: {time.time() - t0:.0f}s", flush=True)
+        np.savez_compressed(os.path.join(HERE, "full_extra_golden.npz"), **out)
+    toks = host.synthetic_tokens(2048, seed=12345)
+    ns = (257, 1024, 2047, 2048)
+    for name, wd, ad in MODES()[:2]:                # f16, q8 (q4: full_model_golden.npz long.q4)
+        for kind in ("avx", "scalar"):
+            m = refs[kind].tinyllama(2048, wd, ad)
+            m.load(f"/tmp/gten_golden_{name}.gten")
+            t0 = time.time()
+            for n in range(1, 2049):
+                lg = m.logits(toks[:n], n - 1)
+                if n in ns:
+                    t, v, s, p = summarize(lg)
+                    suffix = "" if kind == "avx" else ".scalar"
+                    out[f"long.{name}.n{n}.top_ids{suffix}"] = t; out[f"long.{name}.n{n}.top_logits{suffix}"] = v
+                    out[f"long.{name}.n{n}.stats{suffix}"] = s; out[f"long.{name}.n{n}.probes{suffix}"] = p
+                if n % 256 == 0:
+                    print(f"  long probe {name}/{kind} n={n} {time.time() - t0:.0f}s", flush=True)
+            m.close()
+        out[f"long.{name}.ns"] = np.array(ns, np.int32)
+        np.savez_compressed(os.path.join(HERE, "full_extra_golden.npz"), **out)
+    print("full_extra_golden.npz")
+
+
 def make_full_model_golden(pkg, host, refs, skip_long):
     probe_ids = np.concatenate([PROBE_IDS, np.arange(0, 32003, 32, dtype=np.int32)])
     out = {"probe_ids": probe_ids, "seed": np.array([1234]), "token_seed": np.array([12345])}
@@ -236,6 +293,7 @@ def main():
     ap.add_argument("--skip-long", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-long", action="store_true", help="re-run just the long-context probe into the existing fixture")
+    ap.add_argument("--only-extra", action="store_true", help="just full_extra_golden.npz (full-size prompt processing; f16 / q8 long-context probes)")
     args = ap.parse_args()
     assert os.path.isdir(REFERENCE), "run this in the build container (needs /root/reference)"
     orc.build(ref=True)
@@ -244,6 +302,9 @@ def main():
     pkg = load_package()
     pkg.build.build_all()
     host = pkg.load_host()
+    if args.only_extra:
+        make_full_extra_golden(host, refs)
+        return
     if args.only_long:
         path = os.path.join(HERE, "full_model_golden.npz")
         out = dict(np.load(path))

@@ -146,27 +146,47 @@ def test_decode_at_the_last_position(hip, oracle):
 
 
 @pytest.mark.parametrize("name,wd,ad", MODES())
-def test_one_launch_attention_is_bit_identical(hip, oracle, name, wd, ad, monkeypatch):
-    """GTEN_HIP_ATTN_ONE_LAUNCH=1 (scores, softmax statistics exchanged inside the launch, p.V): the same
-    bytes as the default two launches across a chunk boundary -- every argmax and the last logits row"""
-    import os
+def test_one_pass_attention_against_the_two_launch_form(hip, oracle, name, wd, ad, monkeypatch):
+    """default: scores, chunk-local softmax and p.V in ONE launch per block (k_dec_attn_one64), the chunks joined with
+    their weights in the o projection's prologue.  GTEN_HIP_ATTN_TWO_PASS=1: two launches, probabilities rounded
+    against the statistics of the whole row (the reference's rounding point, gten/ops.h:972-997).  While the context
+    fits one chunk (n <= 256) both are the same bytes; beyond, the logits stay inside the model band (a probability
+    block is rounded against its chunk's scale: fp16 rounding of the block delta) and BOTH sit inside the band
+    around the oracle."""
     pkg = load_package()
     host = pkg.load_host()
     ocfg = tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2)
     cfg = host_cfg(ocfg)
     N = 300
     toks = host.synthetic_tokens(N, seed=11, n_vocab=cfg.n_vocab)
+    weights = [host.synth_weight(cfg, 77, i) for i in range(len(cfg.weight_shapes()))]
+    watch = (1, 2, 100, 255, 256, 257, 290, N)
     outs = []
-    for one in ("0", "1"):
-        monkeypatch.setenv("GTEN_HIP_ATTN_ONE_LAUNCH", one)
+    for two in ("0", "1"):
+        monkeypatch.setenv("GTEN_HIP_ATTN_TWO_PASS", two)
         gm = host.model(cfg)
-        for i in range(gm.n_weights()):
-            gm.set_weight(i, host.synth_weight(cfg, 77, i))
+        for i, w in enumerate(weights):
+            gm.set_weight(i, w)
         gm.decode_begin(toks)                       # the decoder (and its launch choice) is made here
+        got = {}
         for n in range(1, N + 1):
             gm.decode_step(n, n % 2 == 0)           # alternate graph replay and eager launches
-        res = [gm.decode_result(n) for n in range(1, N + 1)]
-        outs.append((res, gm.logits(toks[:N], N - 1).copy()))
+            if n in watch:
+                got[n] = (gm.decode_result(n), gm.logits(toks[:n], n - 1).copy())
+        outs.append(got)
         gm.close()
-    assert outs[0][0] == outs[1][0]
-    assert np.array_equal(outs[0][1], outs[1][1])
+    om = oracle.model(ocfg)
+    for i, w in enumerate(weights):
+        om.set_weight(i, w)
+    for n in range(1, N + 1):
+        want = om.logits(toks[:n], n - 1)
+        if n not in watch:
+            continue
+        (ida, la), (idb, lb) = outs[0][n], outs[1][n]
+        if n <= 256:
+            assert ida == idb and np.array_equal(la, lb), (name, n)
+        else:
+            check_logits(name, la, lb, float(lb.std()))
+        check_logits(name, la, want, float(want.std()))
+        check_logits(name, lb, want, float(want.std()))
+    om.close()

@@ -190,6 +190,7 @@ def test_grouped_attention_is_bit_identical_to_per_head_kernels(hip, monkeypatch
     streams = [host.synthetic_tokens(N, seed=40 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
     runs = []
     monkeypatch.setenv("GTEN_HIP_ATTN_EXACT", "1")     # 16 sequences and up fuse the p.V multiply-add by default
+    monkeypatch.setenv("GTEN_HIP_ATTN_TWO_PASS", "1")  # the per-head kernels in their two-launch form (row-global statistics, as the grouped pair)
     for per_head in ("1", "0"):
         monkeypatch.setenv("GTEN_HIP_ATTN_PER_HEAD", per_head)
         batch = host.batch(cfg, n_seq)

@@ -34,7 +34,8 @@ extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
 
 #define DEC_CHUNK 256            // attention positions per workgroup
 #define DEC_ATT_MAXCH 8          // chunk partials / statistics a consumer requests up front (2048 positions)
-#define GEMVM_F16_LDS_LIMIT 61440  // multi-sequence f16 inputs are staged in LDS up to this many bytes (stays under the 64 KiB default)
+#define GEMVM_F16_LDS_LIMIT 65536  // multi-sequence f16 inputs are staged in LDS up to this many bytes (8 sequences x 2048 x f32; the launchers raise
+                                   // the kernel's dynamic LDS limit past the 64 KiB default where needed)
 
 // launches of a decode step can be restricted to one kernel family (gten_hip_decoder_time_family)
 static int g_only_family = -1;
@@ -74,7 +75,9 @@ __device__ __forceinline__ ActStage carve_stage(int d)
 }
 static size_t stage_bytes(int d) { return 64 + (size_t)d * 4 + (size_t)(d >> 5) * 40; }
 
-enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_ACTQ8 = 4 };
+enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_ATTW = 3, PRO_ACTQ8 = 4 };
+// PRO_ATT: the chunk partials of the two-pass attention are final, the prologue adds them; PRO_ATTW: the one-pass
+// attention (k_dec_attn_one64) left chunk-local partials and statistics, the prologue joins them with their weights
 enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2, EPI_STAGE_FRAG = 3 };
 
 // ------------------------------------------------------------ W.x kernels
@@ -115,7 +118,8 @@ struct Gemv8Args {
     const float* res_a; const float* res_raw;                   // PRO_RESID (f32 rows)
     float* x_out;                                               // PRO_EMBED/PRO_RESID: new residual row, f32
     const uint16_t* norm_w;
-    const float* att_part; int d_head, n_chunks;                // PRO_ATT (d_head a power of two)
+    const float* att_part; int d_head, n_chunks;                // PRO_ATT / PRO_ATTW (d_head a power of two)
+    const float* att_stats; int stats_stride;                   // PRO_ATTW: [n_heads][n_chunks] (max, sum) of k_dec_attn_one64
     int d_head_shift;
     float* best_val; int* best_idx;                             // lm_head: per-wave running argmax (may be null)
     // EPI_SILUMUL writes / PRO_ACTQ8 reads the staged FFN activation in HBM (ActQ8 layout)
@@ -129,8 +133,6 @@ struct Gemv8Args {
     int best_stride;              // best_val / best_idx
     // k_dec_gemvm + EPI_SILUMUL: where the FFN activation is staged (its INPUT stage is act_*)
     int8_t* out_q; float* out_d; int* out_sum; float* out_f;
-    // the qkv launch clears the attention arrival counters of the launch that follows it
-    unsigned* zero_words; int zero_count;
     int frag_rt;                  // EPI_STAGE_FRAG: row tiles (of 16 sequences) of the fragment-major staging (k_dec_mmv)
     // PRO_EMBED (the step's first launch) copies the RoPE rotation of the current position where the score
     // kernels find it without knowing the position: rope_now[seq][rope_half]
@@ -284,9 +286,9 @@ __device__ __forceinline__ float act_round32(float v, bool f16)
 // as seven leading 64-bit scalars (GemvHot), ahead of the full struct; what a prologue kind does not need carries
 // its small integers instead.
 struct GemvHot {
-    const void* p0;               // PRO_RESID res_raw | PRO_EMBED table | PRO_ATT att_part | PRO_ACTQ8 act_q (f16: act_f)
+    const void* p0;               // PRO_RESID res_raw | PRO_EMBED table | PRO_ATT(W) att_part | PRO_ACTQ8 act_q (f16: act_f)
     const void* p1;               // PRO_RESID res_a   | PRO_EMBED tokens | PRO_ATT {d_head_shift, n_chunks} | PRO_ACTQ8 act_d
-    const void* p2;               // PRO_RESID / PRO_EMBED norm_w | PRO_ACTQ8 act_sum
+    const void* p2;               // PRO_RESID / PRO_EMBED norm_w | PRO_ACTQ8 act_sum | PRO_ATTW att_stats
     const uint8_t* qs0; const uint16_t* ds0;
     int d_in, rows0;
     const DecStep* step;
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     const float* res_a = (const float*)hot.p1 + (size_t)seq * d;
     float* x_out = a.x_out ? a.x_out + (size_t)seq * d : nullptr;
     const int32_t* tokens = (const int32_t*)hot.p1 + (size_t)seq * a.tok_stride;        // PRO_EMBED only
-    const float* att_part = (const float*)hot.p0 + (size_t)seq * a.part_stride;      // PRO_ATT only
+    constexpr bool ATT = (PRO == PRO_ATT || PRO == PRO_ATTW);
+    const float* att_part = (const float*)hot.p0 + (size_t)seq * a.part_stride;      // PRO_ATT / PRO_ATTW only
+    const float* att_stats = (const float*)hot.p2 + (size_t)seq * a.stats_stride;   // PRO_ATTW only
     const uint16_t* norm_w = (const uint16_t*)hot.p2;
     const int att_shift = (int)((uintptr_t)hot.p1 & 0xff), att_chunks = (int)(((uintptr_t)hot.p1 >> 8) & 0xffff), att_dh = 1 << att_shift;
     if (STG) {
@@ -371,8 +375,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     }
     // PRO_ATT: all chunk partials of this thread's elements, requested at once (chunks past the context hold
     // stale but readable data and are dropped by a select below; decoder_create: n_chunks <= DEC_ATT_MAXCH)
-    float apart[PRO == PRO_ATT ? DEC_ATT_MAXCH : 1][EPT];
-    if (PRO == PRO_ATT) {
+    float apart[ATT ? DEC_ATT_MAXCH : 1][EPT];
+    float2 cst[PRO == PRO_ATTW ? DEC_ATT_MAXCH : 1];             // PRO_ATTW: (max, sum) of this thread's head, every chunk
+    if (PRO == PRO_ATTW) {
+        const unsigned h = (unsigned)sbase >> att_shift;
+#pragma unroll
+        for (int j = 0; j < DEC_ATT_MAXCH; j++) cst[j] = ((const float2*)att_stats)[h * (unsigned)att_chunks + (unsigned)min(j, att_chunks - 1)];
+    }
+    if (ATT) {
         // (32-bit index arithmetic, the head width as a shift: one integer multiply ahead of the eight requests, not seventeen)
         const unsigned h = (unsigned)sbase >> att_shift, e = (unsigned)sbase & (unsigned)(att_dh - 1);
         const unsigned row0 = h * (unsigned)att_chunks;
@@ -454,7 +464,6 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
         }
     }
     __builtin_amdgcn_sched_barrier(0);            // keep every request above ahead of the prologue's arithmetic
-    if (a.zero_words && blockIdx.x == 0 && (int)threadIdx.x < a.zero_count) a.zero_words[threadIdx.x] = 0u;
 
     // ---- 3. prologue: the element-wise chain of the reference, on chip
     //         (PRO_ACTQ8: nothing to do, the input was staged in HBM by the producer's epilogue)
@@ -484,6 +493,27 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
 #pragma unroll
             for (int i = 0; i < EPT; i++) v[i] = pin1[i] + v[i];
             act_roundN<WT, EPT>(v);                       // Residual output written in the activation dtype
+        } else if (PRO == PRO_ATTW) {                     // chunk-local partials joined with their softmax weights
+            const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
+            float M = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < DEC_ATT_MAXCH; j++) M = fmaxf(M, (j < nch) ? cst[j].x : -INFINITY);
+            float w[DEC_ATT_MAXCH], L = 0.f;
+#pragma unroll
+            for (int j = 0; j < DEC_ATT_MAXCH; j++) {
+                // (hardware exponential: exp(0) = 1 exactly, so a single chunk keeps weight 1; stale chunks are dropped)
+                w[j] = (j < nch) ? cst[j].y * __expf(cst[j].x - M) : 0.f;
+                L += w[j];
+            }
+            const float rL = recip_rn(L);
+#pragma unroll
+            for (int j = 0; j < DEC_ATT_MAXCH; j++) w[j] = (nch == 1) ? 1.0f : w[j] * rL;
+#pragma unroll
+            for (int i = 0; i < EPT; i++) v[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < DEC_ATT_MAXCH; j++)
+#pragma unroll
+                for (int i = 0; i < EPT; i++) v[i] += (j < nch) ? w[j] * apart[j][i] : 0.f;
         } else {                                          // PRO_ATT: sum of the per-chunk partials, fixed order
             const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
 #pragma unroll
@@ -650,8 +680,12 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
     const int total = rows0 + rows1 + rows2;
     const int r0 = (EPI == EPI_SILUMUL) ? (wid >> 2) * rows0 + blockIdx.x * 32 + (wid & 3) * R
                                         : (blockIdx.x * NW + wid) * R;
-    uint4 wq[R][NCH], wq1[R][NCH];
-    uint16_t wd[R][NCH];
+    // f16 weights with 8 rows per wave (gate|up) would hold 8 x 4 x 16 bytes of weights beside R x S accumulators: beyond
+    // the register file (round 1: 270 scratch accesses at 8 sequences).  Those launches take their rows in two batches
+    // of 4 -- the second batch is requested once the first has been consumed.
+    constexpr int RB = (F16W && R == 8) ? (S >= 8 ? 2 : 4) : R;
+    uint4 wq[RB][NCH], wq1[RB][NCH];
+    uint16_t wd[RB][NCH];
     // (one matrix per wave: the row counts of concatenated matrices are multiples of R -- see k_dec_gemv8)
     int lr0 = r0, rows_m = rows0;
     const uint8_t* qbase = qs0;
@@ -660,34 +694,38 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
         lr0 -= rows0; qbase = a.qs[1]; dbase = a.ds[1]; rows_m = rows1;
         if (lr0 >= rows1 && rows2 > 0) { lr0 -= rows1; qbase = a.qs[2]; dbase = a.ds[2]; rows_m = rows2; }
     }
+    auto request_rows = [&](int jb) {
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-        const int lr = min(lr0 + j, rows_m - 1);
-        const uint16_t* drow = dbase + (size_t)lr * nb;
+        for (int j = 0; j < RB; j++) {
+            const int lr = min(lr0 + jb + j, rows_m - 1);
+            const uint16_t* drow = dbase + (size_t)lr * nb;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int b = (c * 64 + lane < nb) ? c * 64 + lane : 0;
-            if (F16W) {
-                const int e = (c * 512 + lane * 8 < d) ? c * 512 + lane * 8 : 0;
-                wq[j][c] = *(const uint4*)((const uint16_t*)qbase + (size_t)lr * d + e);
-                wq1[j][c] = make_uint4(0, 0, 0, 0);
-                wd[j][c] = 0;
-                continue;
+            for (int c = 0; c < NCH; c++) {
+                const int b = (c * 64 + lane < nb) ? c * 64 + lane : 0;
+                if (F16W) {
+                    const int e = (c * 512 + lane * 8 < d) ? c * 512 + lane * 8 : 0;
+                    wq[j][c] = *(const uint4*)((const uint16_t*)qbase + (size_t)lr * d + e);
+                    wq1[j][c] = make_uint4(0, 0, 0, 0);
+                    wd[j][c] = 0;
+                    continue;
+                }
+                if (WT == GTEN_Q4) {
+                    wq[j][c] = ((const uint4*)(qbase + (size_t)lr * nb * 16))[b];
+                } else {
+                    const uint4* q0 = (const uint4*)(qbase + (size_t)lr * nb * 32);
+                    wq[j][c] = q0[b];
+                    wq1[j][c] = q0[nb + b];
+                }
+                wd[j][c] = drow[b];
             }
-            if (WT == GTEN_Q4) {
-                wq[j][c] = ((const uint4*)(qbase + (size_t)lr * nb * 16))[b];
-            } else {
-                const uint4* q0 = (const uint4*)(qbase + (size_t)lr * nb * 32);
-                wq[j][c] = q0[b];
-                wq1[j][c] = q0[nb + b];
-            }
-            wd[j][c] = drow[b];
         }
-    }
+    };
+    request_rows(0);
 
     // ---- the S staged input vectors: HBM -> LDS once per workgroup (every wave needs all of them)
     //      layout: [S][d] quants | [S][nb] deltas | [S][nb] sums   (f16: [S][d] f32 values)
-    const bool lds_f = F16W && ((size_t)S * d * 4 <= GEMVM_F16_LDS_LIMIT);
+    // (decided at compile time from the row capacity NCH x 512 >= d, so that the reads below are LDS or global reads, not FLAT)
+    constexpr bool lds_f = F16W && ((size_t)S * NCH * 512 * 4 <= GEMVM_F16_LDS_LIMIT);
     int8_t* lq = (int8_t*)(g_smem + (EPI == EPI_SILUMUL ? (size_t)S * 64 * 4 : 0));
     float* ld_ = (float*)(lq + (size_t)S * d);
     int* lsum = (int*)(ld_ + (size_t)S * nb);
@@ -701,14 +739,20 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
         for (int i = threadIdx.x; i < S * nb; i += NT) { ld_[i] = act_d[i]; lsum[i] = act_sum[i]; }
     }
     __syncthreads();
-    const float* fsrc = lds_f ? lf : act_f;
 
-    float acc[R][S];
+
+    float best[S];
+    int best_i[S];
 #pragma unroll
-    for (int j = 0; j < R; j++)
+    for (int q = 0; q < S; q++) { best[q] = -INFINITY; best_i[q] = 0x7fffffff; }
+#pragma unroll
+    for (int jb = 0; jb < R; jb += RB) {
+    if (jb > 0) request_rows(jb);
+    float acc[RB][S];                           // a batch's sums are reduced and stored before the next batch starts
+#pragma unroll
+    for (int j = 0; j < RB; j++)
 #pragma unroll
         for (int q = 0; q < S; q++) acc[j][q] = 0.f;
-
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         if (F16W) {
@@ -716,11 +760,12 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
             if (e < d) {
 #pragma unroll
                 for (int q = 0; q < S; q++) {
-                    const float* row = fsrc + (size_t)q * d + e;
-                    const float4 a0 = *(const float4*)row, a1 = *(const float4*)(row + 4);
+                    float4 a0, a1;
+                    if constexpr (lds_f) { const float* row = lf + (size_t)q * d + e; a0 = *(const float4*)row; a1 = *(const float4*)(row + 4); }
+                    else { const float* row = act_f + (size_t)q * d + e; a0 = *(const float4*)row; a1 = *(const float4*)(row + 4); }
                     const float fa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                    for (int j = 0; j < R; j++) {
+                    for (int j = 0; j < RB; j++) {
                         const unsigned u[4] = {wq[j][c].x, wq[j][c].y, wq[j][c].z, wq[j][c].w};
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
@@ -728,6 +773,9 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
                             acc[j][q] += h2f((uint16_t)(u[i] >> 16)) * fa[2 * i + 1];
                         }
                     }
+                    // (many sequences: keep hipcc from hoisting every sequence's LDS reads ahead of the arithmetic --
+                    // 256 live values at 8 sequences, i.e. spills)
+                    if (S >= 8) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             continue;
@@ -749,7 +797,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
             asum[q] = in ? lsum[q * nb + bs] : 0;
         }
 #pragma unroll
-        for (int j = 0; j < R; j++) {
+        for (int j = 0; j < RB; j++) {
             const float dw = h2f(wd[j][c]);
             if (WT == GTEN_Q4) {
                 const Q4Unpacked u = q4_unpack(wq[j][c]);
@@ -761,16 +809,12 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
             }
         }
     }
-
-    float best[S];
-    int best_i[S];
 #pragma unroll
-    for (int q = 0; q < S; q++) { best[q] = -INFINITY; best_i[q] = 0x7fffffff; }
-#pragma unroll
-    for (int j = 0; j < R; j++) {
+    for (int jj = 0; jj < RB; jj++) {
+        const int j = jb + jj;
 #pragma unroll
         for (int q = 0; q < S; q++) {
-            const float v = wave_sum(acc[j][q]);
+            const float v = wave_sum(acc[jj][q]);
             if (EPI == EPI_SILUMUL) {
                 if (lane == 0) res[q * 64 + (wid >> 2) * 32 + (wid & 3) * R + j] = v;
             } else {
@@ -778,6 +822,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemvm(const unsigned long long h0, c
                 if (a.best_val && r0 + j < total && v > best[q]) { best[q] = v; best_i[q] = r0 + j; }
             }
         }
+    }
     }
     if (EPI == EPI_RAW && a.best_val && lane == 0) {
 #pragma unroll
@@ -884,7 +929,11 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
     //         activations, and this wave's first chunk of activation fragments
     const int ppr = rowl >> 4;                                // pieces per feature row of the slice (<= 32 * NPF)
     const int sr = threadIdx.x >> 5, c0 = threadIdx.x & 31;
-    uint4 wp[FT][NPF];
+    uint4 wp[FT][NPF];                                        // (every slot defined: a conditionally written array is left in scratch memory by hipcc)
+#pragma unroll
+    for (int f = 0; f < FT; f++)
+#pragma unroll
+        for (int k = 0; k < NPF; k++) wp[f][k] = make_uint4(0, 0, 0, 0);
     unsigned dwv[FT][3];                                      // nb / 2 <= 88 dwords per row
 #pragma unroll
     for (int f = 0; f < FT; f++) {
@@ -904,6 +953,8 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
     }
     const int ndp = nbs * SP / 4;                             // 16-byte pieces of the slice of the [nb][SP] delta table (same layout in LDS)
     uint4 dap[MMV_MAXD];
+#pragma unroll
+    for (int k = 0; k < MMV_MAXD; k++) dap[k] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < MMV_MAXD; k++)
         if (512 * k < ndp) dap[k] = ((const uint4*)(a_ad + (size_t)b_lo * SP))[min((int)threadIdx.x + 512 * k, ndp - 1)];
@@ -1656,34 +1707,41 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv64(const unsigned long long 
     }
 }
 
-// ---- both passes in ONE launch (single-sequence decode, d_head 64)
+// ---- both passes in ONE launch with CHUNK-LOCAL softmax statistics (d_head 64; single-sequence decode and the
+//      2 / 4-sequence GEMV path)
 //
-// The two passes above are separated only by the softmax statistics of the whole row: 2 floats per
-// chunk.  Here the <= 8 chunk workgroups of a head exchange them INSIDE the launch -- statistics
-// stored with agent-scope (sc1) stores, drained, then one agent-scope atomic add on the head's
-// arrival counter; lane 0 polls that counter, the workgroup barrier releases the other waves, and
-// the statistics are read back with agent-scope loads (MI355X guide, Guideline 16, counter form) --
-// so the scores never leave the registers and the V chunk is requested at kernel entry together with
-// the K rows.  MEASURED SLOWER than the two launches (12.7 us vs 11.3 us at n = 2048: store -> drain ->
-// atomic -> poll -> barrier -> reload is ~3 dependent L2 round trips, more than the 1.6 us launch boundary
-// it removes; tools/microbench_flag_chain.hip shows the same for whole GEMV chains), so it is opt-in
-// (GTEN_HIP_ATTN_ONE_LAUNCH=1) and kept as the parity-tested record of that experiment.
-// Residency: 32 heads x <= 8 chunks = <= 256 workgroups of 256 threads, a fraction of what the chip
-// holds at once, and the previous launch has drained; every spin is bounded and reports through
-// `err`.  The arithmetic is that of the two-pass kernels (same values, same order).
-template <int ADT>
-__global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsigned* __restrict__ arrive, unsigned* __restrict__ err)
+// The two launches above are separated only by the statistics of the whole row.  (Exchanging them inside one launch
+// was built and measured in round 1: store -> drain -> atomic -> poll -> reload is ~3 dependent L2 round trips, 12.7 us
+// against 4.9 + 6.4 us for the two launches.)  Here nothing is exchanged: a (head, chunk) workgroup normalises its
+// probabilities by its OWN maximum m_c and sum l_c, rounds them to the activation dtype (gten/ops.h:972-997 -- Q8
+// blocks of 32 along the context, partial tail block) and leaves o_c = p_c . V_c plus (m_c, l_c); the consumer (the o
+// projection's prologue, PRO_ATTW) joins the chunks: out = sum_c w_c o_c, w_c = l_c exp(m_c - M) / sum_j l_j exp(m_j - M).
+//   * one chunk (n <= 256): m_c = M, l_c = S, w_0 = 1 -- the bytes of the two-pass kernels and of the operator path;
+//   * several chunks: a probability row is rounded against its chunk's scale instead of the row's.  The Q8 quants are
+//     scale-free (q = round(p 127 / absmax)), so what moves is the fp16 rounding of the block delta (and for f16
+//     activations the fp16 rounding of p itself): a relative 2^-11 per block, the size of the rounding the reference
+//     itself applies at that point (deviation 4; inside the f16 / q8 / q4 bands, tests).
+// The K rows and the V chunk are both requested at kernel entry, so the launch costs one memory latency.
+template <int ADT, bool MULTI>
+__global__ __launch_bounds__(256) void k_dec_attn_one64(const unsigned long long h0, const unsigned long long h1, const unsigned long long h2,
+                                                       const unsigned long long h3, const unsigned long long h4, const unsigned long long h5,
+                                                       const unsigned long long h6, const AttnArgs a0)
 {
+    AttnArgs a = MULTI ? attn_for_seq(a0, blockIdx.z) : a0;
+    if (!MULTI) {
+        // hot words: qkv_raw | rope_now | kcache | step | kv_pitch, max_ctx | n_embd, n_heads + (n_kv << 8) + (grp_shift1 << 16) | vcache
+        a.qkv_raw = from_word<float>(h0); a.rope_now = from_word<float2>(h1); a.kcache = (uint8_t*)from_word<uint8_t>(h2);
+        a.step = from_word<DecStep>(h3); a.kv_pitch = (size_t)(unsigned)(h4 & 0xffffffffull); a.max_ctx = (int)(h4 >> 32);
+        a.n_embd = (int)(unsigned)(h5 & 0xffffffffull); a.n_heads = (int)((h5 >> 32) & 0xffu); a.n_kv = (int)((h5 >> 40) & 0xffu); a.grp_shift1 = (int)(h5 >> 48);
+        a.vcache = (uint8_t*)from_word<uint8_t>(h6);
+    }
     constexpr int dh = 64, nblk = 2;
     constexpr int NW = (ADT == GTEN_Q8) ? 17 : 32;     // dwords per kv-head slice
-    const int n = a.step->n, pos = n - 1;
-    const int h = blockIdx.x, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
-    if (c0 >= n) return;
-    const int grp = a.n_heads / a.n_kv, g = h / grp;
+    // grid = (chunk, head, sequence): the chunks of one head go to different XCDs (see k_dec_attn_score64)
+    const int h = blockIdx.y, chunk = blockIdx.x, c0 = chunk * DEC_CHUNK;
+    const int grp = a.grp_shift1 ? (1 << (a.grp_shift1 - 1)) : a.n_heads / a.n_kv, g = a.grp_shift1 ? (h >> (a.grp_shift1 - 1)) : h / grp;
     const int kv_dim = a.n_kv * dh;
     const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
-    const int nch = (n + DEC_CHUNK - 1) / DEC_CHUNK;
-    const int len = min(DEC_CHUNK, n - c0);
 
     float* red = (float*)g_smem;                 // 16
     float* qf = red + 16 + dh;                   // dh
@@ -1694,178 +1752,186 @@ __global__ __launch_bounds__(256) void k_dec_attn_fused64(const AttnArgs a, unsi
     int8_t* qi8 = (int8_t*)(d16 + 16);           // dh
     int8_t* ki8 = qi8 + dh;                      // dh
     int8_t* vi8 = ki8 + dh;                      // dh
-    float* vf = (float*)(g_smem + 1536);         // dh   new v row values (f16 mode)
-    float* p = vf + dh;                          // 256
+    float* p = (float*)(g_smem + 1152);          // 256 (the head-vector scratch above ends at byte 1120)
     float* part = p + DEC_CHUNK;                 // 256
-    unsigned* vl = (unsigned*)(part + DEC_CHUNK);// DEC_CHUNK * NW dwords
+    unsigned* vl = (unsigned*)(part + DEC_CHUNK);// DEC_CHUNK * NW dwords: the chunk's V slices, row-major
 
-    // ---- request, in the order they are needed: this wave's new head row and its rotation,
-    //      this thread's cached K row, its share of the V chunk
-    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
-    const int src = (pw == 0) ? h * dh + t : (pw == 1) ? a.n_embd + g * dh + t : (pw == 2) ? a.n_embd + kv_dim + g * dh + t : 0;
-    const float raw = a.qkv_raw[src];
-    const float2 rot = a.rope[(size_t)pos * (dh / 2) + (t & (dh / 2 - 1))];
+    // ---- every request before the context length is known (k_dec_attn_score64 / k_dec_attn_pv64 explain why each is
+    //      safe): the raw projection this wave turns into a head vector, its rotation, this thread's cached K row,
+    //      the whole V chunk.  The V row AT the new position is being written by this very launch: that term comes
+    //      from the new v row on chip (below).
     const int c = c0 + threadIdx.x;
-    const int cs = (c < n && c != pos) ? c : c0;
-    const unsigned* kp = (const unsigned*)(a.kcache + (size_t)cs * a.kv_pitch + (size_t)g * head_bytes);
-    unsigned kw[NW], vw[NW];
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    const int roff = (pw == 1) ? a.n_embd + g * dh : (pw == 2) ? a.n_embd + kv_dim + g * dh : h * dh;
+    float raw = a.qkv_raw[roff + t];
+    if (MULTI) {
+        const float raw2 = a.qkv_raw[a.qkv_plane + roff + t];
+        raw += a.qkv_plane ? raw2 : 0.f;
+    }
+    const float2 rot = a.rope_now[t & 31];
+    __builtin_amdgcn_sched_barrier(0);
+    const int cs = min(c, a.max_ctx - 1);
+    const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
+    const gmem_u32 kp = as_global(a.kcache + (size_t)g * head_bytes) + (unsigned)cs * pitch_w;
+    unsigned kw[NW];
 #pragma unroll
     for (int j = 0; j < NW; j++) kw[j] = kp[j];
+    unsigned vw[NW];
+    {
+        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        const gmem_u32 vbase = as_global(a.vcache + (size_t)g * head_bytes);
+        const int last = a.max_ctx - 1 - c0;
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const int idx = threadIdx.x + k * 256;
-        int row = idx / NW;
-        const int w = idx - row * NW;
-        if (row >= len || c0 + row == pos) row = 0;           // the new row is patched in from LDS below
-        vw[k] = ((const unsigned*)(a.vcache + (size_t)(c0 + row) * a.kv_pitch + (size_t)g * head_bytes))[w];
+        for (int k = 0; k < NW; k++) {
+            vw[k] = vbase[(unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w];
+            row += 256 / NW; w += 256 % NW;
+            if (w >= NW) { w -= NW; row++; }
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
+    const int len = min(DEC_CHUNK, n - c0);
 
     const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
-    const bool writer = has_new && (h % grp == 0);
-    if (pw == 0) {
-        qf[t] = head_prep_cs(raw, true, true, rot, dh, ADT, qi8, qd, d16);
-    } else if (pw == 1 && has_new) {
-        const float v = head_prep_cs(raw, true, true, rot, dh, ADT, ki8, kd, d16 + 4);
-        kf[t] = v;
-        if (writer) {
-            uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+    const bool writer = has_new && (h == g * grp);
+    float vnew = 0.f;                             // wave 2: the new v row's element t (exact storage value)
+    if (pw < 3) {
+        int8_t* dq = (pw == 0) ? qi8 : (pw == 1) ? ki8 : vi8;
+        float* dd = (pw == 0) ? qd : (pw == 1) ? kd : kd + 4;
+        const float v = head_prep_cs(raw, true, pw != 2, rot, dh, ADT, dq, dd, d16 + 4 * pw);
+        if (pw == 0) qf[t] = v;
+        if (pw == 1) kf[t] = v;
+        if (pw == 2) vnew = v;
+        if (pw >= 1 && writer) {
+            uint8_t* row = ((pw == 1) ? a.kcache : a.vcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
             if (ADT == GTEN_Q8) {
-                uint8_t* blk = krow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-                blk[2 + (t & 31)] = (uint8_t)ki8[t];
-                if ((t & 31) == 0) *(uint16_t*)blk = d16[4 + (t >> 5)];
+                uint8_t* blk = row + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+                store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
+                if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * pw + (t >> 5)]);
             } else {
-                ((uint16_t*)krow)[t] = f2h(v);
-            }
-        }
-    } else if (pw == 2 && has_new) {
-        // every workgroup of the new row's chunk needs the new V row for its own p.V; one of them stores it
-        const float v = head_prep_cs(raw, true, false, rot, dh, ADT, vi8, kd + 4, d16 + 8);
-        vf[t] = v;
-        if (writer) {
-            uint8_t* vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
-            if (ADT == GTEN_Q8) {
-                uint8_t* blk = vrow + (size_t)(t >> 5) * GTEN_Q8_BYTES;
-                blk[2 + (t & 31)] = (uint8_t)vi8[t];
-                if ((t & 31) == 0) *(uint16_t*)blk = d16[8 + (t >> 5)];
-            } else {
-                ((uint16_t*)vrow)[t] = f2h(v);
+                store_global<uint16_t>((uint16_t*)row + t, f2h(v));
             }
         }
     }
-    __syncthreads();
-
-    // ---- pass 1: this thread's score, the chunk's max and sum of exponentials
-    const float scale = 1.0f / sqrtf((float)dh);
-    float sc = -INFINITY;
-    if (c < n) {
-        float acc = 0.f;
-        if (ADT == GTEN_Q8) {
-            const int* qi = (const int*)qi8;
-            if (c == pos) {
-                const int* ki = (const int*)ki8;
-#pragma unroll
-                for (int b = 0; b < nblk; b++) {
-                    int isum = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) isum = dot4(qi[b * 8 + j], ki[b * 8 + j], isum);
-                    acc += (float)isum * (qd[b] * kd[b]);
-                }
-            } else {
-                int isum = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) isum = dot4(qi[j], (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16), isum);
-                acc += (float)isum * (qd[0] * h2f((uint16_t)(kw[0] & 0xffffu)));
-                isum = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) isum = dot4(qi[8 + j], (int)kw[9 + j], isum);
-                acc += (float)isum * (qd[1] * h2f((uint16_t)(kw[8] >> 16)));
-            }
-        } else {
-            if (c == pos) {
-                for (int e = 0; e < dh; e++) acc += qf[e] * kf[e];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    acc += qf[2 * j] * h2f((uint16_t)(kw[j] & 0xffffu));
-                    acc += qf[2 * j + 1] * h2f((uint16_t)(kw[j] >> 16));
-                }
-            }
-        }
-        sc = acc * scale;
-    }
-    const float mx = block_max(sc, red);
-    const float ex = (c < n) ? expf(sc - mx) : 0.f;
-    const float sm = block_sum(ex, red);
-
-    // ---- the head's chunks exchange their statistics
-    float* st = a.stats + (size_t)h * a.n_chunks * 2;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(st + chunk * 2 + 0, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(st + chunk * 2 + 1, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // both stores have left before the arrival is counted
-        __hip_atomic_fetch_add(arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(arrive + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nch) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-    // all 16 words requested at once (words of chunks past nch are stale or another head's: discarded)
-    float sj[8], mj[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        mj[j] = __hip_atomic_load(st + j * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sj[j] = __hip_atomic_load(st + j * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    float M = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; j++) M = (j < nch) ? fmaxf(M, mj[j]) : M;
-    float S = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float term = sj[j] * expf(mj[j] - M);
-        S = (j < nch) ? S + term : S;
-    }
-
-    // ---- pass 2: probabilities rounded to the activation dtype, times V
-    p[threadIdx.x] = (c < n) ? expf(sc - M) / S : 0.f;
-    round_row_inplace(p, ADT, len);
+    // the V chunk goes to LDS now (its requests were issued after the K rows: by the time the scores are done it is
+    // there); the new position's slice is patched from the chip below
 #pragma unroll
     for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
     __syncthreads();
-    if (has_new && threadIdx.x < 64) {
-        // the new V row comes from LDS (its bytes may not have reached the cache yet)
-        uint8_t* row = (uint8_t*)vl + (size_t)(pos - c0) * (NW * 4);
-        if (ADT == GTEN_Q8) {
-            row[(t < 32) ? 2 + t : 36 + (t - 32)] = (uint8_t)vi8[t];
-            if ((t & 31) == 0) *(uint16_t*)(row + (t >> 5) * 34) = d16[8 + (t >> 5)];
-        } else {
-            ((uint16_t*)row)[t] = f2h(vf[t]);
-        }
-    }
-    __syncthreads();
 
-    const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const uint8_t* vb = (const uint8_t*)vl;
+    // ---- scores (k_dec_attn_score64's arithmetic)
+    const float scale = 1.0f / sqrtf((float)dh);
     float acc = 0.f;
     if (ADT == GTEN_Q8) {
+        const int* qi = (const int*)qi8;
+        int isum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) isum = dot4(qi[j], (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16), isum);
+        acc += (float)isum * (qd[0] * h2f((uint16_t)(kw[0] & 0xffffu)));
+        isum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) isum = dot4(qi[8 + j], (int)kw[9 + j], isum);
+        acc += (float)isum * (qd[1] * h2f((uint16_t)(kw[8] >> 16)));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            acc += qf[2 * j] * h2f((uint16_t)(kw[j] & 0xffffu));
+            acc += qf[2 * j + 1] * h2f((uint16_t)(kw[j] >> 16));
+        }
+    }
+    if (has_new) {
+        float accn = 0.f;
+        if (ADT == GTEN_Q8) {
+            const int* qi = (const int*)qi8;
+            const int* ki = (const int*)ki8;
+#pragma unroll
+            for (int b = 0; b < nblk; b++) {
+                int isum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) isum = dot4(qi[b * 8 + j], ki[b * 8 + j], isum);
+                accn += (float)isum * (qd[b] * kd[b]);
+            }
+        } else {
+            for (int e = 0; e < dh; e++) accn += qf[e] * kf[e];
+        }
+        if (c == pos) acc = accn;
+        // the new position's V slice, from the chip: the bytes the writer workgroup stores (every workgroup of the
+        // kv group computes the same ones)
+        if (pw == 2) {
+            uint8_t* vrow = (uint8_t*)vl + (size_t)(pos - c0) * (NW * 4);
+            if (ADT == GTEN_Q8) {
+                vrow[(t >> 5) * GTEN_Q8_BYTES + 2 + (t & 31)] = (uint8_t)vi8[t];
+                if ((t & 31) == 0) *(uint16_t*)(vrow + (t >> 5) * GTEN_Q8_BYTES) = d16[8 + (t >> 5)];
+            } else {
+                ((uint16_t*)vrow)[t] = f2h(vnew);
+            }
+        }
+    }
+    const float sc = (c < n) ? acc * scale : -INFINITY;
+    const float mx = block_max_n<4>(sc, red);               // red: first use; the sum takes its own words
+    const float ex = (c < n) ? expf(sc - mx) : 0.f;
+    const float sm = block_sum_n<4>(ex, red + 4);
+
+    // ---- probabilities against the chunk's own statistics, rounded to the activation dtype in registers
+    float pr = (c < n) ? ex / sm : 0.f;
+    if (ADT == GTEN_Q8) {
+        const Q8Scale s8 = q8_scale_from_absmax(max32(fabsf(pr)));
+        if (c < n) pr = (float)q8_round(pr, s8.scale) * s8.ddeq;
+    } else {
+        pr = h2f(f2h(pr));
+    }
+    p[threadIdx.x] = pr;
+    __syncthreads();                                         // p, and the patched V slice
+
+    // ---- p . V (k_dec_attn_pv64's arithmetic)
+    const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const uint8_t* vb = (const uint8_t*)vl;
+    float o = 0.f;
+    if (ADT == GTEN_Q8) {
         const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+        if (len == DEC_CHUNK) {
+            float pp[2][8];
+            int qv[2][8];
+            unsigned dv[2][8];
+            auto fetch = [&](int r, int slot) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint8_t* row = vb + (size_t)(cg + 4 * (8 * r + u)) * 68;
+                    pp[slot][u] = p[cg + 4 * (8 * r + u)];
+                    qv[slot][u] = (int)(int8_t)row[qoff];
+                    dv[slot][u] = *(const uint16_t*)(row + doff);
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int r = 0; r < DEC_CHUNK / 32; r++) {
+                if (r + 1 < DEC_CHUNK / 32) fetch(r + 1, (r + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) o += pp[r & 1][u] * ((float)qv[r & 1][u] * h2f((uint16_t)dv[r & 1][u]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll 8
-        for (int cl = cg; cl < len; cl += 4) {
-            const uint8_t* row = vb + (size_t)cl * 68;
-            acc += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
+            for (int cl = cg; cl < len; cl += 4) {
+                const uint8_t* row = vb + (size_t)cl * 68;
+                o += p[cl] * ((float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)));
+            }
         }
     } else {
-        for (int cl = cg; cl < len; cl += 4) acc += p[cl] * h2f(((const uint16_t*)(vb + (size_t)cl * 128))[e]);
+        for (int cl = cg; cl < len; cl += 4) o += p[cl] * h2f(((const uint16_t*)(vb + (size_t)cl * 128))[e]);
     }
-    part[threadIdx.x] = acc;
+    part[threadIdx.x] = o;
     __syncthreads();
     if (threadIdx.x < dh) {
-        float o = 0.f;
-        for (int gi = 0; gi < 4; gi++) o += part[gi * dh + threadIdx.x];
-        a.att_part[((size_t)h * a.n_chunks + chunk) * dh + threadIdx.x] = o;
+        float r = 0.f;
+        for (int gi = 0; gi < 4; gi++) r += part[gi * dh + threadIdx.x];
+        a.att_part[((size_t)h * a.n_chunks + chunk) * dh + threadIdx.x] = r;
+    }
+    if (threadIdx.x == 64) {
+        a.stats[((size_t)h * a.n_chunks + chunk) * 2 + 0] = mx;
+        a.stats[((size_t)h * a.n_chunks + chunk) * 2 + 1] = sm;
     }
 }
 
@@ -2364,6 +2430,281 @@ __global__ __launch_bounds__(256) void k_dec_attn_pv_g(const AttnArgs a0)
     }
 }
 
+// ---- both passes of the grouped pair in ONE launch with chunk-local statistics: k_dec_attn_one64's scheme (see there)
+// for a whole kv group.  A (sequence, chunk, kv head) workgroup requests its K rows AND its V chunk at kernel entry,
+// scores every head of the group, normalises against the chunk's own maxima / sums, rounds the probabilities to the
+// activation dtype and leaves p_c . V_c with (m_c, l_c) for the consumer's PRO_ATTW join -- no score round trip through
+// HBM (16.8 MB written and read back per block at 64 sequences), no second launch, the statistics formed once.
+// Per (head, position) the arithmetic and every reduction order are those of k_dec_attn_one64 (EXACT: byte-identical
+// outputs and statistics, the 8-sequence path; EXACT = false fuses each p.V multiply-add, the 16-64-sequence path).
+template <int GRP, bool EXACT, int ADT>
+__global__ __launch_bounds__(256) void k_dec_attn_one_g(const AttnArgs a0)
+{
+    constexpr int dh = 64, nblk = 2, NW = (ADT == GTEN_Q8) ? 17 : 32;
+    constexpr int GP = (GRP + 1) / 2;
+    const int g = blockIdx.z, chunk = blockIdx.y, c0 = chunk * DEC_CHUNK;
+    const AttnArgs a = attn_for_seq(a0, blockIdx.x);
+    const int kv_dim = a.n_kv * dh;
+    const size_t head_bytes = (ADT == GTEN_Q8) ? (size_t)nblk * GTEN_Q8_BYTES : (size_t)dh * 2;
+
+    float* red = (float*)g_smem;                                  // [2][4][GRP]: maxima, then sums
+    float* qd = red + 8 * GRP;                                    // [GRP][2] (+ pad to 4)
+    float* kd = qd + 4 * GRP;                                     // 8: new k deltas, new v deltas
+    float* qf = kd + 8;                                           // scratch f32 row of head_prep (unused values)
+    uint16_t* d16 = (uint16_t*)(qf + dh);                         // [GRP + 2][4] halves
+    int8_t* qi8 = (int8_t*)(d16 + 4 * (GRP + 2));                 // [GRP][64]
+    int8_t* ki8 = qi8 + GRP * dh;                                 // 64
+    int8_t* vi8 = ki8 + dh;                                       // 64
+    float* qfa = (float*)(((uintptr_t)(vi8 + dh) + 15) & ~(uintptr_t)15);   // f16 activations: [GRP][64] q values, then the new k row [64]
+    float* kfa = qfa + GRP * dh;
+    float* p = (ADT == GTEN_Q8) ? qfa : kfa + dh;                 // [GP][4][64][2]: position c of heads 2 jj, 2 jj + 1 at [jj][c & 3][c >> 2][.]
+    float* part = p;                                              // OVER p (see k_dec_attn_pv_g)
+    unsigned* vl = (unsigned*)(p + 2 * GP * DEC_CHUNK);           // DEC_CHUNK * NW dwords: the chunk's V slices, row-major
+
+    // ---- requests, none of which needs the context length
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    constexpr int NJ = (GRP + 3) / 4;
+    float qraw[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+    float kvraw = a.qkv_raw[a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+    {
+        float qraw2[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw2[jj] = a.qkv_raw[a.qkv_plane + (g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+        const float kvraw2 = a.qkv_raw[a.qkv_plane + a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_plane ? qraw2[jj] : 0.f;
+        kvraw += a.qkv_plane ? kvraw2 : 0.f;
+    }
+    const float2 rot = a.rope_now[t & 31];
+    __builtin_amdgcn_sched_barrier(0);
+    const int c = c0 + threadIdx.x;
+    const int cs = min(c, a.max_ctx - 1);
+    const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
+    const gmem_u32 kp = as_global(a.kcache + (size_t)g * head_bytes) + (unsigned)cs * pitch_w;
+    unsigned kw[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) kw[j] = kp[j];
+    unsigned vw[NW];
+    {
+        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        const gmem_u32 vbase = as_global(a.vcache + (size_t)g * head_bytes);
+        const int last = a.max_ctx - 1 - c0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            vw[k] = vbase[(unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w];
+            row += 256 / NW; w += 256 % NW;
+            if (w >= NW) { w -= NW; row++; }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
+    const int len = min(DEC_CHUNK, n - c0);
+
+    // ---- head vectors
+    const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
+    float vnew = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+        const int j = pw + 4 * jj;
+        if (j < GRP) {
+            const float v = head_prep_cs(qraw[jj], true, true, rot, dh, ADT, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+            if (ADT != GTEN_Q8) qfa[j * dh + t] = v;
+        }
+    }
+    if (pw < 2 && has_new) {
+        int8_t* dq = pw ? vi8 : ki8;
+        const float v = head_prep_cs(kvraw, true, pw == 0, rot, dh, ADT, dq, kd + 4 * pw, d16 + 4 * (GRP + pw));
+        uint8_t* row = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+        if (ADT == GTEN_Q8) {
+            uint8_t* blk = row + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+            store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
+            if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
+        } else {
+            if (pw == 0) kfa[t] = v;
+            if (pw == 1) vnew = v;
+            store_global<uint16_t>((uint16_t*)row + t, f2h(v));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
+    __syncthreads();
+
+    // ---- this position against every head of the group (k_dec_attn_score_g's arithmetic)
+    const float scale = 1.0f / sqrtf((float)dh);
+    float sc[GRP];
+    if (ADT == GTEN_Q8) {
+        const float kd0 = h2f((uint16_t)(kw[0] & 0xffffu)), kd1 = h2f((uint16_t)(kw[8] >> 16));
+        int kq[16];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            kq[j] = (int)__builtin_amdgcn_alignbit(kw[j + 1], kw[j], 16);
+            kq[8 + j] = (int)kw[9 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int* qi = (const int*)(qi8 + j * dh);
+            float acc = 0.f;
+            int isum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum = dot4(qi[k], kq[k], isum);
+            acc += (float)isum * (qd[2 * j] * kd0);
+            isum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], kq[8 + k], isum);
+            acc += (float)isum * (qd[2 * j + 1] * kd1);
+            sc[j] = acc * scale;
+        }
+    } else {
+        float acc[GRP];
+#pragma unroll
+        for (int j = 0; j < GRP; j++) acc[j] = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; k++) {
+            const float k0 = h2f((uint16_t)(kw[k] & 0xffffu)), k1 = h2f((uint16_t)(kw[k] >> 16));
+#pragma unroll
+            for (int j = 0; j < GRP; j++) {
+                const float2 q2 = *(const float2*)(qfa + j * dh + 2 * k);
+                acc[j] += q2.x * k0;
+                acc[j] += q2.y * k1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; j++) sc[j] = acc[j] * scale;
+    }
+    if (has_new) {
+        const int* ki = (const int*)ki8;
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            float acc = 0.f;
+            if (ADT == GTEN_Q8) {
+                const int* qi = (const int*)(qi8 + j * dh);
+                int isum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) isum = dot4(qi[k], ki[k], isum);
+                acc += (float)isum * (qd[2 * j] * kd[0]);
+                isum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) isum = dot4(qi[8 + k], ki[8 + k], isum);
+                acc += (float)isum * (qd[2 * j + 1] * kd[1]);
+            } else {
+                for (int e = 0; e < dh; e++) acc += qfa[j * dh + e] * kfa[e];
+            }
+            if (c == pos) sc[j] = acc * scale;
+        }
+        // the new position's V slice comes from the chip (the cache row is being written by this very launch)
+        if (pw == 1) {
+            uint8_t* vrow = (uint8_t*)vl + (size_t)(pos - c0) * (NW * 4);
+            if (ADT == GTEN_Q8) {
+                vrow[(t >> 5) * GTEN_Q8_BYTES + 2 + (t & 31)] = (uint8_t)vi8[t];
+                if ((t & 31) == 0) *(uint16_t*)(vrow + (t >> 5) * GTEN_Q8_BYTES) = d16[4 * (GRP + 1) + (t >> 5)];
+            } else {
+                ((uint16_t*)vrow)[t] = f2h(vnew);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GRP; j++)
+        if (c >= n) sc[j] = -INFINITY;
+    // ---- chunk maximum and sum of exponentials per head (all heads per barrier pair)
+    float mx[GRP], ex[GRP], sm[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        const float m = wave_max_dpp(sc[j]);
+        if (t == 0) red[pw * GRP + j] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        float m = red[j];
+        for (int w = 1; w < 4; w++) m = fmaxf(m, red[w * GRP + j]);
+        mx[j] = m;
+    }
+    float* reds = red + 4 * GRP;                                  // the sums take their own words: no barrier between the two
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        ex[j] = (c < n) ? expf(sc[j] - mx[j]) : 0.f;
+        const float sw = wave_sum(ex[j]);
+        if (t == 0) reds[pw * GRP + j] = sw;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        float s_ = 0.f;
+        for (int w = 0; w < 4; w++) s_ += reds[w * GRP + j];
+        sm[j] = s_;
+    }
+    if (threadIdx.x < GRP) {
+        // (a register array indexed by the thread: selected by a chain of compares, GRP <= 8)
+        float mj = mx[0], sj = sm[0];
+#pragma unroll
+        for (int j = 1; j < GRP; j++) { mj = ((int)threadIdx.x == j) ? mx[j] : mj; sj = ((int)threadIdx.x == j) ? sm[j] : sj; }
+        a.stats[((size_t)(g * GRP + threadIdx.x) * a.n_chunks + chunk) * 2 + 0] = mj;
+        a.stats[((size_t)(g * GRP + threadIdx.x) * a.n_chunks + chunk) * 2 + 1] = sj;
+    }
+    // ---- probabilities against the chunk's own statistics, rounded to the activation dtype (Q8 block = the 32 lanes
+    //      around this thread)
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        const float x = (c < n) ? ex[j] / sm[j] : 0.f;
+        float pr;
+        if (ADT == GTEN_Q8) {
+            const Q8Scale qs = q8_scale_from_absmax(max32(fabsf(x)));
+            pr = (c < n) ? (float)q8_round(x, qs.scale) * qs.ddeq : 0.f;
+        } else {
+            pr = h2f(f2h(x));
+        }
+        p[((((j >> 1) * 4 + (threadIdx.x & 3)) * 64 + (threadIdx.x >> 2)) << 1) + (j & 1)] = pr;
+    }
+    if (GRP & 1) p[((((GRP >> 1) * 4 + (threadIdx.x & 3)) * 64 + (threadIdx.x >> 2)) << 1) + 1] = 0.f;
+    __syncthreads();
+
+    // ---- p.V (k_dec_attn_pv_g's arithmetic)
+    const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const uint8_t* vb = (const uint8_t*)vl;
+    const int qoff = (e < 32) ? 2 + e : 36 + (e - 32), doff = (e < 32) ? 0 : 34;
+    att_f2 acc[GP];
+#pragma unroll
+    for (int jj = 0; jj < GP; jj++) acc[jj] = att_f2{0.f, 0.f};
+    for (int i = 0; cg + 4 * i < len; i += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint8_t* row = vb + (size_t)(cg + 4 * (i + u)) * (NW * 4);
+            v[u] = (ADT == GTEN_Q8) ? (float)(int8_t)row[qoff] * h2f(*(const uint16_t*)(row + doff)) : h2f(((const uint16_t*)row)[e]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < GP; jj++) {
+            const float* pj = p + (((jj * 4 + cg) * 64 + i) << 1);
+            const float4 pa = *(const float4*)pj, pb = *(const float4*)(pj + 4);
+            const att_f2 p0{pa.x, pa.y}, p1{pa.z, pa.w}, p2{pb.x, pb.y}, p3{pb.z, pb.w};
+            if (EXACT) {
+                acc[jj] += p0 * att_f2{v[0], v[0]};
+                acc[jj] += p1 * att_f2{v[1], v[1]};
+                acc[jj] += p2 * att_f2{v[2], v[2]};
+                acc[jj] += p3 * att_f2{v[3], v[3]};
+            } else {
+                acc[jj] = __builtin_elementwise_fma(p0, att_f2{v[0], v[0]}, acc[jj]);
+                acc[jj] = __builtin_elementwise_fma(p1, att_f2{v[1], v[1]}, acc[jj]);
+                acc[jj] = __builtin_elementwise_fma(p2, att_f2{v[2], v[2]}, acc[jj]);
+                acc[jj] = __builtin_elementwise_fma(p3, att_f2{v[3], v[3]}, acc[jj]);
+            }
+        }
+    }
+    // (part lies over p: wave cg has read only p[.][cg][.][.] and writes only part[.][cg][.][lane], the same words)
+#pragma unroll
+    for (int j = 0; j < GRP; j++) part[(((j >> 1) * 4 + cg) * 2 + (j & 1)) * 64 + e] = (j & 1) ? acc[j >> 1].y : acc[j >> 1].x;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < GRP * dh; idx += 256) {
+        const int j = idx >> 6, ee = idx & 63;
+        float o = 0.f;
+        for (int gi = 0; gi < 4; gi++) o += part[(((j >> 1) * 4 + gi) * 2 + (j & 1)) * 64 + ee];
+        a.att_part[((size_t)(g * GRP + j) * a.n_chunks + chunk) * dh + ee] = o;
+    }
+}
+
 // greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424).
 // Works on (value, index) candidates: either the logits themselves (idx == null)
 // or the per-wave winners the lm_head kernel left behind.
@@ -2438,8 +2779,6 @@ struct gten_hip_decoder {
     float* stg_f = nullptr;
     float* logits_m = nullptr;     // [n_seq][n_vocab]
     float* gu_raw = nullptr;       // [n_seq][2 n_ffn] raw gate | up rows (wide decode, n_seq >= 16)
-    unsigned* arrive = nullptr;    // per-head arrival counters of the one-launch attention (+ 1 error word)
-    bool fused_attn = false;
     int n_chunks = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -2455,6 +2794,7 @@ static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
     const bool off = e && e[0] == '1';
     const char* m = std::getenv("GTEN_HIP_ATTN_GROUPED_MIN");   // fewest sequences that take the grouped kernels
     const int min_seq = (m && atoi(m) > 1) ? atoi(m) : 8;        // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
+    if (t.adtype == GTEN_F16 && n_seq < 16) return false;        // f16 below 16 sequences: the per-head kernels (one launch, k_dec_attn_one64)
     return !off && n_seq >= min_seq && (t.adtype == GTEN_Q8 || t.adtype == GTEN_F16) && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
 }
 
@@ -2464,11 +2804,32 @@ static int grp_shift1_of(int n_heads, int n_kv)
     return (grp > 0 && (grp & (grp - 1)) == 0) ? __builtin_ctz(grp) + 1 : 0;
 }
 
+static bool attention_one_pass(int d_head);
+
+// which grouped launches run in the one-pass form (k_dec_attn_one_g; the consumer then joins with PRO_ATTW): every
+// Q8 configuration; f16 only below 16 sequences is per-head anyway, from 16 up its scores stay on the matrix cores
+// (k_dec_attn_score_gm_f16) in the two-launch form
+static bool grouped_one_pass(const AttnArgs& t, int n_seq)
+{
+    (void)n_seq;
+    return attention_one_pass(t.d_head) && t.adtype == GTEN_Q8;
+}
+
 template <int GRP, int ADT>
 static int launch_attention_g(const AttnArgs& t, int n_seq)
 {
     constexpr size_t NW = (ADT == GTEN_Q8) ? 17 : 32;
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
+    if constexpr (ADT == GTEN_Q8) if (grouped_one_pass(t, n_seq)) {
+        constexpr size_t GP = (GRP + 1) / 2;
+        const size_t smem = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 16 +
+                            (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4) + 2 * GP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4;
+        const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
+        const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
+        if (exact) DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_one_g<GRP, true, ADT>), grid, dim3(256), smem, t);
+        else DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_one_g<GRP, false, ADT>), grid, dim3(256), smem, t);
+        return 0;
+    }
     const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64 +
                          (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4 + 16);
     const size_t smem2 = (size_t)((GRP + 1) / 2 * 2) * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
@@ -2519,10 +2880,39 @@ static int launch_attention_grouped(const AttnArgs& t, int n_seq)
     }
 }
 
+// One launch with chunk-local statistics (k_dec_attn_one64) wherever the per-head 64-wide kernels run; the consumer
+// must then join the chunks with PRO_ATTW.  GTEN_HIP_ATTN_TWO_PASS=1 keeps the two launches, whose probabilities are
+// rounded against the statistics of the whole row exactly as the reference stores them (a numerics switch: the
+// contexts beyond one chunk then match the operator path's rounding points; tests compare both).
+static bool attention_one_pass(int d_head)
+{
+    const char* e = std::getenv("GTEN_HIP_ATTN_TWO_PASS");
+    return d_head == 64 && !(e && e[0] == '1');
+}
+
 static int launch_attention(const AttnArgs& t0, dim3 agrid, size_t smem1)
 {
     AttnArgs t = t0;
     t.grp_shift1 = grp_shift1_of(t.n_heads, t.n_kv);
+    if (attention_one_pass(t.d_head)) {
+        const size_t nw = (t.adtype == GTEN_Q8) ? 17 : 32;
+        const size_t smem = 1152 + (size_t)2 * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * nw * 4;
+        const unsigned long long geo = (unsigned long long)(unsigned)t.kv_pitch | ((unsigned long long)(unsigned)t.max_ctx << 32);
+        const unsigned long long heads = ((unsigned long long)(unsigned)t.n_heads << 32) | ((unsigned long long)(unsigned)t.n_kv << 40) |
+                                         ((unsigned long long)(unsigned)t.grp_shift1 << 48);
+        const AttnHotWords hw{{(unsigned long long)(uintptr_t)t.qkv_raw, (unsigned long long)(uintptr_t)t.rope_now, (unsigned long long)(uintptr_t)t.kcache,
+                               (unsigned long long)(uintptr_t)t.step, geo, (unsigned long long)(unsigned)t.n_embd | heads, (unsigned long long)(uintptr_t)t.vcache}};
+        const bool multi = agrid.z > 1 || t.kv_tab != nullptr;
+        const dim3 g64(agrid.y, agrid.x, agrid.z);     // (chunk, head, sequence)
+        if (t.adtype == GTEN_Q8) {
+            if (multi) DEC_LAUNCH_HOT(KT_DEC_ATTN_SCORE, (k_dec_attn_one64<GTEN_Q8, true>), g64, dim3(256), smem, hw, t);
+            else DEC_LAUNCH_HOT(KT_DEC_ATTN_SCORE, (k_dec_attn_one64<GTEN_Q8, false>), g64, dim3(256), smem, hw, t);
+        } else {
+            if (multi) DEC_LAUNCH_HOT(KT_DEC_ATTN_SCORE, (k_dec_attn_one64<GTEN_F16, true>), g64, dim3(256), smem, hw, t);
+            else DEC_LAUNCH_HOT(KT_DEC_ATTN_SCORE, (k_dec_attn_one64<GTEN_F16, false>), g64, dim3(256), smem, hw, t);
+        }
+        return 0;
+    }
     if (t.d_head == 64) {
         const size_t nw = (t.adtype == GTEN_Q8) ? 17 : 32;
         const size_t smem2 = (size_t)2 * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * nw * 4;
@@ -2559,7 +2949,10 @@ static GemvHotWords hot_of(const Gemv8Args& a)
     GemvHot& h = hw.h;
     if (PRO == PRO_RESID) { h.p0 = a.res_raw; h.p1 = a.res_a; h.p2 = a.norm_w; }
     else if (PRO == PRO_EMBED) { h.p0 = a.table; h.p1 = a.tokens; h.p2 = a.norm_w; }
-    else if (PRO == PRO_ATT) { h.p0 = a.att_part; h.p1 = (const void*)(uintptr_t)((unsigned)a.d_head_shift | ((unsigned)a.n_chunks << 8)); h.p2 = nullptr; }
+    else if (PRO == PRO_ATT || PRO == PRO_ATTW) {
+        h.p0 = a.att_part; h.p1 = (const void*)(uintptr_t)((unsigned)a.d_head_shift | ((unsigned)a.n_chunks << 8));
+        h.p2 = (PRO == PRO_ATTW) ? a.att_stats : nullptr;
+    }
     else { h.p0 = (WT == GTEN_F16) ? (const void*)a.act_f : (const void*)a.act_q; h.p1 = a.act_d; h.p2 = a.act_sum; }
     h.qs0 = a.qs[0]; h.ds0 = a.ds[0]; h.d_in = a.d_in; h.rows0 = a.rows[0]; h.step = a.step;
     return hw;
@@ -2629,7 +3022,6 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         a.step = dc->step; a.d_in = E; a.n_mats = 3;
         set_mat(a, 0, L.wq, WT, E, E); set_mat(a, 1, L.wk, WT, KV, E); set_mat(a, 2, L.wv, WT, KV, E);
         a.out = dc->qkv_raw; a.norm_w = (const uint16_t*)L.attn_norm; a.x_out = xbuf;
-        if (dc->fused_attn) { a.zero_words = dc->arrive; a.zero_count = d.n_heads; }
         if (l == 0) {
             a.table = d.embed; a.rope = dc->rope; a.rope_now = dc->rope_now; a.rope_half = dh / 2; a.n_vocab = d.n_vocab; a.tokens = dc->tokens;
             rc = launch_gemv8<WT, PRO_EMBED, NE, 2, 512>(KT_DEC_GEMV_QKV, a, E + 2 * KV);
@@ -2645,19 +3037,14 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         t.n_chunks = dc->n_chunks; t.n_embd = E;
         const dim3 agrid(d.n_heads, dc->n_chunks);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        if (dc->fused_attn) {
-            const size_t nw = (d.adtype == GTEN_Q8) ? 17 : 32;
-            const size_t smemf = 1536 + (size_t)(dh + 2 * DEC_CHUNK) * 4 + (size_t)DEC_CHUNK * nw * 4;
-            if (d.adtype == GTEN_Q8) {
-                DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_fused64<GTEN_Q8>), agrid, dim3(256), smemf, t, dc->arrive, dc->arrive + d.n_heads);
-            } else {
-                DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_fused64<GTEN_F16>), agrid, dim3(256), smemf, t, dc->arrive, dc->arrive + d.n_heads);
-            }
-        } else if (int arc = launch_attention(t, agrid, smem1)) return arc;
+        if (int arc = launch_attention(t, agrid, smem1)) return arc;
         Gemv8Args o{};
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
         o.att_part = dc->att_part; o.d_head = dh; o.d_head_shift = __builtin_ctz(dh); o.n_chunks = dc->n_chunks;
-        if ((rc = launch_gemv8<WT, PRO_ATT, NE, 2, 512, 1>(KT_DEC_GEMV_O, o, E))) return rc;
+        o.att_stats = dc->stats;
+        rc = attention_one_pass(dh) ? launch_gemv8<WT, PRO_ATTW, NE, 2, 512, 1>(KT_DEC_GEMV_O, o, E)
+                                    : launch_gemv8<WT, PRO_ATT, NE, 2, 512, 1>(KT_DEC_GEMV_O, o, E);
+        if (rc) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
         gu.res_a = xbuf; gu.res_raw = dc->proj_raw; gu.x_out = hbuf; gu.norm_w = (const uint16_t*)L.ffn_norm;
@@ -2702,7 +3089,7 @@ static int launch_stage_frag(int tag, Gemv8Args a, int n_seq)
 static size_t gemvm_lds_bytes(int wt, int n_seq, int d, bool silumul)
 {
     size_t b = silumul ? (size_t)n_seq * 64 * 4 : 0;
-    if (wt == GTEN_F16) b += ((size_t)n_seq * d * 4 <= GEMVM_F16_LDS_LIMIT) ? (size_t)n_seq * d * 4 : 0;
+    if (wt == GTEN_F16) b += ((size_t)n_seq * ((d + 511) / 512 * 512) * 4 <= GEMVM_F16_LDS_LIMIT) ? (size_t)n_seq * d * 4 : 0;   // (k_dec_gemvm: lds_f)
     else b += (size_t)n_seq * (d + (size_t)(d / 32) * 8);
     return b + 16;
 }
@@ -2713,8 +3100,13 @@ static int launch_gemvm(int tag, const Gemv8Args& a, int total_rows)
     const int rows_per_wg = (NT / 64) * R;
     for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.rows[k] % R == 0, "decoder: concatenated matrices must hold a multiple of %d rows", R);
     const GemvHotWords hw = hot_of<WT, PRO_ACTQ8>(a);
-    DEC_LAUNCH_HOT(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT),
-                   gemvm_lds_bytes(WT, S, a.d_in, false), hw, a);
+    const size_t lds = gemvm_lds_bytes(WT, S, a.d_in, false);
+    static bool raised = false;                    // (per instantiation)
+    if (lds > 64 * 1024 && !raised) {
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    DEC_LAUNCH_HOT(tag, (k_dec_gemvm<WT, NCH, R, S, EPI_RAW, NT>), dim3((total_rows + rows_per_wg - 1) / rows_per_wg), dim3(NT), lds, hw, a);
     return 0;
 }
 
@@ -2766,12 +3158,16 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         t.part_stride = d.n_heads * dc->n_chunks * dh;
         const dim3 agrid(d.n_heads, dc->n_chunks, S);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
-        if ((rc = attention_grouped_ok(t, S) ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
+        const bool grouped = attention_grouped_ok(t, S);
+        if ((rc = grouped ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
         // attention rows -> stage -> o projection
         Gemv8Args sa = base;
         sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
+        sa.att_stats = dc->stats; sa.stats_stride = d.n_heads * dc->n_chunks * 2;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
-        if ((rc = launch_stage<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
+        rc = (grouped ? grouped_one_pass(t, S) : attention_one_pass(dh)) ? launch_stage<WT, PRO_ATTW>(KT_DEC_STAGE, sa, S)
+                                                                         : launch_stage<WT, PRO_ATT>(KT_DEC_STAGE, sa, S);
+        if (rc) return rc;
         Gemv8Args o = base;
         o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw; o.raw_stride = E;
         o.act_q = dc->stg_q; o.act_d = dc->stg_d; o.act_sum = dc->stg_sum; o.act_f = dc->stg_f;
@@ -2787,7 +3183,10 @@ static int enqueue_step_multi(gten_hip_decoder* dc)
         gu.act_q = dc->stg_q; gu.act_d = dc->stg_d; gu.act_sum = dc->stg_sum; gu.act_f = dc->stg_f;
         gu.out_q = dc->act_q; gu.out_d = dc->act_d; gu.out_sum = dc->act_sum; gu.out_f = dc->act_f;
         const GemvHotWords ghw = hot_of<WT, PRO_ACTQ8>(gu);
-        DEC_LAUNCH_HOT(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), gemvm_lds_bytes(WT, S, E, true), ghw, gu);
+        const size_t gu_lds = gemvm_lds_bytes(WT, S, E, true);
+        if (gu_lds > 64 * 1024 && l == 0)
+            GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gu_lds));
+        DEC_LAUNCH_HOT(KT_DEC_GEMV_GATEUP, (k_dec_gemvm<WT, NE, 8, S, EPI_SILUMUL, 512>), dim3(F / 32), dim3(512), gu_lds, ghw, gu);
         Gemv8Args dn = base;
         dn.d_in = F; dn.n_mats = 1; set_mat(dn, 0, L.wdown, WT, E, F); dn.out = dc->down_raw; dn.raw_stride = E;
         dn.act_q = dc->act_q; dn.act_d = dc->act_d; dn.act_sum = dc->act_sum; dn.act_f = dc->act_f;
@@ -2975,8 +3374,11 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         if ((rc = grouped ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
         Gemv8Args sa = base;
         sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
+        sa.att_stats = dc->stats; sa.stats_stride = d.n_heads * dc->n_chunks * 2;
         sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
-        if ((rc = launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S))) return rc;
+        rc = (grouped ? grouped_one_pass(t, S) : attention_one_pass(dh)) ? launch_stage_frag<WT, PRO_ATTW>(KT_DEC_STAGE, sa, S)
+                                                                         : launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S);
+        if (rc) return rc;
         if ((rc = mmk(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->proj_raw, E, E, ks_of(E), L.wo, E))) return rc;
         Gemv8Args sh = base;
         sh.d_in = E; sh.res_a = xbuf; sh.res_raw = dc->proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
@@ -3036,6 +3438,9 @@ static int enqueue(gten_hip_decoder* dc)
     return fail(-4, "decoder: bad weight dtype %d", dc->d.wdtype);
 }
 
+static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, const gten_hip_layer_ptrs* layers,
+                         const gten_hip_kv_ptrs* kv, int n_seq);
+
 static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers,
                                  const gten_hip_kv_ptrs* kv, int n_seq, gten_hip_decoder** out)
 {
@@ -3059,7 +3464,26 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
                 "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: n_embd and n_ffn %% 256 == 0");
     GTR_REQUIRE(n_seq == 1 || (kv && dh == 64), "decoder_create: multi-sequence decode needs the cache table and d_head 64");
     GTR_REQUIRE(n_seq > 1 || d.logits, "decoder_create: null logits pointer");
+    if (n_seq > 1)
+        for (size_t i = 0; i < (size_t)n_seq * d.n_layers; i++)
+            GTR_REQUIRE(kv[i].kcache && kv[i].vcache, "decoder_create: null cache pointer (sequence %zu, layer %zu)", i / d.n_layers, i % d.n_layers);
+    // every failure past this point goes through gten_hip_decoder_destroy: nothing allocated so far is leaked
     auto* dc = new gten_hip_decoder;
+    if (const int rc = decoder_build(dc, d, layers, kv, n_seq)) {
+        char msg[512];
+        snprintf(msg, sizeof(msg), "%s", gten_hip_last_error());
+        gten_hip_decoder_destroy(dc);
+        return fail(rc, "%s", msg);
+    }
+    *out = dc;
+    return 0;
+}
+
+static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, const gten_hip_layer_ptrs* layers,
+                         const gten_hip_kv_ptrs* kv, int n_seq)
+{
+    const int dh = d.n_embd / d.n_heads;
+    const bool wide = n_seq >= 16;
     dc->d = d;
     dc->n_seq = n_seq;
     dc->layers.assign(layers, layers + d.n_layers);
@@ -3108,32 +3532,21 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
         if (wide) {
             GTR_CHECK(hipMalloc((void**)&dc->gu_raw, planes * S * (size_t)2 * F * 4));
             if (d.wdtype != GTEN_F16)
-                if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) { delete dc; return rc; }
+                if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) return rc;
         }
         std::vector<const void*> tab(S * d.n_layers * 2);
         for (size_t q = 0; q < S; q++)
             for (int l = 0; l < d.n_layers; l++) {
                 const gten_hip_kv_ptrs& p = kv[q * d.n_layers + l];
-                GTR_REQUIRE(p.kcache && p.vcache, "decoder_create: null cache pointer (sequence %zu, layer %d)", q, l);
                 tab[(q * d.n_layers + l) * 2] = p.kcache;
                 tab[(q * d.n_layers + l) * 2 + 1] = p.vcache;
             }
         GTR_CHECK(hipMalloc((void**)&dc->kv_tab, tab.size() * sizeof(void*)));
         GTR_CHECK(hipMemcpy(dc->kv_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
     }
-    // GTEN_HIP_ATTN_ONE_LAUNCH=1: single-sequence decode with 64-wide heads runs scores, softmax and p.V in
-    // one launch (k_dec_attn_fused64).  Off by default: measured 12.7 us against 4.9 + 6.4 us for the two
-    // launches at n = 2048 -- an in-launch exchange through L2 costs more than a kernel boundary here.
-    {
-        const char* one = getenv("GTEN_HIP_ATTN_ONE_LAUNCH");
-        dc->fused_attn = n_seq == 1 && dh == 64 && dc->n_chunks <= 8 && d.n_heads <= 512 && one && one[0] == '1';
-    }
-    GTR_CHECK(hipMalloc((void**)&dc->arrive, (size_t)(d.n_heads + 1) * 4));
-    GTR_CHECK(hipMemset(dc->arrive, 0, (size_t)(d.n_heads + 1) * 4));
-    if (int rc = rope_table(dh, &dc->rope)) { delete dc; return rc; }
+    if (int rc = rope_table(dh, &dc->rope)) return rc;
     GTR_CHECK(hipMalloc((void**)&dc->rope_now, S * (size_t)(dh / 2) * sizeof(float2)));
     GTR_CHECK(hipMemset(dc->rope_now, 0, S * (size_t)(dh / 2) * sizeof(float2)));
-    *out = dc;
     return 0;
 }
 
@@ -3160,7 +3573,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
-                    dc->logits_m, (void*)dc->kv_tab, dc->arrive, dc->gu_raw, dc->rope_now};
+                    dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;
@@ -3176,6 +3589,9 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && tokens_host && first >= 0 && count > 0 && first + count <= dc->d.max_ctx + 1, "decoder_set_tokens: bad range");
     GTR_REQUIRE(seq >= 0 && seq < dc->n_seq, "decoder_set_tokens: sequence %d outside [0, %d)", seq, dc->n_seq);
+    for (int i = 0; i < count; i++)        // the embedding kernels index the table with the raw id
+        GTR_REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < dc->d.n_vocab, "decoder_set_tokens: token id %d at position %d outside [0, %d)",
+                    tokens_host[i], first + i, dc->d.n_vocab);
     GTR_CHECK(hipMemcpyAsync(dc->tokens + (size_t)seq * (dc->d.max_ctx + 1) + first, tokens_host, (size_t)count * 4, hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     return 0;
@@ -3377,10 +3793,7 @@ int gten_hip_decoder_result_seq(gten_hip_decoder* dc, int seq, int n, int32_t* a
     GTR_REQUIRE(dc && argmax_host && n >= 1 && n <= dc->d.max_ctx, "decoder_result: bad arguments");
     GTR_REQUIRE(seq >= 0 && seq < dc->n_seq, "decoder_result: sequence %d outside [0, %d)", seq, dc->n_seq);
     GTR_CHECK(hipMemcpyAsync(argmax_host, dc->result + (size_t)seq * (dc->d.max_ctx + 2) + n, 4, hipMemcpyDeviceToHost, stream()));
-    unsigned stalled = 0;
-    if (dc->fused_attn) GTR_CHECK(hipMemcpyAsync(&stalled, dc->arrive + dc->d.n_heads, 4, hipMemcpyDeviceToHost, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
-    GTR_REQUIRE(!stalled, "decoder: an attention workgroup gave up waiting for its head's chunks (results invalid)");
     return 0;
 }
 

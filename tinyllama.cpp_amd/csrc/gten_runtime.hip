@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace gtr {
@@ -16,8 +17,10 @@ static char g_err[512] = "";
 static bool g_inited = false;
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
-static float2* g_rope = nullptr;      // [GTEN_ROPE_MAX_POS][d_head/2] (cos, sin)
-static int g_rope_dhead = 0;
+// RoPE tables, one per head width ever asked for: [GTEN_ROPE_MAX_POS][d_head/2] (cos, sin).  Never freed while the
+// runtime lives -- decoders keep the pointer in their kernel arguments and in captured hipGraphs, and models of
+// different head widths coexist in one process.
+static std::vector<std::pair<int, float2*>> g_rope;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -36,8 +39,9 @@ bool inited() { return g_inited; }
 // fast-math trig is not accurate at angles up to 2047 rad.
 int rope_table(int d_head, const float2** out)
 {
-    if (g_rope && g_rope_dhead == d_head) { *out = g_rope; return 0; }
-    if (g_rope) { GTR_CHECK(hipStreamSynchronize(g_stream)); GTR_CHECK(hipFree(g_rope)); g_rope = nullptr; }
+    for (const auto& e : g_rope)
+        if (e.first == d_head) { *out = e.second; return 0; }
+    GTR_REQUIRE(d_head >= 2 && d_head <= 1024 && d_head % 2 == 0, "rope_table: head width %d", d_head);
     const int half = d_head / 2;
     std::vector<float2> t((size_t)GTEN_ROPE_MAX_POS * half);
     const float d = (float)d_head;
@@ -46,10 +50,12 @@ int rope_table(int d_head, const float2** out)
             const float th = (float)m * std::pow(10000.0f, -(2.0f * j / d));
             t[(size_t)m * half + j] = make_float2(std::cos(th), std::sin(th));
         }
-    GTR_CHECK(hipMalloc((void**)&g_rope, t.size() * sizeof(float2)));
-    GTR_CHECK(hipMemcpy(g_rope, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
-    g_rope_dhead = d_head;
-    *out = g_rope;
+    float2* dev = nullptr;
+    GTR_CHECK(hipMalloc((void**)&dev, t.size() * sizeof(float2)));
+    const hipError_t e = hipMemcpy(dev, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(dev); GTR_CHECK(e); }
+    g_rope.emplace_back(d_head, dev);
+    *out = dev;
     return 0;
 }
 

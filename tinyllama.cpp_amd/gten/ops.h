@@ -20,7 +20,7 @@ namespace detail {
 
 // Token ids arrive as a non-owning HOST tensor (tinyllama.cpp:406).  Rows
 // [start_pos, n) are staged into one persistent HBM buffer per process.
-inline const int32_t* stage_tokens(const Tensor& tokens, int start_pos)
+inline const int32_t* stage_tokens(const Tensor& tokens, int start_pos, int n_vocab)
 {
     static void* dev = nullptr;
     static int cap = 0;
@@ -33,6 +33,10 @@ inline const int32_t* stage_tokens(const Tensor& tokens, int start_pos)
         GTEN_HIP_OK(gten_hip_malloc(&dev, (size_t)cap * sizeof(int32_t)));
     }
     const int32_t* host = static_cast<const int32_t*>(tokens.host_external_ptr());
+    // the embedding kernel indexes the table with the raw id: an id outside the vocabulary would be an
+    // out-of-bounds HBM read, so it is refused here, where the ids are still host memory
+    for (int i = start_pos; i < n; i++)
+        GTEN_ASSERTM(host[i] >= 0 && host[i] < n_vocab, "token id %d at position %d is outside the vocabulary [0, %d)", host[i], i, n_vocab);
     GTEN_HIP_OK(gten_hip_memcpy_h2d(static_cast<int32_t*>(dev) + start_pos, host + start_pos,
                                     (size_t)(n - start_pos) * sizeof(int32_t)));
     return static_cast<const int32_t*>(dev);
@@ -48,7 +52,7 @@ inline void token_embed(const Tensor& weight, const Tensor& tokens, Tensor& out,
     const int n_ctx = tokens.dimsize(0);
     const int n_embd = weight.dimsize(1);
     GTEN_ASSERT(out.shape_eq({n_ctx, n_embd}));
-    const int32_t* tok = detail::stage_tokens(tokens, start_pos);
+    const int32_t* tok = detail::stage_tokens(tokens, start_pos, weight.dimsize(0));
     GTEN_HIP_OK(gten_hip_token_embed(weight.device_weight(), dtype_code(weight.dtype()), weight.dimsize(0), tok,
                                      out.device_ptr_mut(), dtype_code(out.dtype()), (size_t)out.bstride(0),
                                      n_ctx, n_embd, start_pos));

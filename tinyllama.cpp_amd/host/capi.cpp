@@ -166,7 +166,7 @@ int gten_host_model_time_family(gten_host_model* m, int family, int n, int reps,
 {
     if (!avg_us) return -1;
     *avg_us = m->model->decode_time_family(family, n, reps, launches);
-    return 0;
+    return *avg_us < 0.0 ? -4 : 0;
 }
 
 int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out)
@@ -303,7 +303,7 @@ int gten_host_batch_time_family(gten_host_batch* b, int family, int n, int reps,
 {
     if (!avg_us) return -1;
     *avg_us = b->batch->decode_time_family(family, n, reps, launches);
-    return 0;
+    return *avg_us < 0.0 ? -4 : 0;
 }
 
 int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes)

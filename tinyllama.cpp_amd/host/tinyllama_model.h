@@ -130,7 +130,8 @@ public:
     {
         ensure_decoder();
         double us = 0.0;
-        GTEN_HIP_OK(gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches));
+        // (a family this decoder's step does not launch is reported, not fatal: < 0)
+        if (gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches) != 0) return -1.0;
         return us;
     }
     int decode_result(int n)
@@ -376,7 +377,8 @@ public:
     {
         ensure_decoder();
         double us = 0.0;
-        GTEN_HIP_OK(gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches));
+        // (a family this decoder's step does not launch is reported, not fatal: < 0)
+        if (gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches) != 0) return -1.0;
         return us;
     }
 
