@@ -78,6 +78,7 @@ def parse_args(argv=None):
                          "reported separately, `value` stays the single-sequence rate")
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--generate", type=int, default=256, help="also time real greedy generation of this many ids ending at the context limit (0 = skip)")
+    ap.add_argument("--serve", type=int, default=256, help="also serve a queue of this many synthetic prompts through the wide batch's slots (0 = skip)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
                     help="how the (untimed) context below the timed window is produced: single-token decode steps "
@@ -628,6 +629,27 @@ def worker(args, rank, local_rank, world, dist):
                                    "tok_s": round(new / max(dt - S * t_pre, 1e-9), 1),
                                    "note": "greedy ids generated up to n = %d for every sequence; tok/s = new ids / (wall time - "
                                            "n_seq x one prompt's processing time)" % N_CTX}
+        batch.close()
+    # secondary: continuous batching -- a queue of 256 synthetic prompts (64..512 ids each, up to 128 new ids per prompt)
+    # through 64 slots sharing every weight pass; a slot that ends takes the next prompt while the others go on
+    if secondary and fused and args.serve > 0 and args.wide_streams > 1:
+        S = args.wide_streams
+        batch = host.batch(cfg, S)
+        batch.load_synthetic(args.seed)
+        rng = np.random.default_rng(2024)
+        lens = rng.integers(64, 513, args.serve)
+        prompts = [list(host.synthetic_tokens(int(n), seed=rep_seed(999, j))) for j, n in enumerate(lens)]
+        batch.serve(prompts[:S], N_CTX, -1, 16, max_new=4)           # warm-up: graphs, first-use allocations
+        t0 = time.perf_counter()
+        got, st = batch.serve(prompts, N_CTX, -1, 16, max_new=128)
+        dt = time.perf_counter() - t0
+        out["serving"] = {"slots": S, "prompts": int(args.serve), "prompt_tokens": int(st["prompt_tokens"]), "new_tokens": int(st["new_tokens"]),
+                          "wall_s": round(dt, 3), "new_tok_s": round(st["new_tokens"] / dt, 1),
+                          "all_tok_s": round((st["new_tokens"] + st["prompt_tokens"]) / dt, 1),
+                          "shared_steps": int(st["steps"]), "prefill_s": round(st["prefill_s"], 3), "decode_s": round(st["decode_s"], 3),
+                          "slot_utilisation": round(st["new_tokens"] / max(st["steps"] * S, 1), 3),
+                          "note": "sustained rates over the whole queue, prompt processing included in the wall time (same stream, "
+                                  "between slices of 16 shared steps); slot_utilisation = new ids / (shared steps x slots)"}
         batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if secondary and args.prefill > 0:

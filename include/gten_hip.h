@@ -108,6 +108,13 @@ int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch,
                        void* out, int out_dtype, size_t out_pitch,
                        int n, int d_in, int d_out, int start_pos);
 
+/* ops::matmul_2d with >= 16 new rows and quantized weights runs on the matrix cores in one of two forms
+ * (csrc/gten_mfma.hip): fast (default) -- the block deltas folded into the f16 operands, sums accumulated across K
+ * inside the MFMA, results inside the q8 / q4 logit band -- or exact (on != 0) -- one MFMA per quant block = the
+ * reference's exact integer block dot, rescaled and added in the scalar build's order (gten/ops.h:296-312), bit for
+ * bit.  Process-wide; f16 weights are not affected. */
+int gten_hip_set_prefill_exact(int on);
+
 /* ops::rms_norm, gten/ops.h:762-814.  w: f16[d]. */
 int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f16,
                       void* out, size_t out_pitch, int n, int d, int start_pos);
@@ -188,6 +195,22 @@ int gten_hip_decoder_generate(gten_hip_decoder* dec, int n_first, int max_new, i
  * its caches holding rows [0, n_first[q] - 1)): finished sequences are parked while the others go on.
  * out_host is [n_seq][max_new], n_out [n_seq]. */
 int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, int max_new, int eos, int32_t* out_host, int* n_out);
+/* ---- continuous batching: the slots of a multi-sequence decoder are started and parked independently --------------
+ * A slot (= one sequence's K/V caches and token row) takes a new prompt as soon as its previous sequence has ended,
+ * while the other slots go on decoding; every step still streams the weights once for all slots.
+ *   slot_start: sequence `seq` generates from step n_first on -- its ids [0, n_first) must be set
+ *               (gten_hip_decoder_set_tokens_seq) and its caches hold rows [0, n_first - 1) (operator-path prefill);
+ *               each step's argmax becomes its next input token on the device;
+ *   slot_park:  the slot stops advancing (its row is still computed by the shared launches; the results are ignored);
+ *   run:        `steps` back-to-back graph replays of the whole batch, asynchronous; no live slot may pass max_ctx
+ *               (returns an error instead of launching);
+ *   slot_ids:   waits for the stream and copies the argmax ids of steps [n_from, n_from + count) of `seq`.
+ * The scheduler that drives these (prompt queue, eos, admission) is host code: TinyLlamaBatch::serve,
+ * tinyllama.cpp_amd/host/tinyllama_model.h. */
+int gten_hip_decoder_slot_start(gten_hip_decoder* dec, int seq, int n_first);
+int gten_hip_decoder_slot_park(gten_hip_decoder* dec, int seq);
+int gten_hip_decoder_run(gten_hip_decoder* dec, int steps);
+int gten_hip_decoder_slot_ids(gten_hip_decoder* dec, int seq, int n_from, int count, int32_t* ids_host);
 /* multi-sequence decoders: sequence q decodes row n_per_seq[q] - 1 (continuous batching: sequences of different
  * lengths share the weight passes); results are read per sequence with gten_hip_decoder_result_seq(dec, q, n_per_seq[q]) */
 int gten_hip_decoder_step_ragged(gten_hip_decoder* dec, const int* n_per_seq, int use_graph);

@@ -1,0 +1,108 @@
+"""-m gpu: continuous batching (round-1 verdict "slot admission/eviction").  A queue of prompts is
+served through the slots of a multi-sequence decoder: a slot whose sequence ended takes the next prompt while the
+others go on (TinyLlamaBatch::serve; gten_hip_decoder_slot_start / _slot_park / _run / _slot_ids).  Up to 8 slots every
+sequence's ids must be EXACTLY those of generating it alone on the single-sequence decoder."""
+import numpy as np
+import pytest
+
+from gpu_common import hip  # noqa: F401
+from __graft_entry__ import load_package
+from helpers import MODES, Q4, Q8, tiny_config
+from test_model_gpu import host_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def make_prompts(host, cfg, lengths, seed):
+    return [list(host.synthetic_tokens(n, seed=seed + 7 * i + n, n_vocab=cfg.n_vocab)) for i, n in enumerate(lengths)]
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+@pytest.mark.parametrize("n_seq", [2, 8])
+def test_queue_through_slots_equals_single_sequence_generation(hip, name, wd, ad, n_seq):
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 31337, i) for i in range(len(cfg.weight_shapes()))]
+    # prompts of 1 .. 260 ids: single-row and matrix-core prompt processing, both sides of the attention chunk boundary,
+    # one that fills the context, one with no room at all
+    lengths = [5, 40, 1, 17, 260, 9, 33, 100, 2, 64, 300, 319, 320, 12, 250, 7, 21]
+    prompts = make_prompts(host, cfg, lengths, 1000)
+    total = 320
+    m = host.model(cfg)
+    for i, w in enumerate(weights):
+        m.set_weight(i, w)
+    alone = [m.generate(p, total) if len(p) < total else np.array(p, np.int32) for p in prompts]
+    eos = int(alone[0][30])                              # a token that comes up: several sequences stop early at it
+    want = [m.generate(p, total, eos) if len(p) < total else np.array(p, np.int32) for p in prompts]
+    want_new = [m.generate(p, min(total, len(p) + 25), eos) if len(p) < total else np.array(p, np.int32) for p in prompts]
+    m.close()
+    assert any(len(w) < total for w in want) and any(len(w) == total for w in want)
+    b = host.batch(cfg, n_seq)
+    for i, w in enumerate(weights):
+        b.set_weight(i, w)
+    for slice_steps in (16, 5):
+        got, st = b.serve(prompts, total, eos, slice_steps)
+        assert len(got) == len(prompts)
+        for j in range(len(prompts)):
+            assert got[j].tolist() == want[j].tolist(), (name, n_seq, slice_steps, j, len(got[j]), len(want[j]))
+        assert st["prompt_tokens"] == sum(lengths)
+        assert st["new_tokens"] == sum(len(w) - len(p) for w, p in zip(want, prompts))
+        assert st["admissions"] >= len(prompts) - 2       # (the prompts with no room are returned as they came)
+    # a bound on the new ids per prompt
+    got, st = b.serve(prompts, total, eos, 8, max_new=25)
+    for j in range(len(prompts)):
+        assert got[j].tolist() == want_new[j].tolist(), (name, n_seq, "max_new", j)
+    # the decoder still serves the other entry points afterwards (slots view is reset)
+    toks = host.synthetic_tokens(20, seed=5, n_vocab=cfg.n_vocab)
+    for q in range(n_seq):
+        b.decode_begin(q, toks)
+    for n in range(1, 21):
+        b.decode_step(n, True)
+    assert 0 <= b.decode_result(0, 20) < cfg.n_vocab
+    b.close()
+
+
+def test_wide_batch_serves_a_queue(hip):
+    """16 slots (W.x on the matrix cores): the queue is served completely; with as many prompts as slots (no admission
+    after the start) the ids are those of gten_host_batch_generate on the same batch; longer queues keep every
+    invariant (prompt kept, first new id = argmax of the prompt's logits, lengths within bounds)"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 2718, i) for i in range(len(cfg.weight_shapes()))]
+    b = host.batch(cfg, 16)
+    for i, w in enumerate(weights):
+        b.set_weight(i, w)
+    lengths = [5 + (11 * i) % 90 for i in range(16)]
+    prompts = make_prompts(host, cfg, lengths, 50)
+    ref = b.generate(prompts, 200)
+    got, st = b.serve(prompts, 200, -1, 16)
+    for j in range(16):
+        assert got[j].tolist() == ref[j].tolist(), j
+    lengths = [3 + (17 * i) % 150 for i in range(50)]
+    prompts = make_prompts(host, cfg, lengths, 90)
+    got, st = b.serve(prompts, 220, -1, 16, max_new=40)
+    assert st["admissions"] == 50 and st["new_tokens"] == sum(len(g) - len(p) for g, p in zip(got, prompts))
+    for j, (g, p) in enumerate(zip(got, prompts)):
+        assert g[: len(p)].tolist() == p and len(g) == min(220, len(p) + 40), j
+        lg = b.prefill(0, p)
+        assert int(g[len(p)]) == int(np.argmax(lg)), j
+        assert ((g >= 0) & (g < cfg.n_vocab)).all()
+    b.close()
+
+
+def test_slot_api_errors_are_reported(hip):
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=64, n_layers=1))
+    b = host.batch(cfg, 4)
+    for i in range(len(cfg.weight_shapes())):
+        b.set_weight(i, host.synth_weight(cfg, 1, i))
+    with pytest.raises(pkg.GtenHipError):
+        b.serve([[1, 2, 3]], 0)                          # nothing to generate into
+    with pytest.raises(pkg.GtenHipError):
+        b.serve([list(range(1, 70))], 80)                # prompt longer than the context
+    got, st = b.serve([[1, 2, 3]], 64, -1, 16)
+    assert len(got[0]) == 64
+    b.close()

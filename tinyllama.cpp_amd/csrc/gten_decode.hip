@@ -2767,6 +2767,7 @@ struct gten_hip_decoder {
     float* best_val = nullptr;     // lm_head per-wave winners
     int* best_idx = nullptr;
     int n_best = 0;
+    std::vector<DecStep> slots;    // continuous batching (slot_start / slot_park / run): host view of every slot's step word
     int dev_n = -1;                // value of step->n on the device after the queued work (-1: unknown)
     std::vector<int> dev_ns;       // the same per sequence after a ragged step (empty: uniform, see dev_n)
     int only_family = -1;          // >= 0: enqueue only the launches of this kernel family (timing replays)
@@ -2811,8 +2812,14 @@ static bool attention_one_pass(int d_head);
 // (k_dec_attn_score_gm_f16) in the two-launch form
 static bool grouped_one_pass(const AttnArgs& t, int n_seq)
 {
-    (void)n_seq;
-    return attention_one_pass(t.d_head) && t.adtype == GTEN_Q8;
+    // 8 sequences: one launch (per sequence the bytes of single-sequence decode).  From 16 sequences up the two
+    // launches measured FASTER than the merged kernel (64 sequences, ctx 2048: 22.3 + 25.8 us against 62.4 us per
+    // block -- the merged workgroup holds K rows, V chunk and every head's scores at once: 104 VGPRs, 27 KB of LDS,
+    // 4 workgroups per CU through five barriers each), so the wide path keeps the two-launch pair; GTEN_HIP_ATTN_WIDE_ONE=1
+    // selects the merged kernel there (tests compare both).
+    const char* e = std::getenv("GTEN_HIP_ATTN_WIDE_ONE");
+    const bool wide_one = e && e[0] == '1';
+    return attention_one_pass(t.d_head) && t.adtype == GTEN_Q8 && (n_seq <= 8 || wide_one);
 }
 
 template <int GRP, int ADT>
@@ -3628,6 +3635,7 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
     }
     dc->dev_n = n + 1;
     dc->dev_ns.clear();
+    dc->slots.clear();
     return run_step(dc, use_graph);
 }
 
@@ -3651,6 +3659,7 @@ int gten_hip_decoder_step_ragged(gten_hip_decoder* dc, const int* n_per_seq, int
     dc->dev_ns.assign(n_per_seq, n_per_seq + dc->n_seq);
     for (int& v : dc->dev_ns) v += 1;                 // the argmax kernel advances every sequence
     dc->dev_n = -1;
+    dc->slots.clear();
     return run_step(dc, use_graph);
 }
 
@@ -3670,6 +3679,7 @@ int gten_hip_decoder_generate(gten_hip_decoder* dc, int n_first, int max_new, in
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     dc->dev_ns.clear();
+    dc->slots.clear();
     int got = 0;
     std::vector<int32_t> ids(GEN_SLICE);
     for (int n = n_first; n <= last;) {
@@ -3716,6 +3726,7 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, in
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     dc->dev_ns.clear();
+    dc->slots.clear();
     std::vector<int32_t> ids((size_t)GEN_SLICE);
     while (n_live > 0) {
         int cnt = GEN_SLICE;
@@ -3739,6 +3750,71 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, in
             }
         }
     }
+    return 0;
+}
+
+// ---- continuous batching: slots started / parked independently, the batch replayed free-running
+static int slots_view(gten_hip_decoder* dc)
+{
+    if (dc->slots.empty()) {
+        // every slot parked at a valid position until it is started
+        dc->slots.assign((size_t)dc->n_seq, DecStep{1, 0});
+        GTR_CHECK(hipMemcpyAsync(dc->step, dc->slots.data(), dc->slots.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));
+    }
+    dc->dev_n = -1;
+    dc->dev_ns.clear();
+    return 0;
+}
+
+int gten_hip_decoder_slot_start(gten_hip_decoder* dc, int seq, int n_first)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && seq >= 0 && seq < dc->n_seq, "decoder_slot_start: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
+    GTR_REQUIRE(n_first >= 1 && n_first <= dc->d.max_ctx, "decoder_slot_start: n_first=%d outside [1, %d]", n_first, dc->d.max_ctx);
+    if (int rc = slots_view(dc)) return rc;
+    dc->slots[(size_t)seq] = DecStep{n_first, 3};
+    GTR_CHECK(hipMemcpyAsync(dc->step + seq, &dc->slots[(size_t)seq], sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && seq >= 0 && seq < dc->n_seq, "decoder_slot_park: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
+    if (int rc = slots_view(dc)) return rc;
+    DecStep& s = dc->slots[(size_t)seq];
+    s.n = std::min(std::max(s.n, 1), dc->d.max_ctx);
+    s.advance = 0;
+    GTR_CHECK(hipMemcpyAsync(dc->step + seq, &s, sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && steps >= 0, "decoder_run: bad arguments");
+    GTR_REQUIRE(!prof_on(), "decoder_run: switch the per-launch profiler off first");
+    if (int rc = slots_view(dc)) return rc;
+    for (const DecStep& s : dc->slots)
+        GTR_REQUIRE(!(s.advance & 1) || s.n + steps - 1 <= dc->d.max_ctx, "decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n, dc->d.max_ctx);
+    for (int i = 0; i < steps; i++)
+        if (int rc = run_step(dc, 1)) return rc;
+    for (DecStep& s : dc->slots)
+        if (s.advance & 1) s.n += steps;          // (a slot that reaches max_ctx + 1 has to be parked or restarted before the next run)
+    return 0;
+}
+
+int gten_hip_decoder_slot_ids(gten_hip_decoder* dc, int seq, int n_from, int count, int32_t* ids_host)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && ids_host && seq >= 0 && seq < dc->n_seq, "decoder_slot_ids: bad arguments");
+    GTR_REQUIRE(n_from >= 1 && count >= 0 && n_from + count - 1 <= dc->d.max_ctx, "decoder_slot_ids: steps [%d, %d) outside [1, %d]", n_from, n_from + count, dc->d.max_ctx);
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    if (count > 0)
+        GTR_CHECK(hipMemcpy(ids_host, dc->result + (size_t)seq * (dc->d.max_ctx + 2) + n_from, (size_t)count * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

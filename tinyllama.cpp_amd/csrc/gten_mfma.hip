@@ -26,6 +26,15 @@
 // operands, which turns the nibble/byte -> f16 expansion into mask-and-or instead
 // of byte shuffles.  Results leave straight from the accumulators: a Q8 output
 // block is two adjacent 16-wide tiles of the same wave (DPP row maximum).
+//
+// FAST form (the default for quantized weights; gten_hip_set_prefill_exact(1) selects the exact form above): the block
+// deltas are folded into the f16 operands -- activations are expanded once per call to f16(q * da), a weight fragment
+// is multiplied by its block's dw as it leaves LDS (four v_pk_mul_f16) -- and the products accumulate ACROSS the K
+// blocks inside the matrix core.  No per-block rescale (12 of the exact form's 21 VALU instructions per MFMA), no
+// separate block-sum registers (so the 4 x 4 register tile fits).  What it costs: each operand element carries one
+// fp16 rounding (relative 2^-11, a fifth of the Q8 quantization step's own noise) and the sum is no longer in the
+// scalar build's order -- results agree with the exact form to ~1e-3 relative, inside the q8 / q4 logit band
+// (tests/test_prefill_gpu.py holds both forms to the reference's full-size prompt goldens).
 #include "gten_dev.h"
 #include "gten_rt.h"
 
@@ -63,6 +72,18 @@ __device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask_vgpr, unsig
     unsigned r;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(mask_vgpr), "s"(bits));
     return r;
+}
+
+// two f16 products in one instruction (v_pk_mul_f16)
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned a, unsigned b)
+{
+    half2_t x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    x = x * y;
+    unsigned out;
+    __builtin_memcpy(&out, &x, 4);
+    return out;
 }
 
 // 8 consecutive quants of one weight row (two dwords) -> 8 f16 in the fragment order
@@ -113,6 +134,8 @@ struct MfmaCfg {
 
 // Q8 activation rows [start_pos, n) -> f16 rows in the fragment order (q0,q2,q1,q3 per 4) + f32 block deltas.
 // One thread per (row, quant block).
+// FAST: the values q * delta rounded to f16 (the deltas folded in; `da` is not written).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_act_to_f16(const uint8_t* __restrict__ x, size_t x_pitch, int rows, int nb, int start_pos,
                                                     uint4* __restrict__ a16, float* __restrict__ da)
 {
@@ -129,13 +152,19 @@ __global__ __launch_bounds__(256) void k_act_to_f16(const uint8_t* __restrict__ 
         unsigned f[4];
         int8x4_to_f16(q[i], f[0], f[1]);
         int8x4_to_f16(q[i + 1], f[2], f[3]);
+        if (FAST) {
+            const unsigned d2 = (unsigned)blk[0] | ((unsigned)blk[0] << 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) f[k] = pk_mul_f16(f[k], d2);
+        }
         dst[i >> 1] = make_uint4(f[0], f[1], f[2], f[3]);
     }
-    da[idx] = h2f(blk[0]);
+    if (!FAST) da[idx] = h2f(blk[0]);
 }
 
 // The same, one thread per PAIR of adjacent blocks: a pair is 68 bytes, always 4-byte aligned, i.e. 17 dwords instead of
 // 2 x 17 two-byte loads (rows of an even number of blocks at a 4-byte aligned pitch: every activation width of the model).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_act_to_f16_x2(const uint8_t* __restrict__ x, size_t x_pitch, int rows, int nb, int start_pos,
                                                        uint4* __restrict__ a16, float* __restrict__ da)
 {
@@ -162,16 +191,22 @@ __global__ __launch_bounds__(256) void k_act_to_f16_x2(const uint8_t* __restrict
             unsigned f[4];
             int8x4_to_f16(q[b][i], f[0], f[1]);
             int8x4_to_f16(q[b][i + 1], f[2], f[3]);
+            if (FAST) {
+                const unsigned dh = b ? (w[8] >> 16) : (w[0] & 0xffffu);
+                const unsigned d2 = dh | (dh << 16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) f[k] = pk_mul_f16(f[k], d2);
+            }
             dst[i >> 1] = make_uint4(f[0], f[1], f[2], f[3]);
         }
-        da[bi] = h2f((uint16_t)(b ? (w[8] >> 16) : (w[0] & 0xffffu)));
+        if (!FAST) da[bi] = h2f((uint16_t)(b ? (w[8] >> 16) : (w[0] & 0xffffu)));
     }
 }
 
 // (2 waves per SIMD = a 256-VGPR budget: the block sums then come back in VGPRs instead of AGPRs, which
 //  would cost four v_accvgpr_read per MFMA in a loop that is bound by VALU issue)
 // a16: f16 activation rows of the NEW rows (row 0 = start_pos), pitch d_in * 2 (quantized) or x itself (f16 weights)
-template <int WT, int WM, int WN, int KB_>
+template <int WT, int WM, int WN, int KB_, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_matmul_mfma(
     const uint8_t* __restrict__ a16, size_t a_pitch, const float* __restrict__ da_rows, const void* __restrict__ w,
     uint8_t* __restrict__ out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
@@ -179,6 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     using C = MfmaCfg<WT, WM, WN, KB_>;
     constexpr int BM = C::BM, BN = C::BN, KB = C::KB, APITCH = C::APITCH, WPITCH = C::WPITCH, WROW = C::WROW;
     constexpr bool QUANT = C::QUANT;
+    constexpr bool EXACT = QUANT && !FAST;                   // per-block rescale in the scalar build's order
+    static_assert(QUANT || !FAST, "the fast form is about quantized weights");
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     const int g = lane >> 4, l16 = lane & 15;
@@ -242,8 +279,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (QUANT) {
 #pragma unroll
             for (int k = 0; k < C::W_PIECES; k++) r.w[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_src[k], s * (KB * 16), 0);
+            if (EXACT) {
 #pragma unroll
-            for (int k = 0; k < DA_PIECES; k++) r.da[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_da, da_src[k], s * (KB * 4), 0));
+                for (int k = 0; k < DA_PIECES; k++) r.da[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_da, da_src[k], s * (KB * 4), 0));
+            }
             if (KB == 4) r.dw = __builtin_amdgcn_raw_buffer_load_b64(rs_dw, dw_src, s * (KB * 2), 0);
             else r.dw[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_dw, dw_src, s * (KB * 2), 0);
         }
@@ -256,8 +295,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             float* sda = (float*)(sa + C::A_BYTES);
             uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
             float* sdw = (float*)(sw + C::W_BYTES);
+            if (EXACT) {
 #pragma unroll
-            for (int k = 0; k < DA_PIECES; k++) sda[da_dst[k]] = r.da[k];
+                for (int k = 0; k < DA_PIECES; k++) sda[da_dst[k]] = r.da[k];
+            }
 #pragma unroll
             for (int k = 0; k < C::W_PIECES; k++) {
                 *(v2i_t*)(sw + w_dst[k]) = (v2i_t){r.w[k][0], r.w[k][1]};
@@ -311,6 +352,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                                                      : *(const uint2*)(sw + f * WPITCH + (g >> 1) * (KB * 16) + kb * 16 + (g & 1) * 8);
                     bf[j] = weight_frag<WT>(by, nibble_shift, nib_mask);
                     dw[j] = sdw[kb * 256 + f];
+                    if (FAST) {
+                        // the block's weight delta folded into the fragment (exact f16 value, one rounding per element)
+                        const _Float16 dh = (_Float16)dw[j];
+                        bf[j] = bf[j] * (half8){dh, dh, dh, dh, dh, dh, dh, dh};
+                    }
                 } else {
                     bf[j] = *(const half8*)((const uint16_t*)w + wrow16[j] + (size_t)(s * KB + kb) * 32);
                 }
@@ -321,16 +367,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int t = 0; t < WM; t++) {
                 const int trow = wr * 16 * WM + 16 * t;
                 af[t] = *(const half8*)(sa + (trow + l16) * APITCH + kb * 64 + g * 16);
-                if (QUANT) da4[t] = *(const float4*)(sda + kb * BM + trow + g * 4);
+                if (EXACT) da4[t] = *(const float4*)(sda + kb * BM + trow + g * 4);
             }
             // ---- matrix phase: every MFMA of the block is issued before any result is touched, so the rescale
             //      never waits on the matrix pipe (and the SIMD's other wave fills it meanwhile)
-            floatx4 isum[WM][WN];
+            floatx4 isum[EXACT ? WM : 1][EXACT ? WN : 1];
 #pragma unroll
             for (int t = 0; t < WM; t++)
 #pragma unroll
                 for (int j = 0; j < WN; j++) {
-                    if (QUANT) {
+                    if (EXACT) {
                         const floatx4 z = {0.f, 0.f, 0.f, 0.f};
                         isum[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t], bf[j], z, 0, 0, 0);   // exact integer block sums
                     } else {
@@ -340,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             __builtin_amdgcn_sched_barrier(0);
             // ---- vector phase: dot += isum * da * dw, left to right like the scalar build (gten/ops.h:311).
             //      Plain f32 on purpose: packed f32 beside MFMAs is the slower form on gfx950 (build.py)
-            if (QUANT) {
+            if (EXACT) {
 #pragma unroll
                 for (int t = 0; t < WM; t++) {
                     const float da[4] = {da4[t].x, da4[t].y, da4[t].z, da4[t].w};
@@ -420,7 +466,7 @@ static int act_scratch(size_t a_bytes, size_t d_bytes, uint8_t** a16, float** da
     return 0;
 }
 
-template <int WT, int WM, int WN, int KB_ = 4>
+template <int WT, int WM, int WN, bool FAST, int KB_ = 4>
 static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, int out_dtype, size_t out_pitch,
                       int n, int d_in, int d_out, int start_pos)
 {
@@ -428,7 +474,7 @@ static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, i
     using C = MfmaCfg<WT, WM, WN, KB_>;
     static bool attr_set = false;
     if (!attr_set) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem()));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem()));
         attr_set = true;
     }
     const int rows = n - start_pos, nb = d_in / 32;
@@ -439,47 +485,61 @@ static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, i
         uint8_t* buf = nullptr;
         if (int rc = act_scratch((size_t)rows * d_in * 2, (size_t)rows * nb * 4, &buf, &da)) return rc;
         if (nb % 2 == 0 && x_pitch % 4 == 0 && ((uintptr_t)x % 4) == 0)
-            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16_x2, dim3((rows * (nb / 2) + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb,
+            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16_x2<FAST>, dim3((rows * (nb / 2) + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb,
                        start_pos, (uint4*)buf, da);
         else
-            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16, dim3((rows * nb + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos,
+            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16<FAST>, dim3((rows * nb + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos,
                        (uint4*)buf, da);
         a16 = buf; a_pitch = (size_t)d_in * 2;
     }
     const dim3 grid((d_out + C::BN - 1) / C::BN, (rows + C::BM - 1) / C::BM), block(256);
-    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_>), grid, block, C::smem(), a16, a_pitch, (const float*)da, w, (uint8_t*)out,
+    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, C::smem(), a16, a_pitch, (const float*)da, w, (uint8_t*)out,
                out_dtype, out_pitch, n, d_in, d_out, start_pos);
     return 0;
 }
 
+// exact (per-block rescale, the scalar build's order) or fast (deltas folded into the operands): gten_hip_set_prefill_exact
+static bool g_prefill_exact = false;
+
 // the largest tile that still gives the chip enough workgroups
-template <int WT>
+template <int WT, bool FAST>
 static int launch_wt(const void* x, size_t x_pitch, const void* w, void* out, int out_dtype, size_t out_pitch,
                      int n, int d_in, int d_out, int start_pos)
 {
     const int rows = n - start_pos;
     auto wgs = [&](int bm, int bn) { return ((d_out + bn - 1) / bn) * ((rows + bm - 1) / bm); };
     static const int forced = [] { const char* e = std::getenv("GTEN_HIP_MFMA_CFG"); return e ? atoi(e) : 0; }();   // tuning aid: 44 | 42 | 24 | 22 | 12
-#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos)
-    // (measured at 2048 rows, q4, W.x total: <2,4> 14.2 ms | <2,2> 15.3 | <4,2> 19.3 | <4,4> 26.2 | <2,4> with 2-block
-    //  stages 15.3: the 4-row-tile variants fit one workgroup per CU only, and occupancy matters more than the
+#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos)
+    // (exact form, measured at 2048 rows, q4, W.x total: <2,4> 14.2 ms | <2,2> 15.3 | <4,2> 19.3 | <4,4> 26.2 | <2,4> with
+    //  2-block stages 15.3: the 4-row-tile variants fit one workgroup per CU only, and occupancy matters more than the
     //  amortised nibble expansion once the kernel is VALU-bound at 2 waves per SIMD)
     if (forced == 44) MF_GO(4, 4);
     if (forced == 42) MF_GO(4, 2);
     if (forced == 24) MF_GO(2, 4);
     if (forced == 22) MF_GO(2, 2);
     if (forced == 12) MF_GO(1, 2);
+    if (FAST && rows > 64 && wgs(128, 128) >= 256) MF_GO(4, 4);
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
     if (rows > 32) MF_GO(2, 2);
     MF_GO(1, 2);
 #undef MF_GO
 }
 
+extern "C" int gten_hip_set_prefill_exact(int on)
+{
+    g_prefill_exact = on != 0;
+    return 0;
+}
+
 int gten_launch_matmul_mfma(const void* x, int x_dtype, size_t x_pitch, const void* w, int w_dtype,
                             void* out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
 {
     (void)x_dtype;
-    if (w_dtype == GTEN_F16) return launch_wt<GTEN_F16>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-    if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-    return launch_wt<GTEN_Q4>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    if (w_dtype == GTEN_F16) return launch_wt<GTEN_F16, false>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    if (g_prefill_exact) {
+        if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8, false>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+        return launch_wt<GTEN_Q4, false>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    }
+    if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8, true>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    return launch_wt<GTEN_Q4, true>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
 }

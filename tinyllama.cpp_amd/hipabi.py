@@ -78,13 +78,14 @@ class GtenHip:
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
         "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
-        "gten_hip_add", "gten_hip_qkv_attn",
+        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact",
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
         # the export check covers the whole header
         "gten_hip_decoder_create", "gten_hip_decoder_destroy", "gten_hip_decoder_set_tokens",
         "gten_hip_decoder_step", "gten_hip_decoder_generate", "gten_hip_decoder_generate_multi", "gten_hip_decoder_step_ragged", "gten_hip_decoder_result", "gten_hip_decoder_time_family",
         "gten_hip_decoder_create_multi", "gten_hip_decoder_set_tokens_seq", "gten_hip_decoder_result_seq",
         "gten_hip_decoder_logits_seq",
+        "gten_hip_decoder_slot_start", "gten_hip_decoder_slot_park", "gten_hip_decoder_run", "gten_hip_decoder_slot_ids",
     ]
 
     def __init__(self, path=None):

@@ -285,6 +285,28 @@ int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const i
     return 0;
 }
 
+int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
+                          int max_tokens, int eos, int slice, int max_new, int32_t* out, int32_t* n_total, double* stats)
+{
+    if (!prompts || !n_prompt || !out || !n_total || n_prompts <= 0 || max_tokens <= 0 || slice <= 0) return -1;
+    std::vector<std::vector<int32_t>> ps((size_t)n_prompts), res;
+    for (int j = 0; j < n_prompts; j++) {
+        if (n_prompt[j] <= 0 || n_prompt[j] > max_prompt || n_prompt[j] > b->cfg.max_ctx) return -1;
+        ps[(size_t)j].assign(prompts + (size_t)j * max_prompt, prompts + (size_t)j * max_prompt + n_prompt[j]);
+    }
+    const TinyLlamaBatch::ServeStats st = b->batch->serve(ps, max_tokens, eos, slice, &res, max_new);
+    for (int j = 0; j < n_prompts; j++) {
+        const int take = std::min((int)res[(size_t)j].size(), std::max(max_tokens, n_prompt[j]));
+        std::memcpy(out + (size_t)j * std::max(max_tokens, max_prompt), res[(size_t)j].data(), (size_t)take * sizeof(int32_t));
+        n_total[j] = take;
+    }
+    if (stats) {
+        stats[0] = (double)st.prompt_tokens; stats[1] = (double)st.new_tokens; stats[2] = (double)st.steps;
+        stats[3] = (double)st.admissions; stats[4] = st.prefill_s; stats[5] = st.decode_s;
+    }
+    return 0;
+}
+
 int gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out)
 {
     if (!argmax_out || seq < 0 || seq >= b->batch->n_seq()) return -1;

@@ -5,6 +5,8 @@
 // (SURVEY 8(f) rank 4).
 #pragma once
 
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <fstream>
 #include <iostream>
@@ -380,6 +382,91 @@ public:
         // (a family this decoder's step does not launch is reported, not fatal: < 0)
         if (gten_hip_decoder_time_family(dec_, family, n, reps, &us, launches) != 0) return -1.0;
         return us;
+    }
+
+    // ---- continuous batching: a queue of prompts served through the n_seq slots ------------------------------
+    // Every prompt is generated greedily to `max_tokens` ids in all (prompt included) or until `eos` (not stored,
+    // tinyllama.cpp:425), as greedy_sample does for one sequence.  A slot whose sequence has ended takes the next
+    // prompt of the queue at once: the prompt is processed on the slot's own caches (operator path, iteration 0 of
+    // the reference loop incl. the host argmax of its logits), the slot is started (gten_hip_decoder_slot_start) and
+    // joins the shared steps; the batch runs `slice` free-running steps between two looks at the results.  Per
+    // sequence the ids are those of generating it alone (bit for bit up to 8 slots; tests/test_serving_gpu.py).
+    struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0; double prefill_s = 0.0, decode_s = 0.0; };
+    // (max_new > 0 additionally bounds the ids generated per prompt)
+    ServeStats serve(const std::vector<std::vector<int32_t>>& prompts, int max_tokens, int eos, int slice,
+                     std::vector<std::vector<int32_t>>* out, int max_new = 0)
+    {
+        using clock = std::chrono::steady_clock;
+        ensure_decoder();
+        const int S = n_seq();
+        ServeStats st;
+        out->assign(prompts.size(), {});
+        std::vector<int> job((size_t)S, -1), cur((size_t)S, 0), last((size_t)S, 0);   // per slot: prompt index, next step, last step
+        size_t next = 0;
+        int live = 0;
+        std::vector<int32_t> ids((size_t)std::max(slice, 1));
+        for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
+        auto admit = [&](int q) {
+            while (next < prompts.size()) {
+                const int j = (int)next++;
+                std::vector<int32_t>& row = (*out)[(size_t)j];
+                row = prompts[(size_t)j];
+                const int P = (int)row.size();
+                GTEN_ASSERTM(P >= 1 && P <= n_ctx_, "serve: prompt %d has %d ids (context %d)", j, P, n_ctx_);
+                st.prompt_tokens += P;
+                const int limit = std::min(std::min(max_tokens, n_ctx_), max_new > 0 ? P + max_new : n_ctx_);   // ids in all
+                if (P >= limit) continue;                                  // no room to generate: returned as is
+                const auto t0 = clock::now();
+                Tensor tk(row.data(), {P}, kInt32);
+                const Tensor lg = seq(q).logits(tk, 0);                    // this slot's caches now hold rows [0, P)
+                const float* p = lg.data_ptr<float>();
+                int best_i = 0;
+                float best = -std::numeric_limits<float>::infinity();
+                for (int k = 0; k < lg.numel(); k++)
+                    if (p[k] > best) { best = p[k]; best_i = k; }
+                st.prefill_s += std::chrono::duration<double>(clock::now() - t0).count();
+                st.admissions++;
+                if (best_i == eos) continue;                               // ended at once: the slot takes the next prompt
+                row.push_back(best_i);
+                st.new_tokens++;
+                if ((int)row.size() >= limit) continue;
+                GTEN_HIP_OK(gten_hip_decoder_set_tokens_seq(dec_, q, row.data(), 0, (int)row.size()));
+                GTEN_HIP_OK(gten_hip_decoder_slot_start(dec_, q, (int)row.size()));
+                job[(size_t)q] = j; cur[(size_t)q] = (int)row.size(); last[(size_t)q] = limit - 1;
+                live++;
+                return;
+            }
+        };
+        for (int q = 0; q < S; q++) admit(q);
+        while (live > 0) {
+            int cnt = std::max(slice, 1);
+            for (int q = 0; q < S; q++)
+                if (job[(size_t)q] >= 0) cnt = std::min(cnt, last[(size_t)q] - cur[(size_t)q] + 1);   // nobody runs past its last step
+            const auto t0 = clock::now();
+            GTEN_HIP_OK(gten_hip_decoder_run(dec_, cnt));
+            st.steps += cnt;
+            for (int q = 0; q < S; q++) {
+                if (job[(size_t)q] < 0) continue;
+                GTEN_HIP_OK(gten_hip_decoder_slot_ids(dec_, q, cur[(size_t)q], cnt, ids.data()));
+                std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
+                bool stop = false;
+                for (int i = 0; i < cnt && !stop; i++) {
+                    if (ids[(size_t)i] == eos) stop = true;
+                    else { row.push_back(ids[(size_t)i]); st.new_tokens++; }
+                }
+                cur[(size_t)q] += cnt;
+                if (stop || cur[(size_t)q] > last[(size_t)q]) {
+                    GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
+                    job[(size_t)q] = -1;
+                    live--;
+                }
+            }
+            st.decode_s += std::chrono::duration<double>(clock::now() - t0).count();
+            for (int q = 0; q < S; q++)
+                if (job[(size_t)q] < 0) admit(q);
+        }
+        for (auto& m : seqs_) (void)m;                                   // (logits mirrors are refreshed on the next read)
+        return st;
     }
 
 private:

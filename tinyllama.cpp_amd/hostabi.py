@@ -39,7 +39,7 @@ class GtenHost:
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
-        "gten_host_batch_prefill", "gten_host_batch_generate", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
+        "gten_host_batch_prefill", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
         "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
     ]
 
@@ -80,6 +80,7 @@ class GtenHost:
         self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
         self._bstepr = _sig(L, "gten_host_batch_decode_step_ragged", ci, [vp, vp, ci])
         self._bgen = _sig(L, "gten_host_batch_generate", ci, [vp, vp, vp, ci, ci, ci, vp, vp])
+        self._bserve = _sig(L, "gten_host_batch_serve", ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp])
         self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
         self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
         self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
@@ -303,6 +304,25 @@ class HostBatch:
         self._ck(self.host._bgen(self.h, pr.ctypes.data_as(C.c_void_p), npr.ctypes.data_as(C.c_void_p), mp, max_tokens, eos,
                                  out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p)), "batch_generate")
         return [out[q, : tot[q]].copy() for q in range(self.n_seq)]
+
+    def serve(self, prompts, max_tokens, eos=-1, slice_steps=16, max_new=0):
+        """continuous batching: the queue `prompts` (any number) through this batch's slots; returns (list of id
+        arrays -- prompt + new ids, one per prompt, in queue order -- and a dict of counters)"""
+        mp = max(len(p) for p in prompts)
+        width = max(max_tokens, mp)
+        pr = np.zeros((len(prompts), mp), np.int32)
+        npr = np.zeros(len(prompts), np.int32)
+        for j, p in enumerate(prompts):
+            pr[j, : len(p)] = p
+            npr[j] = len(p)
+        out = np.zeros((len(prompts), width), np.int32)
+        tot = np.zeros(len(prompts), np.int32)
+        st = np.zeros(6, np.float64)
+        self._ck(self.host._bserve(self.h, pr.ctypes.data_as(C.c_void_p), npr.ctypes.data_as(C.c_void_p), len(prompts), mp, max_tokens, eos,
+                                   slice_steps, max_new, out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)),
+                 "batch_serve")
+        keys = ("prompt_tokens", "new_tokens", "steps", "admissions", "prefill_s", "decode_s")
+        return [out[j, : tot[j]].copy() for j in range(len(prompts))], dict(zip(keys, st.tolist()))
 
     def decode_result(self, seq, n):
         out = C.c_int32(-1)
