@@ -466,11 +466,11 @@ def worker(args, rank, local_rank, world, dist):
         # library's stream around 20 replays of a graph holding ONLY that family's launches.
         bracket_us = ms * 1e3 / launches
         avg_us, per_replay = bracket_us, launches // P
-        if fused:
+        if fused and use_graph:              # (--no-graph runs are counter collections: no graph is captured at all)
             avg_us, per_replay = model.time_family(hip.prof_family_index(fam), N_CTX, 20)
         # the same isolated timing for every family of the step (launches of ONE family replayed back to back)
         family_us = {}
-        if fused:
+        if fused and use_graph:
             for f2 in prof:
                 try:
                     u2, _ = model.time_family(hip.prof_family_index(f2), N_CTX, 20)
@@ -664,11 +664,20 @@ def worker(args, rank, local_rank, world, dist):
         hip.sync()
         dt = (time.perf_counter() - t0) / reps
         flops = 2.0 * 1_034_426_368 * P
+        # where the time goes: one more pass with an event pair around every launch (adds ~2 us per launch)
+        hip.prof_enable(True)
+        model.logits(toks[:P], 0, want=False)
+        fams = {k: round(v[1], 3) for k, v in hip.prof_read().items()}
+        hip.prof_enable(False)
+        wx_ms = fams.get("matmul_2d_mfma", 0.0)
         out["prefill"] = {"prompt_tokens": P, "ms": round(dt * 1e3, 3), "tok_s": round(P / dt, 1),
                           "linear_tflops": round(flops / dt / 1e12, 2),
-                          "note": "W.x on v_mfma_f32_16x16x32_f16 (one MFMA = one exact 32-wide quant block; gten_mfma.hip), "
+                          "family_ms": fams,
+                          "wx_tflops": round((flops - 2.0 * 32003 * 2048 * (P - 1)) / (wx_ms * 1e-3) / 1e12, 1) if wx_ms > 0 else None,
+                          "note": "W.x on v_mfma_f32_16x16x32_f16 (gten_mfma.hip, fast form: block deltas folded into the f16 operands, K accumulated in the matrix core), "
                                   "attention on gten_attn_tiled.hip (int8 / f16 MFMA scores), element-wise ops on the "
-                                  "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time"}
+                                  "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time; wx_tflops = the same FLOPs (lm_head: last row only) / "
+                                  "the event-bracketed time of the W.x launches alone (activation expansion included)"}
     # secondary: real greedy generation (every token is the argmax of the previous step), the reference-style loop
     # (logits to the host, host argmax, one call per token) against the sampler on the device
     if secondary and fused and args.generate > 0:

@@ -192,9 +192,11 @@ int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
  * stored, as in the reference).  The new ids are copied to out_host[0 .. *n_out).  Single-sequence decoders. */
 int gten_hip_decoder_generate(gten_hip_decoder* dec, int n_first, int max_new, int eos, int32_t* out_host, int* n_out);
 /* ... and for every sequence of a multi-sequence decoder, sequence q from step n_first[q] (its ids [0, n_first[q]) set,
- * its caches holding rows [0, n_first[q] - 1)): finished sequences are parked while the others go on.
- * out_host is [n_seq][max_new], n_out [n_seq]. */
-int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, int max_new, int eos, int32_t* out_host, int* n_out);
+ * its caches holding rows [0, n_first[q] - 1)): finished sequences are parked while the others go on.  Sequence q produces at
+ * most max_new_seq[q] ids (NULL: max_new for all; 0: the sequence is parked from the start); out_host is [n_seq][max_new],
+ * n_out [n_seq]. */
+int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, const int* max_new_seq, int max_new, int eos,
+                                    int32_t* out_host, int* n_out);
 /* ---- continuous batching: the slots of a multi-sequence decoder are started and parked independently --------------
  * A slot (= one sequence's K/V caches and token row) takes a new prompt as soon as its previous sequence has ended,
  * while the other slots go on decoding; every step still streams the weights once for all slots.

@@ -68,8 +68,19 @@ def make_converter_pins():
     blocks8 = np.concatenate([d8.numpy().view(np.uint8).reshape(-1, 2), q8.numpy().view(np.uint8).reshape(-1, 32)], axis=1)
     blocks4 = np.concatenate([d4.numpy().view(np.uint8).reshape(-1, 2), q4.numpy().reshape(-1, 16)], axis=1)
     f16 = t.to(torch.float16).numpy().view(np.uint8)
-    np.savez_compressed(os.path.join(HERE, "converter_pins.npz"), w=w, q8=blocks8.reshape(8, -1), q4=blocks4.reshape(8, -1),
-                        f16=f16.reshape(8, -1))
+    out = dict(w=w, q8=blocks8.reshape(8, -1), q4=blocks4.reshape(8, -1), f16=f16.reshape(8, -1))
+    # checkpoints stored in bf16 (TinyLlama's own) or f16: the reference divides absmax in the CHECKPOINT's dtype before
+    # it goes to f32 (tinyllama_to_gten.py:38-39,68-69), so the deltas -- and with them the quants -- differ from the
+    # f32 path.  The inputs below are `w` rounded to that dtype (stored here as the f32 values they hold).
+    for tag, dt in (("bf16", torch.bfloat16), ("f16src", torch.float16)):
+        ts = t.to(dt)
+        d8, q8 = q8q(ts.clone())
+        d4, q4 = q4q(ts.clone())
+        out[f"w_{tag}"] = ts.to(torch.float32).numpy()
+        out[f"q8_{tag}"] = np.concatenate([d8.numpy().view(np.uint8).reshape(-1, 2), q8.numpy().view(np.uint8).reshape(-1, 32)], axis=1).reshape(8, -1)
+        out[f"q4_{tag}"] = np.concatenate([d4.numpy().view(np.uint8).reshape(-1, 2), q4.numpy().reshape(-1, 16)], axis=1).reshape(8, -1)
+        out[f"f16_{tag}"] = ts.to(torch.float16).numpy().view(np.uint8).reshape(8, -1)
+    np.savez_compressed(os.path.join(HERE, "converter_pins.npz"), **out)
     print("converter_pins.npz", blocks8.shape, blocks4.shape)
 
 
@@ -293,9 +304,13 @@ def main():
     ap.add_argument("--skip-long", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-long", action="store_true", help="re-run just the long-context probe into the existing fixture")
+    ap.add_argument("--only-pins", action="store_true", help="just converter_pins.npz")
     ap.add_argument("--only-extra", action="store_true", help="just full_extra_golden.npz (full-size prompt processing; f16 / q8 long-context probes)")
     args = ap.parse_args()
     assert os.path.isdir(REFERENCE), "run this in the build container (needs /root/reference)"
+    if args.only_pins:
+        make_converter_pins()
+        return
     orc.build(ref=True)
     oracle = orc.load_oracle()
     refs = {"avx": orc.load_ref("avx"), "scalar": orc.load_ref("scalar")}

@@ -34,6 +34,36 @@ def test_quantizers_match_the_reference_converter_pins(conv):
     assert np.array_equal(conv.to_f16(w), g["f16"])
 
 
+@pytest.mark.parametrize("tag,src", [("bf16", "bf16"), ("f16src", "f16")])
+def test_quantizers_follow_the_checkpoint_dtype(conv, tag, src):
+    """a bf16 (TinyLlama's own) or f16 checkpoint: the reference forms absmax / qmax in THAT dtype, so deltas and quants
+    differ from the f32 path; pins from the reference converter run on bf16 / f16 tensors"""
+    g = np.load(os.path.join(G, "converter_pins.npz"))
+    w = g[f"w_{tag}"]
+    assert np.array_equal(conv.quantize_q8(w, src), g[f"q8_{tag}"])
+    assert np.array_equal(conv.quantize_q4(w, src), g[f"q4_{tag}"])
+    assert np.array_equal(conv.to_f16(w), g[f"f16_{tag}"])
+    assert not np.array_equal(conv.quantize_q8(w, "f32"), g[f"q8_{tag}"])       # the dtype matters
+    with pytest.raises(ValueError):
+        conv.quantize_q8(w, "f64")
+
+
+def test_bf16_checkpoint_file_is_read(conv, tmp_path):
+    torch = pytest.importorskip("torch")
+    from safetensors.torch import save_file
+    g = np.load(os.path.join(G, "converter_pins.npz"))
+    t = torch.from_numpy(g["w_bf16"].copy()).to(torch.bfloat16)
+    save_file({"model.embed_tokens.weight": t, "lm_head.weight": t.to(torch.float16), "model.norm.weight": t[0].to(torch.float32),
+               "bad": torch.zeros(4, dtype=torch.int32)}, str(tmp_path / "m.safetensors"))
+    get, n_layers = conv.open_checkpoint(str(tmp_path / "m.safetensors"))
+    w, src = get("model.embed_tokens.weight")
+    assert src == "bf16" and np.array_equal(w, g["w_bf16"])
+    assert np.array_equal(conv.quantize(w, "q4", src), g["q4_bf16"])
+    assert get("lm_head.weight")[1] == "f16" and get("model.norm.weight")[1] == "f32"
+    with pytest.raises(ValueError):
+        get("bad")
+
+
 def test_quantizers_match_the_oracle_on_random_and_degenerate_rows(conv, oracle):
     from helpers import F16, Q4, Q8
     r = np.random.default_rng(5)

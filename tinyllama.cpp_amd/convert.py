@@ -7,7 +7,13 @@ Counterpart of the reference's `tinyllama_to_gten.py` (behaviour restated, nothi
     0..15 into the high nibbles, 16..31 into the low nibbles; a zero block stores delta 0 and q 0
   * norm vectors stay fp16 in every mode; embedding and lm_head are quantized like any linear
 
-numpy only (plus `safetensors` to read a checkpoint); pinned byte for byte by tests/golden/converter_pins.npz
+Checkpoint dtype: the reference divides absmax by 127 (7) IN THE CHECKPOINT'S OWN DTYPE before the delta goes to f32
+(tinyllama_to_gten.py:38-39, 68-69), so for a bf16 checkpoint -- TinyLlama's own -- the f32 delta is a bf16 value, and
+the quants follow from it.  `quantize_q8 / quantize_q4(w, src=...)` reproduce that for src in ("f32", "bf16", "f16");
+`open_checkpoint` reads bf16 / f16 / f32 safetensors (through torch for bf16, which numpy cannot hold) and reports each
+tensor's dtype.  Other dtypes are refused.
+
+numpy only (plus `safetensors`, and torch for bf16 files, to read a checkpoint); pinned byte for byte by tests/golden/converter_pins.npz
 (tests/test_convert_cpu.py).  The GPU library repacks these blocks at load (gten_hip_pack_weight).
 
     python -m tinyllama.cpp_amd.convert <model.safetensors | checkpoint dir> out.q4.gten --dtype q4
@@ -34,28 +40,45 @@ def _blocks(w):
     return w.reshape(rows, cols // 32, 32), rows, cols // 32
 
 
-def _quants(blocks, qmax):
+SRC_DTYPES = ("f32", "bf16", "f16")
+
+
+def _round_to(x, src):
+    """f32 values rounded (to nearest even) to the checkpoint's dtype, returned as f32"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if src == "f32":
+        return x
+    if src == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    if src == "bf16":
+        u = x.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000          # round to nearest even on the upper 16 bits
+        return u.astype(np.uint32).view(np.float32)
+    raise ValueError(f"checkpoint dtype {src!r} not in {SRC_DTYPES}")
+
+
+def _quants(blocks, qmax, src="f32"):
     amax = np.abs(blocks).max(axis=2, keepdims=True)
-    delta = (amax / np.float32(qmax)).astype(np.float32)
+    delta = _round_to((amax / np.float32(qmax)).astype(np.float32), src)   # the division happens in the checkpoint's dtype
     scale = np.divide(np.float32(1.0), delta, out=np.zeros_like(delta), where=delta != 0)
     q = np.rint(blocks * scale).astype(np.int32)          # np.rint: half to even, like torch.round
     return q, delta.astype(np.float16)
 
 
-def quantize_q8(w):
+def quantize_q8(w, src="f32"):
     """[rows][cols] f32 -> [rows][cols/32 * 34] bytes: {f16 delta, int8 x 32} per block"""
     blocks, rows, nb = _blocks(w)
-    q, d16 = _quants(blocks, 127)
+    q, d16 = _quants(blocks, 127, src)
     out = np.empty((rows, nb, 34), np.uint8)
     out[:, :, :2] = d16.view(np.uint8).reshape(rows, nb, 2)
     out[:, :, 2:] = q.astype(np.int8).view(np.uint8)
     return out.reshape(rows, nb * 34)
 
 
-def quantize_q4(w):
+def quantize_q4(w, src="f32"):
     """[rows][cols] f32 -> [rows][cols/32 * 18] bytes: {f16 delta, 16 bytes: hi nibble = element j + 7, lo = element j + 16 + 7}"""
     blocks, rows, nb = _blocks(w)
-    q, d16 = _quants(blocks, 7)
+    q, d16 = _quants(blocks, 7, src)
     q = (q + 7).astype(np.uint8)
     out = np.empty((rows, nb, 18), np.uint8)
     out[:, :, :2] = d16.view(np.uint8).reshape(rows, nb, 2)
@@ -63,8 +86,10 @@ def quantize_q4(w):
     return out.reshape(rows, nb * 18)
 
 
-def quantize(w, dtype):
-    return {"f16": to_f16, "q8": quantize_q8, "q4": quantize_q4}[dtype](w)
+def quantize(w, dtype, src="f32"):
+    if dtype == "f16":
+        return to_f16(w)
+    return {"q8": quantize_q8, "q4": quantize_q4}[dtype](w, src)
 
 
 def tensor_names(n_layers):
@@ -80,7 +105,8 @@ def tensor_names(n_layers):
 
 
 def write_gten(path, get_tensor, n_layers, dtype, progress=None):
-    """get_tensor(name) -> 2-D (linear) or 1-D (norm) float array.  Returns the number of bytes written."""
+    """get_tensor(name) -> 2-D (linear) or 1-D (norm) float array, or a pair (array, checkpoint dtype in SRC_DTYPES).
+    Returns the number of bytes written."""
     if dtype not in DTYPES:
         raise ValueError(f"dtype {dtype!r} not in {DTYPES}")
     total = 0
@@ -88,11 +114,13 @@ def write_gten(path, get_tensor, n_layers, dtype, progress=None):
         f.write(struct.pack("<q", GTEN_MAGIC))
         total += 8
         for name, is_linear in tensor_names(n_layers):
-            w = np.asarray(get_tensor(name), dtype=np.float32)
+            got = get_tensor(name)
+            w, src = got if isinstance(got, tuple) else (got, "f32")
+            w = np.asarray(w, dtype=np.float32)
             if is_linear:
                 if w.ndim != 2:
                     raise ValueError(f"{name}: expected a matrix, got shape {w.shape}")
-                payload = quantize(w, dtype)
+                payload = quantize(w, dtype, src)
             else:
                 payload = to_f16(w.reshape(1, -1))
             raw = name.encode()
@@ -110,18 +138,28 @@ def write_gten(path, get_tensor, n_layers, dtype, progress=None):
 
 
 def open_checkpoint(src):
-    """name -> array accessor over one .safetensors file or a directory of shards"""
+    """name -> (f32 array, checkpoint dtype) accessor over one .safetensors file or a directory of shards"""
     from safetensors import safe_open
     files = [src] if os.path.isfile(src) else sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith(".safetensors"))
     if not files:
         raise FileNotFoundError(f"no .safetensors under {src}")
     handles = [safe_open(f, framework="np") for f in files]
-    index = {k: h for h in handles for k in h.keys()}
+    index = {k: (h, f) for h, f in zip(handles, files) for k in h.keys()}
+    pt_handles = {}
 
     def get(name):
         if name not in index:
             raise KeyError(f"{name} missing from the checkpoint")
-        return index[name].get_tensor(name)
+        h, f = index[name]
+        dt = h.get_slice(name).get_dtype()
+        if dt in ("F32", "F16"):
+            return np.asarray(h.get_tensor(name), dtype=np.float32), ("f32" if dt == "F32" else "f16")
+        if dt == "BF16":
+            import torch                       # numpy has no bf16: read through torch, hand on the exact f32 values
+            if f not in pt_handles:
+                pt_handles[f] = safe_open(f, framework="pt")
+            return pt_handles[f].get_tensor(name).to(torch.float32).numpy(), "bf16"
+        raise ValueError(f"{name}: checkpoint dtype {dt} is not supported (f32, f16 or bf16)")
 
     n_layers = 1 + max((int(k.split(".")[2]) for k in index if k.startswith("model.layers.")), default=-1)
     return get, n_layers

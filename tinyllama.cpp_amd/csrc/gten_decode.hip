@@ -3703,7 +3703,7 @@ int gten_hip_decoder_generate(gten_hip_decoder* dc, int n_first, int max_new, in
 // The same for the sequences of a multi-sequence decoder, each from its own position (continuous batching): sequence q
 // starts at step n_first[q]; one that produced `eos`, its max_new ids or a full context is PARKED (its step word stops
 // advancing: it recomputes the same row, which changes nothing) while the others go on.  out_host is [n_seq][max_new].
-int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, int max_new, int eos, int32_t* out_host, int* n_out)
+int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, const int* max_new_seq, int max_new, int eos, int32_t* out_host, int* n_out)
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && n_first && out_host && n_out && max_new >= 0, "decoder_generate_multi: bad arguments");
@@ -3716,7 +3716,8 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, in
     std::vector<char> live((size_t)S, 1);
     int n_live = 0;
     for (int q = 0; q < S; q++) {
-        last[q] = std::min(ctx, n_first[q] + max_new - 1);
+        const int room = max_new_seq ? std::min(std::max(max_new_seq[q], 0), max_new) : max_new;   // this sequence's own bound
+        last[q] = std::min(ctx, n_first[q] + room - 1);
         live[q] = last[q] >= n_first[q];
         st[q] = DecStep{n_first[q], live[q] ? 3 : 0};
         n_out[q] = 0;

@@ -120,6 +120,7 @@ class GtenHip:
         self._mul = _sig(L, "gten_hip_mul", ci, [vp, vp, vp, ci, sz, ci, ci, ci])
         self._add = _sig(L, "gten_hip_add", ci, [vp, vp, vp, ci, sz, ci, ci, ci])
         self._attn = _sig(L, "gten_hip_qkv_attn", ci, [vp, vp, vp, vp, ci, sz, sz, sz, ci, ci, ci, ci, ci])
+        self._prefill_exact = _sig(L, "gten_hip_set_prefill_exact", ci, [ci])
         self.initialised = False
 
     # -- runtime
@@ -149,6 +150,10 @@ class GtenHip:
 
     def stream(self):
         return self._stream()
+
+    def set_prefill_exact(self, on):
+        """prompt-sized W.x with quantized weights: exact form (scalar-build order, bit for bit) instead of the fast one"""
+        self._check(self._prefill_exact(1 if on else 0))
 
     def prof_enable(self, on):
         self._check(self._prof_enable(1 if on else 0))

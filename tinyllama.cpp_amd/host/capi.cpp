@@ -251,7 +251,7 @@ int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const i
 {
     if (!prompts || !n_prompt || !out || !n_total || max_tokens <= 0) return -1;
     const int S = b->batch->n_seq();
-    std::vector<int> n_first((size_t)S);
+    std::vector<int> n_first((size_t)S), room((size_t)S);
     int max_new = 0;
     for (int q = 0; q < S; q++) {
         const int P = n_prompt[q];
@@ -268,11 +268,14 @@ int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const i
         row[P] = best_i;                                          // (an eos here ends the sequence below)
         n_first[q] = P + 1;
         b->batch->decode_set_tokens(q, row, 0, P + 1);
-        max_new = std::max(max_new, max_tokens - (P + 1));
+        // this sequence's own room; none when the prompt's argmax is already eos (the sequence is then parked from the start
+        // instead of being decoded for the longest sequence's length)
+        room[(size_t)q] = (best_i == eos) ? 0 : max_tokens - (P + 1);
+        max_new = std::max(max_new, room[(size_t)q]);
     }
     std::vector<int32_t> gen((size_t)S * (size_t)std::max(max_new, 1));
     std::vector<int> n_out((size_t)S, 0);
-    b->batch->decode_generate(n_first.data(), max_new, eos, gen.data(), n_out.data());
+    b->batch->decode_generate(n_first.data(), max_new, eos, gen.data(), n_out.data(), room.data());
     for (int q = 0; q < S; q++) {
         int32_t* row = out + (size_t)q * max_tokens;
         int total = n_first[q];

@@ -352,10 +352,11 @@ public:
     }
     // greedy generation of every sequence with the sampler on the device (gten_hip_decoder_generate_multi): sequence q's
     // ids [0, n_first[q]) are set and its caches hold rows [0, n_first[q] - 1); out is [n_seq][max_new]
-    void decode_generate(const int* n_first, int max_new, int eos, int32_t* out, int* n_out)
+    // (max_new_seq: each sequence's own bound, may be null)
+    void decode_generate(const int* n_first, int max_new, int eos, int32_t* out, int* n_out, const int* max_new_seq = nullptr)
     {
         ensure_decoder();
-        GTEN_HIP_OK(gten_hip_decoder_generate_multi(dec_, n_first, max_new, eos, out, n_out));
+        GTEN_HIP_OK(gten_hip_decoder_generate_multi(dec_, n_first, max_new_seq, max_new, eos, out, n_out));
     }
     // asynchronous: row n[q]-1 of sequence q (continuous batching)
     void decode_step_ragged(const int* n_per_seq, bool use_graph)
