@@ -90,13 +90,31 @@ __device__ __forceinline__ void tile_scores(const QFrag& q, const uint8_t* __res
     }
 }
 
+// FAST (the default; gten_hip_set_prefill_exact(1) selects the exact form): p.V on the matrix cores.  The probabilities
+// -- still rounded to Q8 blocks along the context exactly as above -- are kept as f16 rows, a V sub-tile is staged
+// TRANSPOSED as f16 values [element][position], and one v_mfma_f32_16x16x32_f16 adds 32 positions of 16 rows x 16
+// elements inside the matrix core: 16 MFMAs per wave and 256-position tile instead of ~2700 VALU instructions per
+// thread.  Each operand element carries one fp16 rounding (relative 2^-11) and the sum follows the core's order, not
+// k_attn's four stride-4 accumulators: outputs agree with the exact form to f32 / fp16 rounding noise (inside the
+// model band: tests/test_prefill_gpu.py against the reference's full-size prompt goldens), not byte for byte.
+constexpr int AT_PHPITCH = AT_TILE + 8;      // halfs per probability row (528 bytes: 16 rows x 16-byte reads cover all banks)
+constexpr int AT_VTPITCH = AT_VSUB + 8;      // halfs per element row of the transposed V sub-tile (144 bytes)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_tiled_q8(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
                                                        const uint8_t* __restrict__ v, uint8_t* __restrict__ out,
                                                        size_t q_pitch, size_t kv_pitch, size_t out_pitch,
                                                        int n_heads, int n_kv, int n, int start_pos)
 {
-    __shared__ __attribute__((aligned(16))) float s_p[AT_ROWS * AT_PPITCH];
-    __shared__ __attribute__((aligned(16))) float s_v[AT_VSUB * 64];
+    constexpr int P_BYTES = FAST ? AT_ROWS * AT_PHPITCH * 2 : AT_ROWS * AT_PPITCH * 4;
+    constexpr int V_BYTES = FAST ? 64 * AT_VTPITCH * 2 + AT_ROWS * 64 * 4 : AT_VSUB * 64 * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[P_BYTES + V_BYTES];
+    float* s_p = (float*)s_mem;                                 // exact: f32 probability rows
+    float* s_v = (float*)(s_mem + P_BYTES);                     // exact: f32 V sub-tile [position][element]
+    _Float16* s_ph = (_Float16*)s_mem;                          // fast: f16 probability rows
+    _Float16* s_vt = (_Float16*)(s_mem + P_BYTES);              // fast: f16 V sub-tile, transposed [element][position]
+    float* s_o = (float*)(s_mem + P_BYTES + 64 * AT_VTPITCH * 2);   // fast: the output tile [row][element] on its way to the epilogue
     __shared__ float s_red[4 * AT_ROWS];
     __shared__ float s_row[AT_ROWS];
 
@@ -216,6 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int rr = 0; rr < 4; rr++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[rr][j] = (v2f){0.f, 0.f};
+    v4f macc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // fast: [row tile], rows 16 rt + 4 lq + i, element 16 w + lc
 
     for (int t = 0; t < ntile; t++) {
         float p[2][4][4];
@@ -250,7 +269,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const float x = p[rg][2 * bp + u][i];
-                        s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * (2 * bp + u) + lc] = (float)q8_round(x, sc.scale) * sc.ddeq;
+                        const float pq = (float)q8_round(x, sc.scale) * sc.ddeq;
+                        if (FAST) s_ph[(16 * rg + 4 * lq + i) * AT_PHPITCH + 64 * w + 16 * (2 * bp + u) + lc] = (_Float16)pq;
+                        else s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * (2 * bp + u) + lc] = pq;
                     }
                 }
         __syncthreads();
@@ -264,16 +285,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const uint8_t* vs_ = vbase + (size_t)min(c0 + pos, n - 1) * kv_pitch;
                 const U4 raw = *(const U4*)(vs_ + 2 + 34 * b + 16 * (qtr & 1));
                 const float d = h2f(*(const uint16_t*)(vs_ + 34 * b));
-                float* dst = s_v + pos * 64 + 16 * qtr;
+                if (FAST) {
+                    // the sub-tile transposed, as f16 values: element 16 qtr + 4 kk + j of this position
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    v4f o4;
+                    for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) o4[j] = (float)(int8_t)(raw.v[kk] >> (8 * j)) * d;
-                    *(v4f*)(dst + 4 * kk) = o4;
+                        for (int j = 0; j < 4; j++)
+                            s_vt[(16 * qtr + 4 * kk + j) * AT_VTPITCH + pos] = (_Float16)((float)(int8_t)(raw.v[kk] >> (8 * j)) * d);
+                } else {
+                    float* dst = s_v + pos * 64 + 16 * qtr;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        v4f o4;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) o4[j] = (float)(int8_t)(raw.v[kk] >> (8 * j)) * d;
+                        *(v4f*)(dst + 4 * kk) = o4;
+                    }
                 }
             }
             __syncthreads();
+            if (FAST) {
+                // wave w: elements 16 w .. 16 w + 15 of both 16-row tiles; 32 positions per matrix instruction
+                // (positions past r_last meet p = 0; their V rows are clamped reads of real rows)
+#pragma unroll
+                for (int ks = 0; ks < AT_VSUB / 32; ks++) {
+                    const h8 bv = *(const h8*)(s_vt + (16 * w + lc) * AT_VTPITCH + 32 * ks + 8 * lq);
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; rt2++) {
+                        const h8 av = *(const h8*)(s_ph + (16 * rt2 + lc) * AT_PHPITCH + vs * AT_VSUB + 32 * ks + 8 * lq);
+                        macc[rt2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, macc[rt2], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
             const int lim = min(AT_VSUB, r_last - c0 + 1);       // positions past r_last carry p = 0 for every row
 #pragma unroll 4
             for (int c4 = 0; c4 < lim; c4 += 4) {
@@ -293,11 +338,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 
     // ---- output rows in the activation dtype (store_row, gten/ops.h:73-96): a Q8 block = 16 lanes x 2 elements
+    if (FAST) {
+#pragma unroll
+        for (int rt2 = 0; rt2 < 2; rt2++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) s_o[(16 * rt2 + 4 * lq + i) * 64 + 16 * w + lc] = macc[rt2][i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         v2f o = (v2f){0.f, 0.f};
+        if (FAST) {
+            o = *(const v2f*)(s_o + (4 * rq + rr) * 64 + 2 * ep);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) o += acc[rr][j];
+            for (int j = 0; j < 4; j++) o += acc[rr][j];
+        }
         const float amax = row16_max(fmaxf(fabsf(o.x), fabsf(o.y)));
         const Q8Scale sc = q8_scale_from_absmax(amax);
         const int row = r0 + 4 * rq + rr;
@@ -537,7 +593,11 @@ int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* ou
 {
     const int rows = n - start_pos;
     const dim3 grid(n_heads, (rows + AT_ROWS - 1) / AT_ROWS);
-    GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_q8, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
-               (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+    if (gtr::prefill_exact())
+        GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_q8<false>, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
+                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+    else
+        GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_q8<true>, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
+                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
     return 0;
 }

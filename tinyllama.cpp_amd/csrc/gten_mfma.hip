@@ -534,6 +534,8 @@ static int launch_wt(const void* x, size_t x_pitch, const void* w, void* out, in
 #undef MF_GO
 }
 
+bool gtr::prefill_exact() { return g_prefill_exact; }
+
 extern "C" int gten_hip_set_prefill_exact(int on)
 {
     g_prefill_exact = on != 0;
