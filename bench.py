@@ -446,10 +446,10 @@ def worker(args, rank, local_rank, world, dist):
             step(n_of(W + K - P + i, total))
         prof = hip.prof_read()
         hip.prof_enable(False)
-        fam, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
         wb = weight_bytes_per_elt(args.mode)
         act_b = 2.0 if args.mode == "f16" else 34 / 32
         lin = {name: (dout * din * wb + din * act_b + dout * act_b, cnt) for name, dout, din, cnt in linear_shapes()}
+        n_att = N_CTX - K // 2 if total <= N_CTX - 1 else N_CTX - window // 2          # context length in the middle of the timed window
         per_family_bytes = {
             "matmul_2d": sum(b * c for b, c in lin.values()),
             "decode_gemv_qkv": (lin["q"][0] + lin["k"][0] + lin["v"][0]) * 22,
@@ -457,26 +457,29 @@ def worker(args, rank, local_rank, world, dist):
             "decode_gemv_gateup": (lin["gate"][0] + lin["up"][0]) * 22,
             "decode_gemv_down": lin["down"][0] * 22,
             "decode_gemv_head": lin["lm_head"][0],
+            # the one-launch attention reads the K and the V history of its block once: KV(n) of SURVEY 8(d) / 22 blocks
+            "decode_attn_score": 2 * 256 * act_b * n_att * 22,
         }
-        per_launch = None
-        if fam in per_family_bytes:
-            per_launch = per_family_bytes[fam] / (launches / P)
-        # Per-launch event brackets (above) rank the kernels but carry ~2 us of packet handling each.
-        # The dominant kernel's duration is therefore timed on its own: two HIP events on the
-        # library's stream around 20 replays of a graph holding ONLY that family's launches.
-        bracket_us = ms * 1e3 / launches
-        avg_us, per_replay = bracket_us, launches // P
+        # the same isolated timing for every family of the step: two HIP events on the library's stream around 20
+        # replays of a graph holding ONLY that family's launches (per-launch event brackets, above, carry ~2.5 us of
+        # packet handling each and only rank the kernels)
+        family_us, family_n = {}, {}
         if fused and use_graph:              # (--no-graph runs are counter collections: no graph is captured at all)
-            avg_us, per_replay = model.time_family(hip.prof_family_index(fam), N_CTX, 20)
-        # the same isolated timing for every family of the step (launches of ONE family replayed back to back)
-        family_us = {}
-        if fused and use_graph:
             for f2 in prof:
                 try:
-                    u2, _ = model.time_family(hip.prof_family_index(f2), N_CTX, 20)
-                    family_us[f2] = round(u2, 3)
+                    u2, n2 = model.time_family(hip.prof_family_index(f2), N_CTX, 20)
+                    family_us[f2], family_n[f2] = round(u2, 3), n2
                 except Exception:
                     pass
+        # dominant kernel = the family with the largest share of the step (isolated time x launches) among those with
+        # algorithmic bytes
+        share = {f: family_us[f] * family_n[f] for f in family_us if f in per_family_bytes} or \
+                {f: v[1] for f, v in prof.items() if f in per_family_bytes}
+        fam = max(share, key=share.get)
+        launches, ms = prof[fam]
+        per_launch = per_family_bytes[fam] / (launches / P)
+        bracket_us = ms * 1e3 / launches
+        avg_us, per_replay = (family_us[fam], family_n[fam]) if fam in family_us else (bracket_us, launches // P)
         achieved = (per_launch / (avg_us * 1e-6) / 1e9) if per_launch else None
         step_ms = elapsed / K * 1e3
         roofline = {"bound": "hbm", "kernel": fam, "achieved": round(achieved, 1) if achieved else None,

@@ -1,0 +1,30 @@
+"""not gpu: the host-side C++ (tokenizer, synthetic weights + quantizers, .gten writer; host/capi.cpp and the headers it
+pulls in) compiled with -fsanitize=address,undefined and run on the CPU (tests/host_sanitize.cpp).  No GPU call is made:
+the binary links libgten_hip.so only because capi.cpp references it."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_code_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    pkg.build.build_hip()
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_sanitize")
+    csrc = os.path.join(ROOT, "tinyllama.cpp_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tinyllama.cpp_amd"),
+           os.path.join(ROOT, "tests", "host_sanitize.cpp"), os.path.join(ROOT, "tinyllama.cpp_amd", "host", "capi.cpp"),
+           "-o", exe, "-L" + csrc, "-lgten_hip", "-Wl,-rpath," + csrc]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
+    assert "host_sanitize ok" in r.stdout

@@ -2793,8 +2793,7 @@ static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
     const int grp = t.n_heads / t.n_kv;
     const char* e = std::getenv("GTEN_HIP_ATTN_PER_HEAD");      // =1: the per-head kernels (comparison / tests)
     const bool off = e && e[0] == '1';
-    const char* m = std::getenv("GTEN_HIP_ATTN_GROUPED_MIN");   // fewest sequences that take the grouped kernels
-    const int min_seq = (m && atoi(m) > 1) ? atoi(m) : 8;        // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
+    const int min_seq = 8;                                       // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
     if (t.adtype == GTEN_F16 && n_seq < 16) return false;        // f16 below 16 sequences: the per-head kernels (one launch, k_dec_attn_one64)
     return !off && n_seq >= min_seq && (t.adtype == GTEN_Q8 || t.adtype == GTEN_F16) && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
 }
@@ -2815,11 +2814,8 @@ static bool grouped_one_pass(const AttnArgs& t, int n_seq)
     // 8 sequences: one launch (per sequence the bytes of single-sequence decode).  From 16 sequences up the two
     // launches measured FASTER than the merged kernel (64 sequences, ctx 2048: 22.3 + 25.8 us against 62.4 us per
     // block -- the merged workgroup holds K rows, V chunk and every head's scores at once: 104 VGPRs, 27 KB of LDS,
-    // 4 workgroups per CU through five barriers each), so the wide path keeps the two-launch pair; GTEN_HIP_ATTN_WIDE_ONE=1
-    // selects the merged kernel there (tests compare both).
-    const char* e = std::getenv("GTEN_HIP_ATTN_WIDE_ONE");
-    const bool wide_one = e && e[0] == '1';
-    return attention_one_pass(t.d_head) && t.adtype == GTEN_Q8 && (n_seq <= 8 || wide_one);
+    // 4 workgroups per CU through five barriers each), so the wide path keeps the two-launch pair.
+    return attention_one_pass(t.d_head) && t.adtype == GTEN_Q8 && n_seq <= 8;
 }
 
 template <int GRP, int ADT>
@@ -2831,10 +2827,7 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
         constexpr size_t GP = (GRP + 1) / 2;
         const size_t smem = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 16 +
                             (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4) + 2 * GP * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4;
-        const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
-        const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
-        if (exact) DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_one_g<GRP, true, ADT>), grid, dim3(256), smem, t);
-        else DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_one_g<GRP, false, ADT>), grid, dim3(256), smem, t);
+        DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_one_g<GRP, true, ADT>), grid, dim3(256), smem, t);      // (<= 8 sequences: exact p.V terms)
         return 0;
     }
     const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64 +
@@ -2847,8 +2840,7 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, true, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, false, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
     }
-    const char* mse = std::getenv("GTEN_HIP_F16_MFMA_SCORES");
-    if (ADT == GTEN_F16 && n_seq >= 16 && !(mse && mse[0] == '0')) {
+    if (ADT == GTEN_F16 && n_seq >= 16) {
         // 16 sequences and up: the scores of a group as a matrix product on the matrix cores (k_dec_attn_score_gm_f16)
         const size_t smem_m = (size_t)(128 + 16) * 4 + 128 + 128 + 64 + 16 + (size_t)17 * 64 * 2 + 64;
         DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_score_gm_f16<GRP>), grid, dim3(256), smem_m, t);

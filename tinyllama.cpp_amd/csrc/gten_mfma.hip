@@ -508,21 +508,10 @@ static int launch_wt(const void* x, size_t x_pitch, const void* w, void* out, in
 {
     const int rows = n - start_pos;
     auto wgs = [&](int bm, int bn) { return ((d_out + bn - 1) / bn) * ((rows + bm - 1) / bm); };
-    static const int forced = [] { const char* e = std::getenv("GTEN_HIP_MFMA_CFG"); return e ? atoi(e) : 0; }();   // tuning aid: 44 | 42 | 24 | 22 | 12
 #define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos)
     // (exact form, measured at 2048 rows, q4, W.x total: <2,4> 14.2 ms | <2,2> 15.3 | <4,2> 19.3 | <4,4> 26.2 | <2,4> with
     //  2-block stages 15.3: the 4-row-tile variants fit one workgroup per CU only, and occupancy matters more than the
     //  amortised nibble expansion once the kernel is VALU-bound at 2 waves per SIMD)
-    if constexpr (FAST) if (forced == 44) MF_GO(4, 4);       // (the exact form's 4 x 4 tile does not fit the register file)
-    if constexpr (FAST) {
-        // two-block stages: half the LDS per workgroup, i.e. two 128 x 128 workgroups per CU
-        if (forced == 442) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-        if (forced == 242) return launch_cfg<WT, 2, 4, FAST, 2>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-    }
-    if (forced == 42) MF_GO(4, 2);
-    if (forced == 24) MF_GO(2, 4);
-    if (forced == 22) MF_GO(2, 2);
-    if (forced == 12) MF_GO(1, 2);
     if constexpr (FAST) {
         // 128 x 128 outputs per workgroup on two-block stages (two workgroups per CU): 2048 rows, q4, W.x total 10.7 ms against
         // 11.6 for <2,4> on four-block stages and 12.5 for <4,4> on four-block stages (one workgroup per CU)
