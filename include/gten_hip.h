@@ -185,6 +185,10 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dec, int seq, const int32_
 /* asynchronous: computes row n-1, logits and their argmax.  use_graph != 0
  * replays the captured hipGraph (captured on first use). */
 int gten_hip_decoder_step(gten_hip_decoder* dec, int n, int use_graph);
+/* `count` consecutive steps n_first, n_first + 1, ... (ids already set): asynchronous and free-running -- the position lives
+ * on the device and each step's last kernel advances it -- replayed four steps per hipGraph launch (the idle time between
+ * two graph replays is then paid once per four tokens).  Same results as `count` calls of gten_hip_decoder_step. */
+int gten_hip_decoder_steps(gten_hip_decoder* dec, int n_first, int count, int use_graph);
 /* Greedy generation with the sampler on the device (tinyllama.cpp:395-440 without the 128 KB logits copy and the host
  * argmax per token): token ids [0, n_first) must be set (gten_hip_decoder_set_tokens) and the caches hold rows
  * [0, n_first - 1).  Steps n_first, n_first + 1, ... run back to back, each argmax (strict >, first maximum wins) becoming

@@ -77,6 +77,7 @@ int gten_host_model_set_fast_decode(gten_host_model* m, int on);
  * [0, n) of the caches and leaves logits + argmax on the device. */
 int gten_host_model_decode_begin(gten_host_model* m, const int32_t* tokens, int count);
 int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph);          /* asynchronous */
+int  gten_host_model_decode_steps(gten_host_model* m, int n_first, int count, int use_graph);  /* asynchronous: steps n_first .. n_first + count - 1, four per graph replay */
 int gten_host_model_decode_result(gten_host_model* m, int n, int32_t* argmax_out);  /* waits */
 
 /* ---- several sequences on one GPU sharing one copy of the weights.
@@ -108,6 +109,7 @@ int  gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int
                            int max_tokens, int eos, int slice, int max_new, int32_t* out, int32_t* n_total, double* stats);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
+int  gten_host_batch_decode_steps(gten_host_batch* b, int n_first, int count, int use_graph);   /* asynchronous: count consecutive steps, four per graph replay */
 int  gten_host_batch_decode_step_ragged(gten_host_batch* b, const int32_t* n_per_seq, int use_graph);   /* sequence q at its own n */
 int  gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out); /* waits */
 int  gten_host_batch_logits(gten_host_batch* b, int seq, float* logits_out);                /* waits; f32[n_vocab] */

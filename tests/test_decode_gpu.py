@@ -190,3 +190,42 @@ def test_one_pass_attention_against_the_two_launch_form(hip, oracle, name, wd, a
         check_logits(name, la, want, float(want.std()))
         check_logits(name, lb, want, float(want.std()))
     om.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_steps_call_equals_single_steps(hip, name, wd, ad):
+    """gten_hip_decoder_steps (count consecutive steps, four per hipGraph replay, the position advanced on the device) leaves
+    the same argmax ids, logits and K/V rows as the same steps one call at a time; counts that are not multiples of four,
+    a start in the middle, eager mode, and the multi-sequence decoder"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 404, i) for i in range(len(cfg.weight_shapes()))]
+    toks = host.synthetic_tokens(300, seed=21, n_vocab=cfg.n_vocab)
+    a, b = host.model(cfg), host.model(cfg)
+    for i, w in enumerate(weights):
+        a.set_weight(i, w); b.set_weight(i, w)
+    a.decode_begin(toks); b.decode_begin(toks)
+    for n in range(1, 301):
+        a.decode_step(n, True)
+    b.decode_steps(1, 7, True)           # 4 + 3
+    b.decode_steps(8, 1, True)
+    b.decode_steps(9, 250, True)
+    b.decode_steps(259, 10, False)       # eager
+    b.decode_steps(269, 32, True)
+    for n in (1, 7, 8, 9, 12, 255, 256, 257, 258, 268, 269, 300):
+        assert a.decode_result(n) == b.decode_result(n), (name, n)
+    assert np.array_equal(a.logits(toks[:300], 299), b.logits(toks[:300], 299))
+    a.close(); b.close()
+    ba, bb = host.batch(cfg, 4), host.batch(cfg, 4)
+    for i, w in enumerate(weights):
+        ba.set_weight(i, w); bb.set_weight(i, w)
+    streams = [host.synthetic_tokens(60, seed=60 + q, n_vocab=cfg.n_vocab) for q in range(4)]
+    for q in range(4):
+        ba.decode_begin(q, streams[q]); bb.decode_begin(q, streams[q])
+    for n in range(1, 61):
+        ba.decode_step(n, True)
+    bb.decode_steps(1, 60, True)
+    for q in range(4):
+        assert ba.decode_result(q, 60) == bb.decode_result(q, 60) and np.array_equal(ba.logits(q), bb.logits(q))
+    ba.close(); bb.close()

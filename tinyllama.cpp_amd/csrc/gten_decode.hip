@@ -2783,6 +2783,8 @@ struct gten_hip_decoder {
     int n_chunks = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_k = nullptr;       // DEC_GRAPH_STEPS consecutive steps in one graph (the position lives on the device and
+    hipGraphExec_t exec_k = nullptr;    // the last kernel of a step advances it): one replay per DEC_GRAPH_STEPS tokens
     const float2* rope = nullptr;
     float2* rope_now = nullptr;       // [n_seq][d_head / 2], see Gemv8Args
 };
@@ -3569,6 +3571,8 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     GTR_CHECK(hipStreamSynchronize(stream()));
     if (dc->exec) hipGraphExecDestroy(dc->exec);
     if (dc->graph) hipGraphDestroy(dc->graph);
+    if (dc->exec_k) hipGraphExecDestroy(dc->exec_k);
+    if (dc->graph_k) hipGraphDestroy(dc->graph_k);
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
@@ -3593,6 +3597,34 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t
                     tokens_host[i], first + i, dc->d.n_vocab);
     GTR_CHECK(hipMemcpyAsync(dc->tokens + (size_t)seq * (dc->d.max_ctx + 1) + first, tokens_host, (size_t)count * 4, hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
+    return 0;
+}
+
+// Consecutive free-running steps replay a graph that holds DEC_GRAPH_STEPS of them: between two graph replays the
+// command processor idles for several microseconds (8.6 us between a step's last kernel and the next step's first one
+// in the rocprofv3 kernel trace, profiles/r02_*), i.e. ~1.5 % of a batch-1 step; four steps per replay pay it once.
+#define DEC_GRAPH_STEPS 4
+static int run_step(gten_hip_decoder* dc, int use_graph);
+static int run_steps_free(gten_hip_decoder* dc, int count)
+{
+    if (prof_on()) { for (int i = 0; i < count; i++) if (int rc = run_step(dc, 0)) return rc; return 0; }
+    while (count >= DEC_GRAPH_STEPS) {
+        if (!dc->exec_k) {
+            GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
+            int rc = 0;
+            for (int i = 0; i < DEC_GRAPH_STEPS && !rc; i++) rc = enqueue(dc);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(stream(), &g);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            GTR_CHECK(e);
+            dc->graph_k = g;
+            GTR_CHECK(hipGraphInstantiate(&dc->exec_k, dc->graph_k, nullptr, nullptr, 0));
+        }
+        GTR_CHECK(hipGraphLaunch(dc->exec_k, stream()));
+        count -= DEC_GRAPH_STEPS;
+    }
+    for (int i = 0; i < count; i++)
+        if (int rc = run_step(dc, 1)) return rc;
     return 0;
 }
 
@@ -3629,6 +3661,26 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
     dc->dev_ns.clear();
     dc->slots.clear();
     return run_step(dc, use_graph);
+}
+
+// `count` consecutive steps n_first, n_first + 1, ... of every sequence (teacher-forced ids already on the device):
+// asynchronous, free-running (each step's last kernel advances the position), DEC_GRAPH_STEPS steps per graph replay.
+int gten_hip_decoder_steps(gten_hip_decoder* dc, int n_first, int count, int use_graph)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && count >= 0 && n_first >= 1 && n_first + count - 1 <= dc->d.max_ctx, "decoder_steps: steps [%d, %d) outside [1, %d]",
+                n_first, n_first + count, dc ? dc->d.max_ctx : 0);
+    if (count == 0) return 0;
+    if (dc->dev_n != n_first || !dc->dev_ns.empty()) {
+        std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n_first, 1});
+        GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipStreamSynchronize(stream()));
+    }
+    dc->dev_n = n_first + count;
+    dc->dev_ns.clear();
+    dc->slots.clear();
+    if (!use_graph) { for (int i = 0; i < count; i++) if (int rc = run_step(dc, 0)) return rc; return 0; }
+    return run_steps_free(dc, count);
 }
 
 // Sequences at DIFFERENT positions (continuous batching): sequence q decodes row n[q] - 1.  Every kernel of the
@@ -3676,8 +3728,7 @@ int gten_hip_decoder_generate(gten_hip_decoder* dc, int n_first, int max_new, in
     std::vector<int32_t> ids(GEN_SLICE);
     for (int n = n_first; n <= last;) {
         const int cnt = std::min(GEN_SLICE, last - n + 1);
-        for (int i = 0; i < cnt; i++)
-            if (int rc = run_step(dc, 1)) return rc;
+        if (int rc = run_steps_free(dc, cnt)) return rc;
         GTR_CHECK(hipMemcpyAsync(ids.data(), dc->result + n, (size_t)cnt * 4, hipMemcpyDeviceToHost, stream()));
         GTR_CHECK(hipStreamSynchronize(stream()));
         bool stop = false;
@@ -3724,8 +3775,7 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, co
     while (n_live > 0) {
         int cnt = GEN_SLICE;
         for (int q = 0; q < S; q++) if (live[q]) cnt = std::min(cnt, last[q] - cur[q] + 1);   // nobody runs past its last step
-        for (int i = 0; i < cnt; i++)
-            if (int rc = run_step(dc, 1)) return rc;
+        if (int rc = run_steps_free(dc, cnt)) return rc;
         GTR_CHECK(hipStreamSynchronize(stream()));
         for (int q = 0; q < S; q++) {
             if (!live[q]) continue;
@@ -3793,8 +3843,7 @@ int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
     if (int rc = slots_view(dc)) return rc;
     for (const DecStep& s : dc->slots)
         GTR_REQUIRE(!(s.advance & 1) || s.n + steps - 1 <= dc->d.max_ctx, "decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n, dc->d.max_ctx);
-    for (int i = 0; i < steps; i++)
-        if (int rc = run_step(dc, 1)) return rc;
+    if (int rc = run_steps_free(dc, steps)) return rc;
     for (DecStep& s : dc->slots)
         if (s.advance & 1) s.n += steps;          // (a slot that reaches max_ctx + 1 has to be parked or restarted before the next run)
     return 0;

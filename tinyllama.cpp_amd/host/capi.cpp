@@ -162,6 +162,12 @@ int gten_host_model_decode_step(gten_host_model* m, int n, int use_graph)
     return 0;
 }
 
+int gten_host_model_decode_steps(gten_host_model* m, int n_first, int count, int use_graph)
+{
+    m->model->decode_steps(n_first, count, use_graph != 0);
+    return 0;
+}
+
 int gten_host_model_time_family(gten_host_model* m, int family, int n, int reps, double* avg_us, int* launches)
 {
     if (!avg_us) return -1;
@@ -231,6 +237,12 @@ int gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph)
 {
     if (n < 1 || n > b->cfg.max_ctx) return -1;
     b->batch->decode_step(n, use_graph != 0);
+    return 0;
+}
+
+int gten_host_batch_decode_steps(gten_host_batch* b, int n_first, int count, int use_graph)
+{
+    b->batch->decode_steps(n_first, count, use_graph != 0);
     return 0;
 }
 

@@ -98,6 +98,12 @@ public:
         ensure_decoder();
         GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
     }
+    // asynchronous: `count` consecutive rows n_first - 1, n_first, ... (ids on the device), four steps per graph replay
+    void decode_steps(int n_first, int count, bool use_graph)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_steps(dec_, n_first, count, use_graph ? 1 : 0));
+    }
     // device pointers of this model's weights / logits buffer for a decoder (shared code with TinyLlamaBatch)
     void describe(gten_hip_decoder_desc* d, std::vector<gten_hip_layer_ptrs>* L)
     {
@@ -349,6 +355,11 @@ public:
     {
         ensure_decoder();
         GTEN_HIP_OK(gten_hip_decoder_step(dec_, n, use_graph ? 1 : 0));
+    }
+    void decode_steps(int n_first, int count, bool use_graph)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_steps(dec_, n_first, count, use_graph ? 1 : 0));
     }
     // greedy generation of every sequence with the sampler on the device (gten_hip_decoder_generate_multi): sequence q's
     // ids [0, n_first[q]) are set and its caches hold rows [0, n_first[q] - 1); out is [n_seq][max_new]

@@ -36,7 +36,7 @@ class GtenHost:
         "gten_host_model_load_synthetic", "gten_host_model_logits", "gten_host_model_greedy", "gten_host_model_generate",
         "gten_host_tokenizer_create", "gten_host_tokenizer_free", "gten_host_tokenizer_encode", "gten_host_tokenizer_decode",
         "gten_host_synth_weight", "gten_host_write_gten", "gten_host_synthetic_tokens",
-        "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step",
+        "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step", "gten_host_model_decode_steps", "gten_host_batch_decode_steps",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
         "gten_host_batch_prefill", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
@@ -69,6 +69,8 @@ class GtenHost:
         self._setfast = _sig(L, "gten_host_model_set_fast_decode", ci, [vp, ci])
         self._dbegin = _sig(L, "gten_host_model_decode_begin", ci, [vp, vp, ci])
         self._dstep = _sig(L, "gten_host_model_decode_step", ci, [vp, ci, ci])
+        self._dsteps = _sig(L, "gten_host_model_decode_steps", ci, [vp, ci, ci, ci])
+        self._bsteps = _sig(L, "gten_host_batch_decode_steps", ci, [vp, ci, ci, ci])
         self._dresult = _sig(L, "gten_host_model_decode_result", ci, [vp, ci, C.POINTER(C.c_int32)])
         self._timefam = _sig(L, "gten_host_model_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
         self._bcreate = _sig(L, "gten_host_batch_create", vp, [cfgp, ci])
@@ -208,6 +210,12 @@ class HostModel:
         if rc:
             raise GtenHipError(f"decode_step({n}) rc={rc}")
 
+    def decode_steps(self, n_first, count, use_graph=True):
+        """asynchronous: steps n_first .. n_first + count - 1 (ids from decode_begin), four steps per graph replay"""
+        rc = self.host._dsteps(self.h, n_first, count, 1 if use_graph else 0)
+        if rc:
+            raise GtenHipError(f"decode_steps({n_first}, {count}) rc={rc}")
+
     def decode_result(self, n):
         out = C.c_int32(-1)
         rc = self.host._dresult(self.h, n, C.byref(out))
@@ -283,6 +291,9 @@ class HostBatch:
 
     def decode_step(self, n, use_graph=True):
         self._ck(self.host._bstep(self.h, n, 1 if use_graph else 0), f"batch_decode_step({n})")
+
+    def decode_steps(self, n_first, count, use_graph=True):
+        self._ck(self.host._bsteps(self.h, n_first, count, 1 if use_graph else 0), f"batch_decode_steps({n_first}, {count})")
 
     def decode_step_ragged(self, ns, use_graph=True):
         """sequence q decodes row ns[q] - 1 (continuous batching)"""
