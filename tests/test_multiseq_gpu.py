@@ -149,7 +149,7 @@ def test_batch_generation_on_device_equals_single_sequence_generation(hip, name,
 def test_wide_batch_k_split_planes_agree_with_single_plane(hip, monkeypatch):
     """k_dec_mmv splits K over two workgroups per feature tile and the consumers add the two planes of partial sums
     (default); GTEN_HIP_MMV_KSPLIT=1 keeps one workgroup and one plane.  Same block sums, one more f32 association:
-    the logits of both runs agree to summation-order noise and the greedy ids are equal."""
+    the logits of both runs agree inside the model band and the greedy ids are equal where the margin is clear."""
     from helpers import Q4, Q8
     pkg = load_package()
     host = pkg.load_host()
@@ -169,9 +169,11 @@ def test_wide_batch_k_split_planes_agree_with_single_plane(hip, monkeypatch):
             batch.decode_step(n, True)
         runs.append([(batch.decode_result(q, N), batch.logits(q).copy()) for q in range(n_seq)])
         batch.close()
+    from test_model_gpu import check_logits
     for (ra, la), (rb, lb) in zip(*runs):
-        scale = float(np.abs(la).max())
-        assert float(np.abs(la - lb).max()) <= 2e-2 * max(scale, 1.0)
+        # one more f32 association in every W.x: a rounding flip of a Q8 activation moves logits by percents of their spread;
+        # the yardstick is the model band, as everywhere on the wide path
+        check_logits("q4", la, lb, float(lb.std()))
         top2 = np.sort(la)[-2:]
         if top2[1] - top2[0] > 0.05 * float(la.std()):
             assert ra == rb

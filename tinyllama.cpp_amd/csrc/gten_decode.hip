@@ -2705,6 +2705,275 @@ __global__ __launch_bounds__(256) void k_dec_attn_one_g(const AttnArgs a0)
     }
 }
 
+// ---- 16-64 sequences, Q8 activations: the whole attention of a (sequence, chunk, kv head) in ONE launch ON THE MATRIX CORES.
+//
+// The VALU pair above spends ~1900 instructions per thread on a chunk (scores 8 heads x 17 dot4, exponentials and Q8
+// roundings per (head, position), 2 VALU operations per p.V term); merged as it stands it lost to the pair (occupancy,
+// DESIGN.md 3.3).  Here the two contractions are matrix instructions and a workgroup needs ~1000 instructions per thread:
+//   * K and V rows are loaded row-per-thread (17 dwords), re-aligned in registers (the quants of block 0 straddle the
+//     dwords by two bytes) and parked in LDS as [position][64 quants | d0 d1 | pad] = 72-byte rows;
+//   * scores: v_mfma_i32_16x16x32_i8, A = the group's head vectors (rows 8..15 zero), B = 16 positions of K; one
+//     instruction per (16 positions, quant block) gives the exact integer block dots, scaled dq dk as the scalar code;
+//   * chunk-local softmax (k_dec_attn_one64's scheme, hardware exponential), probabilities rounded to Q8 blocks of 32
+//     along the context exactly as the reference stores them;
+//   * p.V: v_mfma_f32_16x16x32_f16 with A = f16(p_q8 * dv[position]) -- the V row's block delta folded into the
+//     probability, one fp16 rounding -- and B = the V quants as exact f16 integers: 8 matrix instructions per wave.
+// The consumer joins the chunks with PRO_ATTW.  Numerics: the wide path's (model band; tests/test_multiseq_oracle_gpu.py
+// holds every slot to the oracle and to the reference's goldens), not the byte-exact 8-sequence path's.
+typedef int att_v4i __attribute__((ext_vector_type(4)));
+
+// (Measured and not kept: the same kernel PERSISTENT -- at most 4 workgroups per CU walking the items, the next item's K / V
+// chunk requested into registers while the current one is computed, so that loading and computing overlap instead of
+// alternating in two rounds: 64 us against 37 us per launch at 64 sequences.  The 40 prefetch registers pushed the
+// compute phase into scratch, and a wait for a scratch reload is a wait for every older request -- the prefetch itself.)
+template <int GRP>
+__global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const int n_seq)
+{
+    constexpr int dh = 64, NW = 17, PP = 264;                     // dwords per cached kv-head slice; halfs per probability row
+    // 1-D grid, id = ((sc / 8) * n_kv + g) * 8 + sc % 8 with sc = chunk * n_seq + seq: the kv heads of one (sequence, chunk)
+    // -- whose 68-byte slices share the 128-byte lines of a 272-byte cache row -- are 8 ids apart, i.e. dispatched together
+    // on ONE XCD (ids go round-robin over the 8 XCDs), so that its L2 fetches each line once (PMC: 95 MB per launch at 64
+    // sequences against 71 MB of K / V with the kv head in the slowest grid dimension); short contexts still spread
+    // their few live chunks over all XCDs.
+    const int sc_lo = blockIdx.x & 7, t1 = blockIdx.x >> 3, g = t1 % a0.n_kv, sci = (t1 / a0.n_kv) * 8 + sc_lo;
+    const int chunk = sci / n_seq, c0 = chunk * DEC_CHUNK;
+    const AttnArgs a = attn_for_seq(a0, sci - chunk * n_seq);
+    const int kv_dim = a.n_kv * dh;
+    constexpr size_t head_bytes = 2 * GTEN_Q8_BYTES;
+
+    unsigned* kl = (unsigned*)g_smem;                             // [256][17]: the chunk's K slices as they lie in the cache; dead after
+    _Float16* pl = (_Float16*)g_smem;                             // the scores: the probability rows [2 halves][8 heads][PP] lie over them
+    unsigned* vl = kl + DEC_CHUNK * NW;                           // [256][17]
+    int8_t* qi8 = (int8_t*)(vl + DEC_CHUNK * NW);                 // [16][64], rows GRP..15 zero
+    float* qd = (float*)(qi8 + 16 * dh);                          // [16][2]
+    float* kd = qd + 32;                                          // 8: new k deltas, new v deltas (head_prep scratch)
+    uint16_t* d16 = (uint16_t*)(kd + 8);                          // [GRP + 2][4] halves
+    int8_t* ki8 = (int8_t*)(d16 + 4 * (DEC_MAXGRP + 2));          // 64
+    int8_t* vi8 = ki8 + dh;                                       // 64
+    float* red = (float*)(vi8 + dh);                              // [2][4][16]: maxima, then sums
+    unsigned* vnew = (unsigned*)(red + 128);                      // 17 dwords: the new position's V slice in cache layout
+
+    // ---- requests, none of which needs the context length: raw projections, rotation, then the K and the V chunk as
+    //      coalesced dwords (dword idx -> (row idx / 17, word idx % 17); rows past the context are readable and masked below)
+    const int t = threadIdx.x & 63, pw = threadIdx.x >> 6, lc = t & 15, lq = t >> 4;
+    constexpr int NJ = (GRP + 3) / 4;
+    float qraw[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+    float kvraw = a.qkv_raw[a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+    {
+        float qraw2[NJ];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw2[jj] = a.qkv_raw[a.qkv_plane + (g * GRP + min(pw + 4 * jj, GRP - 1)) * dh + t];
+        const float kvraw2 = a.qkv_raw[a.qkv_plane + a.n_embd + ((pw & 1) ? kv_dim : 0) + g * dh + t];
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_plane ? qraw2[jj] : 0.f;
+        kvraw += a.qkv_plane ? kvraw2 : 0.f;
+    }
+    const float2 rot = a.rope_now[t & 31];
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned kw[NW], vw[NW];
+    {
+        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        const gmem_u32 kbase = as_global(a.kcache + (size_t)g * head_bytes), vbase = as_global(a.vcache + (size_t)g * head_bytes);
+        const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
+        const int last = a.max_ctx - 1 - c0;
+        // (all of K first, then all of V: requests return in order, and the scores must not wait for the V chunk)
+        unsigned off[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            off[k] = (unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w;
+            kw[k] = kbase[off[k]];
+            row += 256 / NW; w += 256 % NW;
+            if (w >= NW) { w -= NW; row++; }
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++) vw[k] = vbase[off[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
+
+    // ---- head vectors (k_dec_attn_score_g's), rows GRP..15 of the A operand zeroed
+    const bool has_new = (pos >= c0) && (pos < c0 + DEC_CHUNK);
+    for (int i = threadIdx.x; i < (16 - GRP) * dh / 4; i += 256) ((int*)(qi8 + GRP * dh))[i] = 0;
+    if (threadIdx.x < 2 * (16 - GRP)) qd[2 * GRP + threadIdx.x] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+        const int j = pw + 4 * jj;
+        if (j < GRP) head_prep_cs(qraw[jj], true, true, rot, dh, GTEN_Q8, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+    }
+    if (pw < 2 && has_new) {
+        int8_t* dq = pw ? vi8 : ki8;
+        head_prep_cs(kvraw, true, pw == 0, rot, dh, GTEN_Q8, dq, kd + 4 * pw, d16 + 4 * (GRP + pw));
+        uint8_t* row = (pw ? a.vcache : a.kcache) + (size_t)pos * a.kv_pitch + (size_t)g * head_bytes;
+        uint8_t* blk = row + (size_t)(t >> 5) * GTEN_Q8_BYTES;
+        store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
+        if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
+    }
+    // the K chunk goes to LDS now; the V chunk stays in its registers, in flight, until the scores are done
+#pragma unroll
+    for (int k = 0; k < NW; k++) kl[threadIdx.x + k * 256] = kw[k];
+    __syncthreads();
+    if (pw < 2 && has_new) {
+        // the new position's K / V slice comes from the chip (the cache row is being written by this very launch): K patched
+        // in place, V assembled in cache layout for the store below
+        uint8_t* row = pw ? (uint8_t*)vnew : (uint8_t*)kl + (size_t)(pos - c0) * (NW * 4);
+        const int8_t* dq = pw ? vi8 : ki8;
+        row[(t >> 5) * GTEN_Q8_BYTES + 2 + (t & 31)] = (uint8_t)dq[t];
+        if ((t & 31) == 0) *(uint16_t*)(row + (t >> 5) * GTEN_Q8_BYTES) = d16[4 * (GRP + pw) + (t >> 5)];
+    }
+    if (has_new) __syncthreads();                                 // (uniform per workgroup)
+
+    // ---- scores on the matrix cores: rows = heads, columns = positions 64 pw + 16 tt + lc.  A K slice is
+    //      [d0 | q0 x32 | d1 | q1 x32]: block 0's quants straddle the dwords by two bytes, block 1's are aligned.
+    //      The group's 8 heads fill rows 0..7 of the 16-row tile, so the results sit in lanes 0..31 (lq < 2) only;
+    //      v_permlane32_swap hands tiles 2, 3 to lanes 32..63: afterwards lane (lc, lq) owns heads 4 (lq & 1) + i
+    //      and tiles 2 (lq >> 1) + u -- 8 (head, position) pairs per lane, every lane busy, and the lane's two
+    //      positions under a head are exactly one Q8 block of the probability row.
+    long qa[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) qa[s2] = *(const long*)(qi8 + lc * dh + 32 * s2 + 8 * lq);
+    att_v4i i0[4], i1[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) {
+        const unsigned* krow = kl + (64 * pw + 16 * tt + lc) * NW;
+        const unsigned w0 = krow[2 * lq], w1 = krow[2 * lq + 1], w2 = krow[2 * lq + 2];
+        const unsigned x0 = krow[9 + 2 * lq], x1 = krow[10 + 2 * lq];
+        const long kb0 = (long)(((unsigned long)__builtin_amdgcn_alignbit(w2, w1, 16) << 32) | __builtin_amdgcn_alignbit(w1, w0, 16));
+        const long kb1 = (long)(((unsigned long)x1 << 32) | x0);
+        const att_v4i z = {0, 0, 0, 0};
+        i0[tt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(qa[0], kb0, z, 0, 0, 0);
+        i1[tt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(qa[1], kb1, z, 0, 0, 0);
+    }
+    const int hq = lq & 1, tsel = lq >> 1;
+    float qdl[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { qdl[i][0] = qd[2 * (4 * hq + i)]; qdl[i][1] = qd[2 * (4 * hq + i) + 1]; }
+    float sc[2][4];                                               // scores, later their exponentials: [tile 2 tsel + u][head 4 hq + i]
+    int pl_[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        pl_[u] = 64 * pw + 16 * (2 * tsel + u) + lc;
+        const unsigned kd0w = kl[pl_[u] * NW], kd1w = kl[pl_[u] * NW + 8];
+        const float kd0 = h2f((uint16_t)(kd0w & 0xffffu)), kd1 = h2f((uint16_t)(kd1w >> 16));
+        const bool live = c0 + pl_[u] < n;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // (first operand: lanes 32..63 receive the second operand's lanes 0..31)
+            const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)i0[u][i], (unsigned)i0[2 + u][i], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)i1[u][i], (unsigned)i1[2 + u][i], false, false);
+            float acc = 0.f;
+            acc += (float)(int)r0[0] * (qdl[i][0] * kd0);
+            acc += (float)(int)r1[0] * (qdl[i][1] * kd1);
+            sc[u][i] = live ? acc * 0.125f : -INFINITY;           // 1 / sqrt(64)
+        }
+    }
+    // ---- chunk maximum and sum of exponentials per head: 8 partials per head (4 waves x 2 lane halves)
+    float M[4], L[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float m = row16_max_f(fmaxf(sc[0][i], sc[1][i]));
+        if (lc == 0) red[(2 * pw + tsel) * 8 + 4 * hq + i] = m;
+    }
+    __syncthreads();                                              // (every wave is done with the K rows: pl may be written from here on)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int hh = 4 * hq + i;
+        float m = red[hh];
+#pragma unroll
+        for (int q = 1; q < 8; q++) m = fmaxf(m, red[q * 8 + hh]);
+        M[i] = m;
+    }
+    float* reds = red + 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        sc[0][i] = __expf(sc[0][i] - M[i]);                       // exp(-inf) = 0 for masked positions
+        sc[1][i] = __expf(sc[1][i] - M[i]);
+        const float e = row16_sum_f(sc[0][i] + sc[1][i]);
+        if (lc == 0) reds[(2 * pw + tsel) * 8 + 4 * hq + i] = e;
+    }
+    {
+        // the V chunk lands in LDS (its requests have been in flight since kernel entry); the new position's slice from the chip
+        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        const int newrow = has_new ? pos - c0 : -1;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            vl[threadIdx.x + k * 256] = (row == newrow) ? vnew[w] : vw[k];
+            row += 256 / NW; w += 256 % NW;
+            if (w >= NW) { w -= NW; row++; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int hh = 4 * hq + i;
+        float l = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) l += reds[q * 8 + hh];
+        L[i] = l;
+    }
+    if (pw == 0 && tsel == 0 && lc == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (4 * hq + i < GRP) {
+                a.stats[((size_t)(g * GRP + 4 * hq + i) * a.n_chunks + chunk) * 2 + 0] = M[i];
+                a.stats[((size_t)(g * GRP + 4 * hq + i) * a.n_chunks + chunk) * 2 + 1] = L[i];
+            }
+    }
+    // ---- probabilities: this lane's two positions under a head are one Q8 block of 32 along the context (with the other 15
+    //      lanes of its row); then the V row's block delta folded in and rounded to f16: the A operand of p.V,
+    //      [half][head][position]
+    float dvl[2][2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        dvl[u][0] = h2f((uint16_t)(vl[pl_[u] * NW] & 0xffffu)); dvl[u][1] = h2f((uint16_t)(vl[pl_[u] * NW + 8] >> 16));
+        live[u] = c0 + pl_[u] < n;                               // (rows past the context hold arbitrary deltas: keep them out)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float rL = recip_rn(L[i]);
+        const float p0 = sc[0][i] * rL, p1 = sc[1][i] * rL;
+        const Q8Scale qs = q8_scale_from_absmax(row16_max_f(fmaxf(p0, p1)));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float pq = (float)q8_round(u ? p1 : p0, qs.scale) * qs.ddeq;
+            pl[(0 * 8 + 4 * hq + i) * PP + pl_[u]] = (_Float16)(live[u] ? pq * dvl[u][0] : 0.f);
+            pl[(1 * 8 + 4 * hq + i) * PP + pl_[u]] = (_Float16)(live[u] ? pq * dvl[u][1] : 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- p.V on the matrix cores: wave pw owns elements 16 pw .. 16 pw + 15 (block half pw >> 1), 32 positions per instruction
+    att_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const _Float16* prow = pl + ((pw >> 1) * 8 + (lc & 7)) * PP + 8 * lq;
+        // element e of a slice sits at byte 2 + e (block 0) or 4 + e (block 1: behind the second delta)
+        const uint8_t* vcol = (const uint8_t*)vl + (size_t)(8 * lq) * (NW * 4) + 16 * pw + lc + ((pw >> 1) ? 4 : 2);
+#pragma unroll
+        for (int ks = 0; ks < DEC_CHUNK / 32; ks++) {
+            const att_h8 av = *(const att_h8*)(prow + 32 * ks);
+            unsigned hb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned b0 = vcol[(size_t)(32 * ks + 2 * j) * (NW * 4)], b1 = vcol[(size_t)(32 * ks + 2 * j + 1) * (NW * 4)];
+                // int8 -> exact f16: 0x6400 | (b ^ 0x80) is 1024 + (b + 128); minus 1152
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const unsigned u = (b0 | (b1 << 16)) ^ 0x64806480u;
+                h2 hv = __builtin_bit_cast(h2, u) - (h2){(_Float16)1152.0f, (_Float16)1152.0f};
+                hb[j] = __builtin_bit_cast(unsigned, hv);
+            }
+            att_h8 bv;
+            __builtin_memcpy(&bv, hb, 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (4 * lq + i < GRP) a.att_part[((size_t)(g * GRP + 4 * lq + i) * a.n_chunks + chunk) * dh + 16 * pw + lc] = acc[i];
+}
+
 // greedy argmax, strict '>' so the first maximum wins (tinyllama.cpp:416-424).
 // Works on (value, index) candidates: either the logits themselves (idx == null)
 // or the per-wave winners the lm_head kernel left behind.
@@ -2811,8 +3080,18 @@ static bool attention_one_pass(int d_head);
 // which grouped launches run in the one-pass form (k_dec_attn_one_g; the consumer then joins with PRO_ATTW): every
 // Q8 configuration; f16 only below 16 sequences is per-head anyway, from 16 up its scores stay on the matrix cores
 // (k_dec_attn_score_gm_f16) in the two-launch form
+// 16-64 sequences with Q8 activations: k_dec_attn_mm_g (one launch, matrix cores).  GTEN_HIP_ATTN_EXACT=1 or
+// GTEN_HIP_ATTN_TWO_PASS=1 keep the VALU pair (exact p.V terms / row-global rounding points; tests compare).
+static bool grouped_mm(const AttnArgs& t, int n_seq)
+{
+    const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
+    const char* tp = std::getenv("GTEN_HIP_ATTN_TWO_PASS");
+    return n_seq >= 16 && t.adtype == GTEN_Q8 && t.d_head == 64 && !(ex && ex[0] == '1') && !(tp && tp[0] == '1');
+}
+
 static bool grouped_one_pass(const AttnArgs& t, int n_seq)
 {
+    if (grouped_mm(t, n_seq)) return true;
     // 8 sequences: one launch (per sequence the bytes of single-sequence decode).  From 16 sequences up the two
     // launches measured FASTER than the merged kernel (64 sequences, ctx 2048: 22.3 + 25.8 us against 62.4 us per
     // block -- the merged workgroup holds K rows, V chunk and every head's scores at once: 104 VGPRs, 27 KB of LDS,
@@ -2825,6 +3104,12 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
 {
     constexpr size_t NW = (ADT == GTEN_Q8) ? 17 : 32;
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
+    if constexpr (ADT == GTEN_Q8) if (grouped_mm(t, n_seq)) {
+        const size_t smem = (size_t)2 * DEC_CHUNK * 68 + 16 * 64 + 32 * 4 + 8 * 4 + (size_t)4 * (DEC_MAXGRP + 2) * 2 + 128 + 128 * 4 + 80 + 64;
+        GTR_REQUIRE((n_seq * t.n_chunks) % 8 == 0, "decoder: %d sequences x %d chunks is not a multiple of 8", n_seq, t.n_chunks);
+        DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_mm_g<GRP>), dim3(n_seq * t.n_chunks * t.n_kv), dim3(256), smem, t, n_seq);
+        return 0;
+    }
     if constexpr (ADT == GTEN_Q8) if (grouped_one_pass(t, n_seq)) {
         constexpr size_t GP = (GRP + 1) / 2;
         const size_t smem = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 16 +
