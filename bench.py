@@ -656,17 +656,19 @@ def worker(args, rank, local_rank, world, dist):
         rng = np.random.default_rng(2024)
         lens = rng.integers(64, 513, args.serve)
         prompts = [list(host.synthetic_tokens(int(n), seed=rep_seed(999, j))) for j, n in enumerate(lens)]
+        budgets = rng.integers(32, 225, args.serve).astype(np.int32)  # new ids per prompt: 32..224 (mean 128) -- requests end at different times
         batch.serve(prompts[:S], N_CTX, -1, 16, max_new=4)           # warm-up: graphs, first-use allocations
         t0 = time.perf_counter()
-        got, st = batch.serve(prompts, N_CTX, -1, 16, max_new=128)
+        got, st = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
         dt = time.perf_counter() - t0
         out["serving"] = {"slots": S, "prompts": int(args.serve), "prompt_tokens": int(st["prompt_tokens"]), "new_tokens": int(st["new_tokens"]),
                           "wall_s": round(dt, 3), "new_tok_s": round(st["new_tokens"] / dt, 1),
                           "all_tok_s": round((st["new_tokens"] + st["prompt_tokens"]) / dt, 1),
                           "shared_steps": int(st["steps"]), "prefill_s": round(st["prefill_s"], 3), "decode_s": round(st["decode_s"], 3),
                           "slot_utilisation": round(st["new_tokens"] / max(st["steps"] * S, 1), 3),
-                          "note": "sustained rates over the whole queue, prompt processing included in the wall time (same stream, "
-                                  "between slices of 16 shared steps); slot_utilisation = new ids / (shared steps x slots)"}
+                          "note": "sustained rates over the whole queue (256 prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
+                                  "the library's second stream BESIDE the slices of 16 shared steps (prefill_s = host time spent in it, "
+                                  "overlapped); slot_utilisation = new ids / (shared steps x slots)"}
         batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if secondary and args.prefill > 0:

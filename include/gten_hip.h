@@ -57,8 +57,15 @@ enum { GTEN_I32 = 0, GTEN_F16 = 1, GTEN_F32 = 2, GTEN_Q8 = 3, GTEN_Q4 = 4 };
 int         gten_hip_device_count(void);             /* does not initialise the GPU */
 int         gten_hip_init(int device);               /* idempotent per process */
 const char* gten_hip_last_error(void);
-void*       gten_hip_stream(void);                   /* hipStream_t all work is queued on */
-int         gten_hip_sync(void);
+void*       gten_hip_stream(void);                   /* hipStream_t work is being queued on (the selected one) */
+int         gten_hip_sync(void);                     /* waits for the selected stream */
+/* The library owns two streams; every call queues on the selected one (0 at start).  Stream 1 exists so that the prompt of a
+ * NEW sequence can be processed beside the decode steps of the others (continuous batching, TinyLlamaBatch::serve): work on
+ * different streams is unordered unless gten_hip_stream_wait(waiter, on) makes `waiter` wait for what `on` holds so far.
+ * One calling thread; buffers touched on both streams are the caller's to order. */
+int         gten_hip_select_stream(int idx);
+int         gten_hip_stream_wait(int waiter, int on);
+int         gten_hip_stream_idle(int idx, int* idle);   /* *idle = 1 when everything queued on stream idx has finished (no wait) */
 
 /* replaces std::malloc / std::free of Tensor storage, gten/tensor.cpp:23-25,61 */
 int gten_hip_malloc(void** dptr, size_t nbytes);

@@ -102,11 +102,11 @@ int  gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const 
  * through the batch's n_seq slots -- a slot whose sequence has ended (eos, `max_tokens` ids in all, or the context) takes the
  * next prompt at once while the other slots go on decoding (TinyLlamaBatch::serve, host/tinyllama_model.h; device side:
  * gten_hip_decoder_slot_start / _run / _slot_ids).  `slice` = shared steps between two looks at the results; max_new > 0
- * additionally bounds the ids generated per prompt.
+ * additionally bounds the ids generated per prompt (max_new_each, when not NULL: prompt j's own bound).
  * out is [n_prompts][max(max_tokens, max_prompt)] (prompt + new ids), n_total [n_prompts]; stats (may be NULL) receives
  * {prompt tokens, new tokens, shared steps, admissions, seconds in prompt processing, seconds in shared steps}. */
 int  gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
-                           int max_tokens, int eos, int slice, int max_new, int32_t* out, int32_t* n_total, double* stats);
+                           int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
 int  gten_host_batch_decode_steps(gten_host_batch* b, int n_first, int count, int use_graph);   /* asynchronous: count consecutive steps, four per graph replay */

@@ -53,6 +53,18 @@ def test_queue_through_slots_equals_single_sequence_generation(hip, name, wd, ad
     got, st = b.serve(prompts, total, eos, 8, max_new=25)
     for j in range(len(prompts)):
         assert got[j].tolist() == want_new[j].tolist(), (name, n_seq, "max_new", j)
+    # ... and per prompt (requests that end at different times: slots are refilled while the others decode)
+    each = [3 + (7 * j) % 40 for j in range(len(prompts))]
+    want_each = []
+    m = host.model(cfg)
+    for i, w in enumerate(weights):
+        m.set_weight(i, w)
+    for p, e in zip(prompts, each):
+        want_each.append(m.generate(p, min(total, len(p) + e), eos) if len(p) < total else np.array(p, np.int32))
+    m.close()
+    got, st = b.serve(prompts, total, eos, 4, max_new_each=each)
+    for j in range(len(prompts)):
+        assert got[j].tolist() == want_each[j].tolist(), (name, n_seq, "max_new_each", j)
     # the decoder still serves the other entry points afterwards (slots view is reset)
     toks = host.synthetic_tokens(20, seed=5, n_vocab=cfg.n_vocab)
     for q in range(n_seq):

@@ -3043,6 +3043,9 @@ struct gten_hip_decoder {
     // ---- multi-sequence decode (n_seq > 1): per-sequence rows of every scratch buffer above, plus
     int n_seq = 1;
     const void** kv_tab = nullptr; // device: [n_seq][n_layers][k|v]
+    std::vector<const void*> kv_real;   // the same on the host (slot_park points a slot's entries at the dummy caches, slot_start back)
+    std::vector<char> kv_parked;        // per sequence: entries currently redirected
+    void* dummy_kv = nullptr;           // one K and one V cache nobody reads meaningfully: where a PARKED slot's idle steps write
     int8_t* stg_q = nullptr;       // staged n_embd-wide input of the next W.x: [n_seq] ActQ8 / f32 rows
     float* stg_d = nullptr;
     int* stg_sum = nullptr;
@@ -3829,6 +3832,11 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
             }
         GTR_CHECK(hipMalloc((void**)&dc->kv_tab, tab.size() * sizeof(void*)));
         GTR_CHECK(hipMemcpy(dc->kv_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
+        dc->kv_real = tab;
+        dc->kv_parked.assign(S, 0);
+        const size_t cache_bytes = (size_t)d.max_ctx * gten_hip_row_bytes(d.adtype, KV);
+        GTR_CHECK(hipMalloc(&dc->dummy_kv, 2 * cache_bytes));
+        GTR_CHECK(hipMemset(dc->dummy_kv, 0, 2 * cache_bytes));
     }
     if (int rc = rope_table(dh, &dc->rope)) return rc;
     GTR_CHECK(hipMalloc((void**)&dc->rope_now, S * (size_t)(dh / 2) * sizeof(float2)));
@@ -3861,7 +3869,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
-                    dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now};
+                    dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now, dc->dummy_kv};
     for (void* b : bufs) if (b) hipFree(b);
     delete dc;
     return 0;
@@ -3889,6 +3897,7 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t
 // command processor idles for several microseconds (8.6 us between a step's last kernel and the next step's first one
 // in the rocprofv3 kernel trace, profiles/r02_*), i.e. ~1.5 % of a batch-1 step; four steps per replay pay it once.
 #define DEC_GRAPH_STEPS 4
+static int slots_leave(gten_hip_decoder* dc);     // continuous batching (below): back to every sequence's own caches
 static int run_step(gten_hip_decoder* dc, int use_graph);
 static int run_steps_free(gten_hip_decoder* dc, int count)
 {
@@ -3944,7 +3953,7 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
     }
     dc->dev_n = n + 1;
     dc->dev_ns.clear();
-    dc->slots.clear();
+    if (int rc_ = slots_leave(dc)) return rc_;
     return run_step(dc, use_graph);
 }
 
@@ -3963,7 +3972,7 @@ int gten_hip_decoder_steps(gten_hip_decoder* dc, int n_first, int count, int use
     }
     dc->dev_n = n_first + count;
     dc->dev_ns.clear();
-    dc->slots.clear();
+    if (int rc_ = slots_leave(dc)) return rc_;
     if (!use_graph) { for (int i = 0; i < count; i++) if (int rc = run_step(dc, 0)) return rc; return 0; }
     return run_steps_free(dc, count);
 }
@@ -3988,7 +3997,7 @@ int gten_hip_decoder_step_ragged(gten_hip_decoder* dc, const int* n_per_seq, int
     dc->dev_ns.assign(n_per_seq, n_per_seq + dc->n_seq);
     for (int& v : dc->dev_ns) v += 1;                 // the argmax kernel advances every sequence
     dc->dev_n = -1;
-    dc->slots.clear();
+    if (int rc_ = slots_leave(dc)) return rc_;
     return run_step(dc, use_graph);
 }
 
@@ -4008,7 +4017,7 @@ int gten_hip_decoder_generate(gten_hip_decoder* dc, int n_first, int max_new, in
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     dc->dev_ns.clear();
-    dc->slots.clear();
+    if (int rc_ = slots_leave(dc)) return rc_;
     int got = 0;
     std::vector<int32_t> ids(GEN_SLICE);
     for (int n = n_first; n <= last;) {
@@ -4055,7 +4064,7 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, co
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     dc->dev_ns.clear();
-    dc->slots.clear();
+    if (int rc_ = slots_leave(dc)) return rc_;
     std::vector<int32_t> ids((size_t)GEN_SLICE);
     while (n_live > 0) {
         int cnt = GEN_SLICE;
@@ -4082,6 +4091,25 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, co
 }
 
 // ---- continuous batching: slots started / parked independently, the batch replayed free-running
+// A PARKED slot keeps taking part in the shared launches (the batch is one matrix of n_seq rows), at position 1 and on
+// the decoder's dummy K / V caches: its own caches are then free to be filled by the prompt processing of the NEXT
+// sequence -- on the library's second stream, beside the steps of the live slots.
+static int slot_caches(gten_hip_decoder* dc, int seq, bool parked)
+{
+    if (dc->kv_parked.empty() || (bool)dc->kv_parked[(size_t)seq] == parked) return 0;
+    const size_t L = (size_t)dc->d.n_layers, off = (size_t)seq * L * 2;
+    std::vector<const void*> row(L * 2);
+    const size_t cache_bytes = (size_t)dc->d.max_ctx * gten_hip_row_bytes(dc->d.adtype, (dc->d.n_embd / dc->d.n_heads) * dc->d.n_kv_heads);
+    for (size_t l = 0; l < L; l++) {
+        row[2 * l] = parked ? dc->dummy_kv : dc->kv_real[off + 2 * l];
+        row[2 * l + 1] = parked ? (const void*)((const uint8_t*)dc->dummy_kv + cache_bytes) : dc->kv_real[off + 2 * l + 1];
+    }
+    GTR_CHECK(hipMemcpyAsync(dc->kv_tab + off, row.data(), row.size() * sizeof(void*), hipMemcpyHostToDevice, stream()));
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    dc->kv_parked[(size_t)seq] = parked;
+    return 0;
+}
+
 static int slots_view(gten_hip_decoder* dc)
 {
     if (dc->slots.empty()) {
@@ -4089,9 +4117,20 @@ static int slots_view(gten_hip_decoder* dc)
         dc->slots.assign((size_t)dc->n_seq, DecStep{1, 0});
         GTR_CHECK(hipMemcpyAsync(dc->step, dc->slots.data(), dc->slots.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
         GTR_CHECK(hipStreamSynchronize(stream()));
+        for (int q = 0; q < dc->n_seq; q++)
+            if (int rc = slot_caches(dc, q, true)) return rc;
     }
     dc->dev_n = -1;
     dc->dev_ns.clear();
+    return 0;
+}
+
+// the other entry points work on every sequence's own caches
+static int slots_leave(gten_hip_decoder* dc)
+{
+    for (int q = 0; q < dc->n_seq && !dc->kv_parked.empty(); q++)
+        if (int rc = slot_caches(dc, q, false)) return rc;
+    dc->slots.clear();
     return 0;
 }
 
@@ -4101,6 +4140,7 @@ int gten_hip_decoder_slot_start(gten_hip_decoder* dc, int seq, int n_first)
     GTR_REQUIRE(dc && seq >= 0 && seq < dc->n_seq, "decoder_slot_start: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
     GTR_REQUIRE(n_first >= 1 && n_first <= dc->d.max_ctx, "decoder_slot_start: n_first=%d outside [1, %d]", n_first, dc->d.max_ctx);
     if (int rc = slots_view(dc)) return rc;
+    if (int rc = slot_caches(dc, seq, false)) return rc;
     dc->slots[(size_t)seq] = DecStep{n_first, 3};
     GTR_CHECK(hipMemcpyAsync(dc->step + seq, &dc->slots[(size_t)seq], sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
@@ -4112,8 +4152,9 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && seq >= 0 && seq < dc->n_seq, "decoder_slot_park: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
     if (int rc = slots_view(dc)) return rc;
+    if (int rc = slot_caches(dc, seq, true)) return rc;
     DecStep& s = dc->slots[(size_t)seq];
-    s.n = std::min(std::max(s.n, 1), dc->d.max_ctx);
+    s.n = 1;
     s.advance = 0;
     GTR_CHECK(hipMemcpyAsync(dc->step + seq, &s, sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));

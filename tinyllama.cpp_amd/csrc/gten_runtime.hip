@@ -16,7 +16,11 @@ namespace gtr {
 static char g_err[512] = "";
 static bool g_inited = false;
 static int g_device = -1;
-static hipStream_t g_stream = nullptr;
+// Two streams: 0 is the default; 1 lets prompt processing be queued beside the decode steps of other sequences
+// (gten_hip_select_stream; one calling thread, so `current` is a plain variable)
+static hipStream_t g_streams[2] = {nullptr, nullptr};
+static int g_cur = 0;
+#define g_stream (g_streams[g_cur])
 // RoPE tables, one per head width ever asked for: [GTEN_ROPE_MAX_POS][d_head/2] (cos, sin).  Never freed while the
 // runtime lives -- decoders keep the pointer in their kernel arguments and in captured hipGraphs, and models of
 // different head widths coexist in one process.
@@ -31,7 +35,7 @@ int fail(int code, const char* fmt, ...)
     return code ? code : -1;
 }
 
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() { return g_streams[g_cur]; }
 bool inited() { return g_inited; }
 
 // RoPE angles use the host libm exactly as the reference does
@@ -109,7 +113,8 @@ int gten_hip_init(int device)
         return 0;
     }
     GTR_CHECK(hipSetDevice(device));
-    GTR_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    GTR_CHECK(hipStreamCreateWithFlags(&g_streams[0], hipStreamNonBlocking));
+    GTR_CHECK(hipStreamCreateWithFlags(&g_streams[1], hipStreamNonBlocking));
     g_device = device;
     g_inited = true;
     return 0;
@@ -137,8 +142,38 @@ int gten_hip_free(void* dptr)
 {
     GTR_NEED_INIT();
     if (!dptr) return 0;
-    GTR_CHECK(hipStreamSynchronize(g_stream));
+    GTR_CHECK(hipStreamSynchronize(g_streams[0]));    // (work on either stream may still use the buffer)
+    GTR_CHECK(hipStreamSynchronize(g_streams[1]));
     GTR_CHECK(hipFree(dptr));
+    return 0;
+}
+
+int gten_hip_select_stream(int idx)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(idx == 0 || idx == 1, "gten_hip_select_stream: stream %d (0 or 1)", idx);
+    g_cur = idx;
+    return 0;
+}
+
+int gten_hip_stream_wait(int waiter, int on)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE((waiter == 0 || waiter == 1) && (on == 0 || on == 1) && waiter != on, "gten_hip_stream_wait: streams %d, %d", waiter, on);
+    static hipEvent_t ev = nullptr;
+    if (!ev) GTR_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GTR_CHECK(hipEventRecord(ev, g_streams[on]));
+    GTR_CHECK(hipStreamWaitEvent(g_streams[waiter], ev, 0));
+    return 0;
+}
+
+int gten_hip_stream_idle(int idx, int* idle)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE((idx == 0 || idx == 1) && idle, "gten_hip_stream_idle: stream %d (0 or 1), idle %p", idx, (void*)idle);
+    const hipError_t e = hipStreamQuery(g_streams[idx]);
+    if (e != hipSuccess && e != hipErrorNotReady) GTR_CHECK(e);
+    *idle = e == hipSuccess;
     return 0;
 }
 

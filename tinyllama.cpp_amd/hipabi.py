@@ -73,7 +73,7 @@ class GtenHip:
     """Loaded libgten_hip.so with every symbol of include/gten_hip.h bound."""
 
     SYMBOLS = [
-        "gten_hip_device_count", "gten_hip_init", "gten_hip_last_error", "gten_hip_stream", "gten_hip_sync",
+        "gten_hip_device_count", "gten_hip_init", "gten_hip_last_error", "gten_hip_stream", "gten_hip_sync", "gten_hip_select_stream", "gten_hip_stream_wait", "gten_hip_stream_idle",
         "gten_hip_malloc", "gten_hip_free", "gten_hip_memset", "gten_hip_memcpy_h2d", "gten_hip_memcpy_d2h",
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
         "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",

@@ -301,7 +301,7 @@ int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const i
 }
 
 int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
-                          int max_tokens, int eos, int slice, int max_new, int32_t* out, int32_t* n_total, double* stats)
+                          int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats)
 {
     if (!prompts || !n_prompt || !out || !n_total || n_prompts <= 0 || max_tokens <= 0 || slice <= 0) return -1;
     std::vector<std::vector<int32_t>> ps((size_t)n_prompts), res;
@@ -309,7 +309,7 @@ int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int3
         if (n_prompt[j] <= 0 || n_prompt[j] > max_prompt || n_prompt[j] > b->cfg.max_ctx) return -1;
         ps[(size_t)j].assign(prompts + (size_t)j * max_prompt, prompts + (size_t)j * max_prompt + n_prompt[j]);
     }
-    const TinyLlamaBatch::ServeStats st = b->batch->serve(ps, max_tokens, eos, slice, &res, max_new);
+    const TinyLlamaBatch::ServeStats st = b->batch->serve(ps, max_tokens, eos, slice, &res, max_new, max_new_each);
     for (int j = 0; j < n_prompts; j++) {
         const int take = std::min((int)res[(size_t)j].size(), std::max(max_tokens, n_prompt[j]));
         std::memcpy(out + (size_t)j * std::max(max_tokens, max_prompt), res[(size_t)j].data(), (size_t)take * sizeof(int32_t));

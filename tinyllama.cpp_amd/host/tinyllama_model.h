@@ -398,27 +398,38 @@ public:
 
     // ---- continuous batching: a queue of prompts served through the n_seq slots ------------------------------
     // Every prompt is generated greedily to `max_tokens` ids in all (prompt included) or until `eos` (not stored,
-    // tinyllama.cpp:425), as greedy_sample does for one sequence.  A slot whose sequence has ended takes the next
-    // prompt of the queue at once: the prompt is processed on the slot's own caches (operator path, iteration 0 of
-    // the reference loop incl. the host argmax of its logits), the slot is started (gten_hip_decoder_slot_start) and
-    // joins the shared steps; the batch runs `slice` free-running steps between two looks at the results.  Per
-    // sequence the ids are those of generating it alone (bit for bit up to 8 slots; tests/test_serving_gpu.py).
+    // tinyllama.cpp:425), as greedy_sample does for one sequence; max_new > 0 additionally bounds the new ids per prompt.
+    // One host thread keeps two things going that OVERLAP on the GPU:
+    //   * a slice of `slice` shared free-running steps of the live slots, queued on stream 0 (gten_hip_decoder_run);
+    //   * while it runs: the prompts of the next sequences, one after the other, each on a free slot's own caches on stream 1
+    //     (operator path: iteration 0 of the reference's loop incl. the host argmax of its logits).  A parked slot idles on
+    //     the decoder's dummy caches (gten_hip_decoder_slot_park), so nothing the shared steps do touches the caches being
+    //     filled.  Prompt processing is host-bound (~500 short launches) and the shared steps are GPU-bound: side by side
+    //     they hide each other.
+    // Between two prompts the slice is polled (gten_hip_stream_idle): once done its ids are read (eos / length -> the slot is
+    // parked and becomes free) and the next slice starts at once with the slots whose prompts became ready meanwhile.  Nobody
+    // runs past its last step (the slice is cut to the shortest remaining run).  Per sequence the ids are those of
+    // generating it alone (bit for bit up to 8 slots; tests/test_serving_gpu.py).
     struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0; double prefill_s = 0.0, decode_s = 0.0; };
-    // (max_new > 0 additionally bounds the ids generated per prompt)
+    // (max_new_each, when given, bounds the new ids of prompt j by max_new_each[j] instead of max_new)
     ServeStats serve(const std::vector<std::vector<int32_t>>& prompts, int max_tokens, int eos, int slice,
-                     std::vector<std::vector<int32_t>>* out, int max_new = 0)
+                     std::vector<std::vector<int32_t>>* out, int max_new = 0, const int32_t* max_new_each = nullptr)
     {
         using clock = std::chrono::steady_clock;
         ensure_decoder();
         const int S = n_seq();
         ServeStats st;
         out->assign(prompts.size(), {});
-        std::vector<int> job((size_t)S, -1), cur((size_t)S, 0), last((size_t)S, 0);   // per slot: prompt index, next step, last step
+        // per slot: prompt index (-1: free), next step, last step; ready: prompt processed, waiting to join
+        std::vector<int> job((size_t)S, -1), cur((size_t)S, 0), last((size_t)S, 0);
+        std::vector<char> live((size_t)S, 0);
         size_t next = 0;
-        int live = 0;
+        int n_live = 0, n_ready = 0;
         std::vector<int32_t> ids((size_t)std::max(slice, 1));
+        GTEN_HIP_OK(gten_hip_select_stream(0));
         for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
-        auto admit = [&](int q) {
+        // the next prompt of the queue onto free slot q (stream 1); false when the queue is empty
+        auto prepare = [&](int q) {
             while (next < prompts.size()) {
                 const int j = (int)next++;
                 std::vector<int32_t>& row = (*out)[(size_t)j];
@@ -426,12 +437,13 @@ public:
                 const int P = (int)row.size();
                 GTEN_ASSERTM(P >= 1 && P <= n_ctx_, "serve: prompt %d has %d ids (context %d)", j, P, n_ctx_);
                 st.prompt_tokens += P;
-                const int limit = std::min(std::min(max_tokens, n_ctx_), max_new > 0 ? P + max_new : n_ctx_);   // ids in all
+                const int mn = max_new_each ? max_new_each[j] : max_new;
+                const int limit = std::min(std::min(max_tokens, n_ctx_), mn > 0 ? P + mn : n_ctx_);   // ids in all
                 if (P >= limit) continue;                                  // no room to generate: returned as is
                 const auto t0 = clock::now();
                 Tensor tk(row.data(), {P}, kInt32);
                 const Tensor lg = seq(q).logits(tk, 0);                    // this slot's caches now hold rows [0, P)
-                const float* p = lg.data_ptr<float>();
+                const float* p = lg.data_ptr<float>();                     // (waits for stream 1 only)
                 int best_i = 0;
                 float best = -std::numeric_limits<float>::infinity();
                 for (int k = 0; k < lg.numel(); k++)
@@ -442,24 +454,36 @@ public:
                 row.push_back(best_i);
                 st.new_tokens++;
                 if ((int)row.size() >= limit) continue;
-                GTEN_HIP_OK(gten_hip_decoder_set_tokens_seq(dec_, q, row.data(), 0, (int)row.size()));
-                GTEN_HIP_OK(gten_hip_decoder_slot_start(dec_, q, (int)row.size()));
                 job[(size_t)q] = j; cur[(size_t)q] = (int)row.size(); last[(size_t)q] = limit - 1;
-                live++;
-                return;
+                n_ready++;
+                return true;
             }
+            return false;
         };
-        for (int q = 0; q < S; q++) admit(q);
-        while (live > 0) {
-            int cnt = std::max(slice, 1);
+        int cnt = 0;                                                       // steps of the slice in flight (0: none)
+        auto t_slice = clock::now();
+        // ready slots join, then the next slice starts (stream 0, asynchronous)
+        auto launch_slice = [&]() {
+            for (int q = 0; q < S && n_ready > 0; q++)
+                if (job[(size_t)q] >= 0 && !live[(size_t)q]) {
+                    const std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
+                    GTEN_HIP_OK(gten_hip_decoder_set_tokens_seq(dec_, q, row.data(), 0, (int)row.size()));
+                    GTEN_HIP_OK(gten_hip_decoder_slot_start(dec_, q, cur[(size_t)q]));
+                    live[(size_t)q] = 1; n_live++; n_ready--;
+                }
+            if (n_live == 0) return;
+            cnt = std::max(slice, 1);
             for (int q = 0; q < S; q++)
-                if (job[(size_t)q] >= 0) cnt = std::min(cnt, last[(size_t)q] - cur[(size_t)q] + 1);   // nobody runs past its last step
-            const auto t0 = clock::now();
+                if (live[(size_t)q]) cnt = std::min(cnt, last[(size_t)q] - cur[(size_t)q] + 1);   // nobody runs past its last step
+            t_slice = clock::now();
             GTEN_HIP_OK(gten_hip_decoder_run(dec_, cnt));
             st.steps += cnt;
+        };
+        // the ids of the finished slice; slots that ended are parked (their caches are free for the next prompt)
+        auto harvest = [&]() {
             for (int q = 0; q < S; q++) {
-                if (job[(size_t)q] < 0) continue;
-                GTEN_HIP_OK(gten_hip_decoder_slot_ids(dec_, q, cur[(size_t)q], cnt, ids.data()));
+                if (!live[(size_t)q]) continue;
+                GTEN_HIP_OK(gten_hip_decoder_slot_ids(dec_, q, cur[(size_t)q], cnt, ids.data()));   // (waits for stream 0)
                 std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
                 bool stop = false;
                 for (int i = 0; i < cnt && !stop; i++) {
@@ -469,15 +493,43 @@ public:
                 cur[(size_t)q] += cnt;
                 if (stop || cur[(size_t)q] > last[(size_t)q]) {
                     GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
-                    job[(size_t)q] = -1;
-                    live--;
+                    job[(size_t)q] = -1; live[(size_t)q] = 0; n_live--;
                 }
             }
-            st.decode_s += std::chrono::duration<double>(clock::now() - t0).count();
-            for (int q = 0; q < S; q++)
-                if (job[(size_t)q] < 0) admit(q);
+            st.decode_s += std::chrono::duration<double>(clock::now() - t_slice).count();
+            cnt = 0;
+        };
+        // One host thread: prompts are processed back to back on stream 1; between two prompts the slice on stream 0 is
+        // polled, and when it has finished its ids are read and the next slice (with the slots that became ready) starts.
+        bool queue_left = true;
+        for (;;) {
+            if (cnt > 0) {
+                int idle = 0;
+                GTEN_HIP_OK(gten_hip_stream_idle(0, &idle));
+                int free_q = -1;
+                if (!idle && queue_left)
+                    for (int q = 0; q < S && free_q < 0; q++)
+                        if (job[(size_t)q] < 0) free_q = q;
+                if (free_q >= 0) {                                          // slice still running: one more prompt beside it
+                    GTEN_HIP_OK(gten_hip_select_stream(1));
+                    queue_left = prepare(free_q);
+                    GTEN_HIP_OK(gten_hip_select_stream(0));
+                    continue;
+                }
+                harvest();                                                  // (waits when nothing is left to prepare)
+            }
+            if (n_live == 0 && n_ready == 0) {                              // nothing to decode: a prompt first
+                int free_q = -1;
+                for (int q = 0; q < S && free_q < 0 && queue_left; q++)
+                    if (job[(size_t)q] < 0) free_q = q;
+                if (free_q < 0) break;                                      // queue empty, nothing in flight
+                GTEN_HIP_OK(gten_hip_select_stream(1));
+                queue_left = prepare(free_q);
+                GTEN_HIP_OK(gten_hip_select_stream(0));
+                if (n_ready == 0) { if (!queue_left) break; continue; }
+            }
+            launch_slice();
         }
-        for (auto& m : seqs_) (void)m;                                   // (logits mirrors are refreshed on the next read)
         return st;
     }
 

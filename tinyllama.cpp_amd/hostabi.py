@@ -82,7 +82,7 @@ class GtenHost:
         self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
         self._bstepr = _sig(L, "gten_host_batch_decode_step_ragged", ci, [vp, vp, ci])
         self._bgen = _sig(L, "gten_host_batch_generate", ci, [vp, vp, vp, ci, ci, ci, vp, vp])
-        self._bserve = _sig(L, "gten_host_batch_serve", ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp])
+        self._bserve = _sig(L, "gten_host_batch_serve", ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp])
         self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
         self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
         self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
@@ -316,7 +316,7 @@ class HostBatch:
                                  out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p)), "batch_generate")
         return [out[q, : tot[q]].copy() for q in range(self.n_seq)]
 
-    def serve(self, prompts, max_tokens, eos=-1, slice_steps=16, max_new=0):
+    def serve(self, prompts, max_tokens, eos=-1, slice_steps=16, max_new=0, max_new_each=None):
         """continuous batching: the queue `prompts` (any number) through this batch's slots; returns (list of id
         arrays -- prompt + new ids, one per prompt, in queue order -- and a dict of counters)"""
         mp = max(len(p) for p in prompts)
@@ -329,8 +329,10 @@ class HostBatch:
         out = np.zeros((len(prompts), width), np.int32)
         tot = np.zeros(len(prompts), np.int32)
         st = np.zeros(6, np.float64)
+        each = None if max_new_each is None else np.ascontiguousarray(max_new_each, dtype=np.int32)
+        assert each is None or len(each) == len(prompts)
         self._ck(self.host._bserve(self.h, pr.ctypes.data_as(C.c_void_p), npr.ctypes.data_as(C.c_void_p), len(prompts), mp, max_tokens, eos,
-                                   slice_steps, max_new, out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)),
+                                   slice_steps, max_new, None if each is None else each.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)),
                  "batch_serve")
         keys = ("prompt_tokens", "new_tokens", "steps", "admissions", "prefill_s", "decode_s")
         return [out[j, : tot[j]].copy() for j in range(len(prompts))], dict(zip(keys, st.tolist()))
