@@ -2710,8 +2710,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_one_g(const AttnArgs a0)
 // The VALU pair above spends ~1900 instructions per thread on a chunk (scores 8 heads x 17 dot4, exponentials and Q8
 // roundings per (head, position), 2 VALU operations per p.V term); merged as it stands it lost to the pair (occupancy,
 // DESIGN.md 3.3).  Here the two contractions are matrix instructions and a workgroup needs ~1000 instructions per thread:
-//   * K and V rows are loaded row-per-thread (17 dwords), re-aligned in registers (the quants of block 0 straddle the
-//     dwords by two bytes) and parked in LDS as [position][64 quants | d0 d1 | pad] = 72-byte rows;
+//   * the K and the V chunk are requested at entry as COALESCED dwords exactly as they lie in the cache (256 positions x
+//     17 dwords each, 17 requests per thread and matrix); K is parked in LDS at once, V stays in registers until the scores
+//     are done (its arrival hides behind them) and then takes K's place;
 //   * scores: v_mfma_i32_16x16x32_i8, A = the group's head vectors (rows 8..15 zero), B = 16 positions of K; one
 //     instruction per (16 positions, quant block) gives the exact integer block dots, scaled dq dk as the scalar code;
 //   * chunk-local softmax (k_dec_attn_one64's scheme, hardware exponential), probabilities rounded to Q8 blocks of 32
