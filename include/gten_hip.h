@@ -145,6 +145,30 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
                       size_t q_pitch, size_t kv_pitch, size_t out_pitch,
                       int n, int n_heads, int n_kv_heads, int d_head, int start_pos);
 
+/* ---- one transformer block over many new rows (prompt processing) ------
+ * AttentionBlock::forward (gten/modules.cpp:224-254) for rows [start_pos, n) as ONE call: the same kernels as the
+ * operators above, composed so that matrices sharing an input share its conversion and its launch (q | k | v, gate | up),
+ * q and k are rotated together, silu and the product are one pass and the residual sums ride in the epilogues of the o and
+ * down projections -- 12 launches instead of 23.  Every buffer named here ends with exactly the bytes the module-by-module
+ * sequence leaves in it (tests/test_block_rows_gpu.py).  Activation buffers are dense rows in `adtype`; k and v are the
+ * K / V caches.  Returns GTEN_HIP_NOT_HANDLED (no error recorded) for configurations this path does not compute (fp16
+ * activations, fewer than 16 new rows, d_head != 64): the caller then runs the operators. */
+#define GTEN_HIP_NOT_HANDLED 1
+typedef struct {
+    int adtype, wdtype;         /* GTEN_Q8 activations, GTEN_Q8 / GTEN_Q4 weights */
+    int n_embd, n_heads, n_kv_heads, n_ffn;
+    const void *attn_norm_w, *wq, *wk, *wv, *wo, *ffn_norm_w, *wgate, *wup, *wdown;
+    const void* inp;            /* [.][n_embd]: the block's input rows */
+    void *attn_norm_out, *q, *k, *v, *attn_out, *o;
+    void* h;                    /* inp + o (Residual) */
+    void *ffn_norm_out, *gate, *up, *down;   /* gate ends as silu(gate) * up, in place like the reference's modules */
+    void* out;                  /* h + down: the block's output rows */
+} gten_hip_block_desc;
+int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos);
+/* 0: gten_hip_block_rows answers GTEN_HIP_NOT_HANDLED for everything (the modules run one by one; tests compare the two);
+ * the environment variable GTEN_HIP_NO_BLOCK_ROWS=1 sets the same at start */
+int gten_hip_set_block_rows(int on);
+
 /* ---- single-token decode fast path -------------------------------------
  * One call = one decoded token = TinyLlama::logits(tokens, start_pos = n-1)
  * (tinyllama.cpp:45-61) plus the greedy argmax of tinyllama.cpp:416-424, for a

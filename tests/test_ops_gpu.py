@@ -305,3 +305,23 @@ def test_q8_scale_arithmetic_is_ieee(hip):
     bad_div, bad_recip = hip.selftest_q8scale()
     assert bad_div == 0
     assert bad_recip == 0
+
+
+def test_rms_norm_wave_kernel_is_bit_identical_to_the_row_kernel(hip, oracle):
+    """2048-wide Q8 rows, four or more at a time, take the one-wave-per-row kernel: same sum tree, same bytes as the
+    workgroup-per-row kernel that single rows take"""
+    r = rng(77)
+    n, d = 37, 2048
+    x, _ = act_rows(oracle, r, n, d, Q8, scale=3.0)
+    x[5] = x[6]                                           # a repeated row
+    w = (1 + 0.1 * r.standard_normal(d)).astype(np.float16)
+    xd, wdv = hip.upload(x), hip.upload(w)
+    many = hip.upload(np.zeros_like(x))
+    one = hip.upload(np.zeros_like(x))
+    hip.rms_norm(xd, Q8, wdv, many, n, d, 0)
+    for row in range(n):
+        hip.rms_norm(xd, Q8, wdv, one, row + 1, d, row)
+    assert np.array_equal(many.download(shape=x.shape), one.download(shape=x.shape))
+    want = np.zeros_like(x)
+    oracle.rms_norm(x, Q8, w, want, n, d, 0)
+    compare_rows(many.download(shape=x.shape), want, Q8, d, "rms_norm wave kernel")

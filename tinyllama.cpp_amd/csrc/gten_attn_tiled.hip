@@ -105,7 +105,7 @@ template <bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_tiled_q8(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
                                                        const uint8_t* __restrict__ v, uint8_t* __restrict__ out,
                                                        size_t q_pitch, size_t kv_pitch, size_t out_pitch,
-                                                       int n_heads, int n_kv, int n, int start_pos)
+                                                       int n_heads, int n_kv, int n, int start_pos, _Float16* __restrict__ a16)
 {
     constexpr int P_BYTES = FAST ? AT_ROWS * AT_PHPITCH * 2 : AT_ROWS * AT_PPITCH * 4;
     constexpr int V_BYTES = FAST ? 64 * AT_VTPITCH * 2 + AT_ROWS * 64 * 4 : AT_VSUB * 64 * 4;
@@ -362,6 +362,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const unsigned b0 = (unsigned)(uint8_t)(int8_t)q8_round(o.x, sc.scale), b1 = (unsigned)(uint8_t)(int8_t)q8_round(o.y, sc.scale);
             *(uint16_t*)(blk + 2 + 2 * (ep & 15)) = (uint16_t)(b0 | (b1 << 8));
             if ((ep & 15) == 0) *(uint16_t*)blk = sc.d16;
+            if (a16) {
+                // the f16 copy the o projection reads (gten_mfma.hip's fragment order: elements 0,2,1,3 of every four)
+                _Float16* ar = a16 + (size_t)(row - start_pos) * (n_heads * 64) + h * 64 + ((2 * ep) & ~3) + (ep & 1);
+                ar[0] = (_Float16)((float)(int)(int8_t)b0 * sc.ddeq);
+                ar[2] = (_Float16)((float)(int)(int8_t)b1 * sc.ddeq);
+            }
         }
     }
 }
@@ -589,15 +595,15 @@ int gten_launch_attn_tiled_f16(const void* q, const void* k, const void* v, void
 }
 
 int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
-                           size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos)
+                           size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos, void* a16)
 {
     const int rows = n - start_pos;
     const dim3 grid(n_heads, (rows + AT_ROWS - 1) / AT_ROWS);
     if (gtr::prefill_exact())
         GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_q8<false>, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
-                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos, (_Float16*)nullptr);
     else
         GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_q8<true>, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
-                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos, (_Float16*)a16);
     return 0;
 }

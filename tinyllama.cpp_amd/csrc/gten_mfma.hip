@@ -203,13 +203,33 @@ __global__ __launch_bounds__(256) void k_act_to_f16_x2(const uint8_t* __restrict
     }
 }
 
+// Up to three weight matrices that share ONE input (q | k | v, gate | up) in one launch: column tiles [tile0[m], tile0[m+1])
+// belong to matrix m.  resid / sum_out (one matrix, Q8 rows): the residual sum behind the projection, ops::add's arithmetic
+// on the row just rounded -- sum_out = Q8(resid + Q8(W x)).
+struct MatArgs {
+    const void* w[3];
+    uint8_t* out[3];
+    size_t out_pitch[3];
+    int d_out[3];
+    int tile0[3];
+    int n_mats;
+    const uint8_t* resid;
+    uint8_t* sum_out;
+    size_t resid_pitch;
+    // fast form, few workgroups: gridDim.z workgroups share a tile's K loop, each writes its f32 partial sums to plane
+    // blockIdx.z of `partial` ([z][new row][sum of d_out]); k_splitk_finish adds the planes in order and rounds the rows
+    float* partial;
+    int part_pitch;
+    int part_col0[3];
+};
+
 // (2 waves per SIMD = a 256-VGPR budget: the block sums then come back in VGPRs instead of AGPRs, which
 //  would cost four v_accvgpr_read per MFMA in a loop that is bound by VALU issue)
 // a16: f16 activation rows of the NEW rows (row 0 = start_pos), pitch d_in * 2 (quantized) or x itself (f16 weights)
 template <int WT, int WM, int WN, int KB_, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_matmul_mfma(
-    const uint8_t* __restrict__ a16, size_t a_pitch, const float* __restrict__ da_rows, const void* __restrict__ w,
-    uint8_t* __restrict__ out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
+    const uint8_t* __restrict__ a16, size_t a_pitch, const float* __restrict__ da_rows, const MatArgs ms,
+    int out_dtype, int n, int d_in, int start_pos)
 {
     using C = MfmaCfg<WT, WM, WN, KB_>;
     constexpr int BM = C::BM, BN = C::BN, KB = C::KB, APITCH = C::APITCH, WPITCH = C::WPITCH, WROW = C::WROW;
@@ -217,14 +237,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr bool EXACT = QUANT && !FAST;                   // per-block rescale in the scalar build's order
     static_assert(QUANT || !FAST, "the fast form is about quantized weights");
 
+    // which of the (up to three) matrices sharing this input the workgroup's column tile belongs to
+    int mi = 0;
+    if (ms.n_mats > 1 && (int)blockIdx.x >= ms.tile0[1]) mi = 1;
+    if (ms.n_mats > 2 && (int)blockIdx.x >= ms.tile0[2]) mi = 2;
+    const void* __restrict__ w = ms.w[mi];
+    uint8_t* __restrict__ out = ms.out[mi];
+    const size_t out_pitch = ms.out_pitch[mi];
+    const int d_out = ms.d_out[mi];
+
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 1, wc = wid & 1;
     const int g = lane >> 4, l16 = lane & 15;
     const int rows = n - start_pos;
     const int row0 = blockIdx.y * BM;                        // relative to start_pos
-    const int colw = blockIdx.x * BN;                        // first feature of the workgroup
+    const int colw = ((int)blockIdx.x - ms.tile0[mi]) * BN;  // first feature of the workgroup
     const int col0 = colw + wc * 16 * WN;                    // first feature of this wave
     const int nb = d_in >> 5;
-    const int nstage = nb / KB;
+    const int nstage_all = nb / KB;
+    // this workgroup's share of the K loop: stages [s0, s0 + nstage)
+    const int s0 = (int)blockIdx.z * nstage_all / (int)gridDim.z;
+    const int nstage = ((int)blockIdx.z + 1) * nstage_all / (int)gridDim.z - s0;
     const PackedW pw = packed_view(w, WT, d_out, d_in);
     const int nibble_shift = (g < 2) ? 4 : 0;
     unsigned nib_mask = 0x000f000fu;
@@ -327,9 +359,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // Stage s is computed from LDS buffer s & 1 while stage s + 1 waits in registers (stored behind the compute)
     // and stage s + 2 is requested: two stages of memory latency are covered by one stage of work each.
     Raw raw0, raw1;
-    load_stage(0, raw0);
+    load_stage(s0, raw0);
     store_stage(raw0, 0);
-    load_stage(1, raw1);
+    load_stage(s0 + 1, raw1);
     __syncthreads();
 
     auto stage_body = [&](int s, Raw& fetch, const Raw& land) {
@@ -338,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const float* sda = (const float*)(sa + C::A_BYTES);
         const uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
         const float* sdw = (const float*)(sw + C::W_BYTES);
-        load_stage(s + 2, fetch);
+        load_stage(s0 + s + 2, fetch);
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) {
             // ---- operands of this quant block
@@ -358,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         bf[j] = bf[j] * (half8){dh, dh, dh, dh, dh, dh, dh, dh};
                     }
                 } else {
-                    bf[j] = *(const half8*)((const uint16_t*)w + wrow16[j] + (size_t)(s * KB + kb) * 32);
+                    bf[j] = *(const half8*)((const uint16_t*)w + wrow16[j] + (size_t)((s0 + s) * KB + kb) * 32);
                 }
             }
             half8 af[WM];
@@ -411,6 +443,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (s + 1 < nstage) stage_body(s + 1, raw1, raw0);
     }
 
+    if (ms.partial) {
+        // K shared with other workgroups: this one's f32 sums into its plane
+        float* plane = ms.partial + (size_t)blockIdx.z * rows * ms.part_pitch + ms.part_col0[mi];
+#pragma unroll
+        for (int t = 0; t < WM; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = row0 + wr * 16 * WM + 16 * t + 4 * g + i;
+                if (r >= rows) continue;
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int c = col0 + 16 * j + l16;
+                    if (c < d_out) plane[(size_t)r * ms.part_pitch + c] = acc[t][j][i];
+                }
+            }
+        return;
+    }
     // ---- rows written in the output dtype straight from the accumulators (gten/ops.h:73-96)
 #pragma unroll
     for (int t = 0; t < WM; t++) {
@@ -428,9 +477,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     // one 32-wide output block = tiles j, j + 1 of this wave
                     const Q8Scale sc = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(v0), fabsf(v1))));
                     uint8_t* blk = orow + (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
-                    if (ok0) blk[2 + l16] = (uint8_t)(int8_t)q8_round(v0, sc.scale);
-                    if (ok1) blk[18 + l16] = (uint8_t)(int8_t)q8_round(v1, sc.scale);
+                    const int q0 = q8_round(v0, sc.scale), q1 = q8_round(v1, sc.scale);
+                    if (ok0) blk[2 + l16] = (uint8_t)(int8_t)q0;
+                    if (ok1) blk[18 + l16] = (uint8_t)(int8_t)q1;
                     if (ok0 && l16 == 0) *(uint16_t*)blk = sc.d16;
+                    if (ms.resid) {
+                        // ops::add on the block just stored (gten/ops.h:816-860 via k_elementwise's arithmetic): both operands
+                        // dequantized from their stored bytes, f32 sum, rounded to a Q8 block again
+                        const size_t boff = (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
+                        const uint8_t* rb = ms.resid + (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch + boff;
+                        const float dr = h2f(*(const uint16_t*)rb), dq = sc.ddeq;
+                        const float s0 = ok0 ? (float)(int)(int8_t)rb[2 + l16] * dr + (float)q0 * dq : 0.f;
+                        const float s1 = ok1 ? (float)(int)(int8_t)rb[18 + l16] * dr + (float)q1 * dq : 0.f;
+                        const Q8Scale ss = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(s0), fabsf(s1))));
+                        uint8_t* sb = ms.sum_out + (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch + boff;
+                        if (ok0) sb[2 + l16] = (uint8_t)(int8_t)q8_round(s0, ss.scale);
+                        if (ok1) sb[18 + l16] = (uint8_t)(int8_t)q8_round(s1, ss.scale);
+                        if (ok0 && l16 == 0) *(uint16_t*)sb = ss.d16;
+                    }
                 } else if (out_dtype == GTEN_F16) {
                     if (ok0) ((uint16_t*)orow)[c0] = f2h(v0);
                     if (ok1) ((uint16_t*)orow)[c1] = f2h(v1);
@@ -440,6 +504,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 }
             }
         }
+    }
+}
+
+// The planes of a shared K loop -> rows: per element the planes are added in order (((p0 + p1) + p2) + p3), then the row
+// is rounded exactly as k_matmul_mfma's own epilogue rounds it (Q8 block of 32 = 32 lanes; the residual sum behind it).
+__global__ __launch_bounds__(256) void k_splitk_finish(const MatArgs ms, int n_planes, int rows, int start_pos)
+{
+    const int nbo = ms.part_pitch >> 5;                                           // Q8 blocks per row over all matrices of the launch
+    const int gb = blockIdx.x * 8 + (threadIdx.x >> 5), e = threadIdx.x & 31;     // one Q8 block per 32 lanes
+    if (gb >= rows * nbo) return;
+    const int r = gb / nbo, bg = gb - r * nbo;
+    int mi = 0;
+    if (ms.n_mats > 1 && bg * 32 >= ms.part_col0[1]) mi = 1;
+    if (ms.n_mats > 2 && bg * 32 >= ms.part_col0[2]) mi = 2;
+    const int b = bg - (ms.part_col0[mi] >> 5);
+    const float* p = ms.partial + (size_t)r * ms.part_pitch + bg * 32 + e;
+    float v = p[0];
+    for (int z = 1; z < n_planes; z++) v = v + p[(size_t)z * rows * ms.part_pitch];
+    const Q8Scale sc = q8_scale_from_absmax(group_max<32>(fabsf(v)));
+    const int qv = q8_round(v, sc.scale);
+    uint8_t* blk = ms.out[mi] + (size_t)(start_pos + r) * ms.out_pitch[mi] + (size_t)b * GTEN_Q8_BYTES;
+    blk[2 + e] = (uint8_t)(int8_t)qv;
+    if (e == 0) *(uint16_t*)blk = sc.d16;
+    if (ms.resid) {
+        const uint8_t* rb = ms.resid + (size_t)(start_pos + r) * ms.resid_pitch + (size_t)b * GTEN_Q8_BYTES;
+        const float sv = (float)(int)(int8_t)rb[2 + e] * h2f(*(const uint16_t*)rb) + (float)qv * sc.ddeq;
+        const Q8Scale ss = q8_scale_from_absmax(group_max<32>(fabsf(sv)));
+        uint8_t* sb = ms.sum_out + (size_t)(start_pos + r) * ms.resid_pitch + (size_t)b * GTEN_Q8_BYTES;
+        sb[2 + e] = (uint8_t)(int8_t)q8_round(sv, ss.scale);
+        if (e == 0) *(uint16_t*)sb = ss.d16;
     }
 }
 
@@ -466,9 +560,64 @@ static int act_scratch(size_t a_bytes, size_t d_bytes, uint8_t** a16, float** da
     return 0;
 }
 
+static int partial_scratch(size_t bytes, float** out)
+{
+    using namespace gtr;
+    static float* buf = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        if (buf) { GTR_CHECK(hipStreamSynchronize(stream())); GTR_CHECK(hipFree(buf)); }
+        buf = nullptr; cap = 0;
+        GTR_CHECK(hipMalloc((void**)&buf, bytes + bytes / 2));
+        cap = bytes + bytes / 2;
+    }
+    *out = buf;
+    return 0;
+}
+
+static bool splitk_enabled()
+{
+    static const bool on = [] { const char* e = std::getenv("GTEN_HIP_MFMA_SPLITK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// measured, whole prompts of 16 / 64 / 256 / 512 ids (q4): 3.09 / 3.67 / 4.26 / 5.21 ms without sharing, 2.22 / 2.55 / 3.59 /
+// 5.09 ms with these factors (twice the factors: 3.79 ms at 256 ids; sharing the wide gate | up loops too: no gain)
+static int splitk_factor(int rows, int d_in, int d_out)
+{
+    if (rows > 512 || d_out > 2560 || d_out % 32 != 0) return 1;
+    return (d_in >= 4096 ? 4 : 2) * (rows <= 128 ? 2 : 1);
+}
+
+// the f16 copy of rows [start_pos, n) of a Q8 activation matrix (fast form: deltas folded in); gten_mfma_convert
+static int convert_rows(const void* x, size_t x_pitch, int n, int d_in, int start_pos, bool fast, uint8_t** buf_out, float** da_out)
+{
+    using namespace gtr;
+    const int rows = n - start_pos, nb = d_in / 32;
+    uint8_t* buf = nullptr;
+    float* da = nullptr;
+    if (int rc = act_scratch((size_t)rows * d_in * 2, (size_t)rows * nb * 4, &buf, &da)) return rc;
+    const bool x2 = nb % 2 == 0 && x_pitch % 4 == 0 && ((uintptr_t)x % 4) == 0;
+    const dim3 grid(x2 ? (rows * (nb / 2) + 255) / 256 : (rows * nb + 255) / 256);
+    if (fast) {
+        if (x2) GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16_x2<true>, grid, dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos, (uint4*)buf, da);
+        else GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16<true>, grid, dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos, (uint4*)buf, da);
+    } else {
+        if (x2) GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16_x2<false>, grid, dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos, (uint4*)buf, da);
+        else GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16<false>, grid, dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos, (uint4*)buf, da);
+    }
+    *buf_out = buf; *da_out = da;
+    return 0;
+}
+
+// the scratch as the last convert_rows left it (the caller vouches that it holds THIS input: gten_block.hip)
+static int converted_rows(int rows, int d_in, uint8_t** buf_out, float** da_out)
+{
+    return act_scratch((size_t)rows * d_in * 2, (size_t)rows * (d_in / 32) * 4, buf_out, da_out);
+}
+
 template <int WT, int WM, int WN, bool FAST, int KB_ = 4>
-static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, int out_dtype, size_t out_pitch,
-                      int n, int d_in, int d_out, int start_pos)
+static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int out_dtype, int n, int d_in, int start_pos, bool converted)
 {
     using namespace gtr;
     using C = MfmaCfg<WT, WM, WN, KB_>;
@@ -477,24 +626,47 @@ static int launch_cfg(const void* x, size_t x_pitch, const void* w, void* out, i
         GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem()));
         attr_set = true;
     }
-    const int rows = n - start_pos, nb = d_in / 32;
+    const int rows = n - start_pos;
     const uint8_t* a16 = (const uint8_t*)x + (size_t)start_pos * x_pitch;
     size_t a_pitch = x_pitch;
     float* da = nullptr;
     if (C::QUANT) {
         uint8_t* buf = nullptr;
-        if (int rc = act_scratch((size_t)rows * d_in * 2, (size_t)rows * nb * 4, &buf, &da)) return rc;
-        if (nb % 2 == 0 && x_pitch % 4 == 0 && ((uintptr_t)x % 4) == 0)
-            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16_x2<FAST>, dim3((rows * (nb / 2) + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb,
-                       start_pos, (uint4*)buf, da);
-        else
-            GTR_LAUNCH(KT_MATMUL_MFMA, k_act_to_f16<FAST>, dim3((rows * nb + 255) / 256), dim3(256), 0, (const uint8_t*)x, x_pitch, rows, nb, start_pos,
-                       (uint4*)buf, da);
+        if (int rc = converted ? converted_rows(rows, d_in, &buf, &da) : convert_rows(x, x_pitch, n, d_in, start_pos, FAST, &buf, &da)) return rc;
         a16 = buf; a_pitch = (size_t)d_in * 2;
     }
-    const dim3 grid((d_out + C::BN - 1) / C::BN, (rows + C::BM - 1) / C::BM), block(256);
-    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, C::smem(), a16, a_pitch, (const float*)da, w, (uint8_t*)out,
-               out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    MatArgs ms{};
+    int tiles = 0;
+    for (int k = 0; k < m.n; k++) {
+        ms.w[k] = m.w[k]; ms.out[k] = (uint8_t*)m.out[k]; ms.out_pitch[k] = m.out_pitch[k]; ms.d_out[k] = m.d_out[k]; ms.tile0[k] = tiles;
+        tiles += (m.d_out[k] + C::BN - 1) / C::BN;
+    }
+    ms.n_mats = m.n;
+    ms.resid = (const uint8_t*)m.resid; ms.sum_out = (uint8_t*)m.sum_out; ms.resid_pitch = m.resid_pitch;
+    // Few new rows and narrow outputs leave most CUs without a workgroup and every workgroup alone with a long K loop whose
+    // loads it cannot cover: the K loop is then shared by 2 (4 for d_in >= 4096) workgroups.  The factor depends on (rows,
+    // d_in, d_out of the matrix) only, so a matrix gets the same sums whether it is launched alone or beside its siblings.
+    int ks = 1;
+    if (FAST && out_dtype == GTEN_Q8 && splitk_enabled()) {
+        ks = splitk_factor(rows, d_in, m.d_out[0]);
+        for (int k = 1; k < m.n; k++)
+            if (splitk_factor(rows, d_in, m.d_out[k]) != ks) ks = 0;              // (mixed: the caller launches them one by one)
+        GTR_REQUIRE(ks != 0, "matmul: matrices of one launch disagree about sharing the K loop");
+        if ((d_in / 32 / C::KB) < 2 * ks) ks = 1;
+    }
+    const dim3 grid(tiles, (rows + C::BM - 1) / C::BM, ks), block(256);
+    if (ks > 1) {
+        int cols = 0;
+        for (int k = 0; k < m.n; k++) { ms.part_col0[k] = cols; cols += (m.d_out[k] + 31) & ~31; }
+        float* planes = nullptr;
+        if (int rc = partial_scratch((size_t)ks * rows * cols * 4, &planes)) return rc;
+        ms.partial = planes; ms.part_pitch = cols;
+        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+        const int blocks = rows * (cols / 32);
+        GTR_LAUNCH(KT_MATMUL_MFMA, k_splitk_finish, dim3((blocks + 7) / 8), dim3(256), 0, ms, ks, rows, start_pos);
+        return 0;
+    }
+    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
     return 0;
 }
 
@@ -503,22 +675,26 @@ static bool g_prefill_exact = false;
 
 // the largest tile that still gives the chip enough workgroups
 template <int WT, bool FAST>
-static int launch_wt(const void* x, size_t x_pitch, const void* w, void* out, int out_dtype, size_t out_pitch,
-                     int n, int d_in, int d_out, int start_pos)
+static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int out_dtype, int n, int d_in, int start_pos, bool converted)
 {
     const int rows = n - start_pos;
-    auto wgs = [&](int bm, int bn) { return ((d_out + bn - 1) / bn) * ((rows + bm - 1) / bm); };
-#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos)
+    auto wgs = [&](int bm, int bn) {
+        int t = 0;
+        for (int k = 0; k < m.n; k++) t += (m.d_out[k] + bn - 1) / bn;
+        return t * ((rows + bm - 1) / bm);
+    };
+#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted)
     // (exact form, measured at 2048 rows, q4, W.x total: <2,4> 14.2 ms | <2,2> 15.3 | <4,2> 19.3 | <4,4> 26.2 | <2,4> with
     //  2-block stages 15.3: the 4-row-tile variants fit one workgroup per CU only, and occupancy matters more than the
     //  amortised nibble expansion once the kernel is VALU-bound at 2 waves per SIMD)
     if constexpr (FAST) {
         // 128 x 128 outputs per workgroup on two-block stages (two workgroups per CU): 2048 rows, q4, W.x total 10.7 ms against
         // 11.6 for <2,4> on four-block stages and 12.5 for <4,4> on four-block stages (one workgroup per CU)
-        if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+        if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
     }
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
-    if (rows > 32) MF_GO(2, 2);
+    static const int small_t = [] { const char* e = std::getenv("GTEN_HIP_MFMA_SMALL"); return e ? atoi(e) : 0; }();
+    if (rows > 32 && wgs(64, 64) >= small_t) MF_GO(2, 2);
     MF_GO(1, 2);
 #undef MF_GO
 }
@@ -531,15 +707,36 @@ extern "C" int gten_hip_set_prefill_exact(int on)
     return 0;
 }
 
+int gten_launch_matmul_mfma_multi(const void* x, size_t x_pitch, int w_dtype, const gtr::MfmaMats& m, int out_dtype,
+                                  int n, int d_in, int start_pos, bool converted)
+{
+    if (w_dtype == GTEN_F16) return launch_wt<GTEN_F16, false>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
+    if (g_prefill_exact) {
+        if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8, false>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
+        return launch_wt<GTEN_Q4, false>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
+    }
+    if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8, true>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
+    return launch_wt<GTEN_Q4, true>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
+}
+
+int gten_mfma_convert(const void* x, size_t x_pitch, int n, int d_in, int start_pos)
+{
+    uint8_t* buf;
+    float* da;
+    return convert_rows(x, x_pitch, n, d_in, start_pos, !g_prefill_exact, &buf, &da);
+}
+
+int gten_mfma_scratch(int rows, int d_max, uint8_t** a16)
+{
+    float* da;
+    return act_scratch((size_t)rows * d_max * 2, (size_t)rows * (d_max / 32) * 4, a16, &da);
+}
+
 int gten_launch_matmul_mfma(const void* x, int x_dtype, size_t x_pitch, const void* w, int w_dtype,
                             void* out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos)
 {
     (void)x_dtype;
-    if (w_dtype == GTEN_F16) return launch_wt<GTEN_F16, false>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-    if (g_prefill_exact) {
-        if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8, false>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-        return launch_wt<GTEN_Q4, false>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-    }
-    if (w_dtype == GTEN_Q8) return launch_wt<GTEN_Q8, true>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
-    return launch_wt<GTEN_Q4, true>(x, x_pitch, w, out, out_dtype, out_pitch, n, d_in, d_out, start_pos);
+    gtr::MfmaMats m{};
+    m.n = 1; m.w[0] = w; m.out[0] = out; m.out_pitch[0] = out_pitch; m.d_out[0] = d_out;
+    return gten_launch_matmul_mfma_multi(x, x_pitch, w_dtype, m, out_dtype, n, d_in, start_pos, false);
 }

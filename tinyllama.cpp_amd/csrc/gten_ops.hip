@@ -147,9 +147,11 @@ __global__ __launch_bounds__(256) void k_matmul(const uint8_t* __restrict__ x, s
 // ------------------------------------------------------------ row-wise ops
 
 // ops::rms_norm, gten/ops.h:762-814: out = x / (sqrt(mean x^2) + 1e-6) * w
+// a16 (Q8 rows, prompt processing): the f16 copy W.x reads -- f16(quant * stored delta) in the fragment order of
+// gten_mfma.hip's k_act_to_f16<FAST> (elements 0,2,1,3 of every four), row 0 = start_pos -- written beside the row itself.
 __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x, int dtype, size_t x_pitch,
                                                   const uint16_t* __restrict__ w, uint8_t* __restrict__ out,
-                                                  size_t out_pitch, int d, int start_pos)
+                                                  size_t out_pitch, int d, int start_pos, _Float16* __restrict__ a16)
 {
     float* red = (float*)g_smem;
     float* v = (float*)(g_smem + 64);
@@ -163,7 +165,108 @@ __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x,
     const float inv = recip_rn(sqrtf(ss / (float)d) + 1e-6f);      // == 1.0f / (...): correctly rounded either way
     for (int i = threadIdx.x; i < d; i += blockDim.x) v[i] = v[i] * inv * h2f(w[i]);
     __syncthreads();
+    if (a16) {
+        // store_row's Q8 branch, with the rounded value kept for the f16 copy
+        uint8_t* orow = out + (size_t)r * out_pitch;
+        _Float16* arow = a16 + (size_t)blockIdx.x * d;
+        for (int i = threadIdx.x; i < d; i += blockDim.x) {
+            const float xv = v[i];
+            const Q8Scale s = q8_scale_from_absmax(group_max<32>(fabsf(xv)));
+            const int qv = q8_round(xv, s.scale);
+            uint8_t* blk = orow + (size_t)(i >> 5) * GTEN_Q8_BYTES;
+            blk[2 + (i & 31)] = (uint8_t)(int8_t)qv;
+            if ((i & 31) == 0) *(uint16_t*)blk = s.d16;
+            arow[(i & ~3) + ((i & 1) << 1) + ((i >> 1) & 1)] = (_Float16)((float)qv * s.ddeq);
+        }
+        return;
+    }
     store_row(v, dtype, d, out + (size_t)r * out_pitch);
+}
+
+// The same operator for Q8 rows of exactly 64 blocks (n_embd 2048), ONE WAVE per row: lane L owns block L -- its 34 bytes
+// arrive as nine dwords, the row lives in registers, and the only cross-lane steps are the sum tree and one delta handed
+// to the neighbour for the straddling dword of a block pair.  The sum of squares is k_rms_norm's tree exactly: a lane's
+// 32 elements are leaves 4L .. 4L+3 of the balanced tree over 256 eight-element partials, reduced in the lane, then
+// wave_sum continues the same tree over the lanes -- bit-identical rows (tests/test_ops_gpu.py compares the two kernels).
+__global__ __launch_bounds__(64) void k_rms_norm_q8w(const uint8_t* __restrict__ x, size_t x_pitch, const uint16_t* __restrict__ w,
+                                                     uint8_t* __restrict__ out, size_t out_pitch, int start_pos, uint4* __restrict__ a16)
+{
+    constexpr int D = 2048;
+    const int L = threadIdx.x, odd = L & 1;
+    const int r = start_pos + blockIdx.x;
+    const unsigned* pw = (const unsigned*)(x + (size_t)r * x_pitch + (size_t)(L >> 1) * 68) + (odd ? 8 : 0);
+    unsigned dw[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) dw[j] = pw[j];
+    uint4 wq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wq[j] = ((const uint4*)(w + L * 32))[j];
+    const float dx = odd ? h2f((uint16_t)(dw[0] >> 16)) : h2f((uint16_t)(dw[0] & 0xffffu));
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned q = odd ? dw[1 + j] : __builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[4 * j + i] = (float)(int)(int8_t)(q >> (8 * i)) * dx;
+    }
+    float part[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float t8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t8[i] = v[8 * k + i];
+        part[k] = sumsq_tree8(t8);
+    }
+    const float ss = wave_sum((part[0] + part[1]) + (part[2] + part[3]));
+    const float inv = recip_rn(sqrtf(ss / (float)D) + 1e-6f);
+    const unsigned* wh = (const unsigned*)wq;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint16_t wb = (uint16_t)((i & 1) ? (wh[i >> 1] >> 16) : (wh[i >> 1] & 0xffffu));
+        v[i] = v[i] * inv * h2f(wb);
+        amax = fmaxf(amax, fabsf(v[i]));
+    }
+    const Q8Scale sc = q8_scale_from_absmax(amax);
+    unsigned pq[8], hw[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        unsigned wd = 0;
+        unsigned short hq[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int qv = q8_round(v[4 * j + i], sc.scale);
+            wd |= ((unsigned)qv & 0xffu) << (8 * i);
+            hq[i] = f2h((float)qv * sc.ddeq);
+        }
+        pq[j] = wd;
+        hw[2 * j] = (unsigned)hq[0] | ((unsigned)hq[2] << 16);
+        hw[2 * j + 1] = (unsigned)hq[1] | ((unsigned)hq[3] << 16);
+    }
+    // the pair's 17 dwords: the even lane writes [d0 | q0 | d1] (dwords 0..8), the odd lane its quants (dwords 9..16)
+    const unsigned d_next = (unsigned)__shfl_down((int)sc.d16, 1, 64);
+    unsigned* op = (unsigned*)(out + (size_t)r * out_pitch + (size_t)(L >> 1) * 68);
+    if (!odd) {
+        op[0] = (unsigned)sc.d16 | (pq[0] << 16);
+#pragma unroll
+        for (int j = 1; j < 8; j++) op[j] = (pq[j - 1] >> 16) | (pq[j] << 16);
+        op[8] = (pq[7] >> 16) | (d_next << 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) op[9 + j] = pq[j];
+    }
+    if (a16) {
+        uint4* dst = a16 + ((size_t)blockIdx.x * 64 + L) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[j] = make_uint4(hw[4 * j], hw[4 * j + 1], hw[4 * j + 2], hw[4 * j + 3]);
+    }
+}
+
+// rows this kernel takes: Q8, 2048 wide, 4-byte aligned pairs
+static bool rms_norm_q8w_ok(const void* x, size_t x_pitch, const void* w, const void* out, size_t out_pitch, int dtype, int d)
+{
+    return dtype == GTEN_Q8 && d == 2048 && x_pitch % 4 == 0 && out_pitch % 4 == 0 && ((uintptr_t)x & 3) == 0 && ((uintptr_t)out & 3) == 0 &&
+           ((uintptr_t)w & 15) == 0;
 }
 
 // ops::rotary_emb, gten/ops.h:714-760 (rotate-half pairing, position = row)
@@ -182,6 +285,29 @@ __global__ __launch_bounds__(256) void k_rope(uint8_t* __restrict__ x, int dtype
         const float x0 = v[h * d_head + j], x1 = v[h * d_head + j + half];
         v[h * d_head + j] = x0 * cs.x - x1 * cs.y;
         v[h * d_head + j + half] = x0 * cs.y + x1 * cs.x;
+    }
+    __syncthreads();
+    store_row(v, dtype, d, row);
+}
+
+// the same for TWO matrices in one launch (q and k of a prompt: blockIdx.y picks the matrix)
+__global__ __launch_bounds__(256) void k_rope2(uint8_t* __restrict__ x0, size_t pitch0, int d0, uint8_t* __restrict__ x1, size_t pitch1, int d1,
+                                               int dtype, int d_head, int start_pos, const float2* __restrict__ table)
+{
+    float* v = (float*)g_smem;
+    const int r = start_pos + blockIdx.x;
+    const bool second = blockIdx.y != 0;
+    const int d = second ? d1 : d0;
+    uint8_t* row = second ? x1 + (size_t)r * pitch1 : x0 + (size_t)r * pitch0;
+    load_row_f32(row, dtype, d, v);
+    __syncthreads();
+    const int half = d_head >> 1;
+    for (int i = threadIdx.x; i < (d >> 1); i += blockDim.x) {
+        const int h = i / half, j = i % half;
+        const float2 cs = table[(size_t)r * half + j];
+        const float x0v = v[h * d_head + j], x1v = v[h * d_head + j + half];
+        v[h * d_head + j] = x0v * cs.x - x1v * cs.y;
+        v[h * d_head + j + half] = x0v * cs.y + x1v * cs.x;
     }
     __syncthreads();
     store_row(v, dtype, d, row);
@@ -273,6 +399,91 @@ __global__ __launch_bounds__(256) void k_elementwise_q8x2(const uint8_t* __restr
 #pragma unroll
     for (int j = 0; j < 8; j++) ow[9 + j] = pq[1][j];
     unsigned* op = (unsigned*)(out + off);
+#pragma unroll
+    for (int j = 0; j < 17; j++) op[j] = ow[j];
+}
+
+// silu_inplace(gate) followed by mul_inplace(gate, up) (gten/modules.cpp:244-249) in ONE pass over Q8 block pairs: the
+// silu values are rounded to their Q8 block exactly as the first operator stores them, dequantized again, multiplied and
+// rounded to the block the second operator stores -- the bytes `gate` ends with are those of the two launches.
+__global__ __launch_bounds__(256) void k_silu_mul_q8x2(uint8_t* gate, const uint8_t* __restrict__ up, size_t pitch, int pairs_per_row,
+                                                       int start_pos, int total_pairs, uint4* __restrict__ a16)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_pairs) return;
+    const int r = start_pos + gid / pairs_per_row, pr = gid % pairs_per_row;
+    const size_t off = (size_t)r * pitch + (size_t)pr * 68;
+    unsigned aw[17], bw[17];
+    const unsigned* ap = (const unsigned*)(gate + off);
+    const unsigned* bp = (const unsigned*)(up + off);
+#pragma unroll
+    for (int j = 0; j < 17; j++) aw[j] = ap[j];
+#pragma unroll
+    for (int j = 0; j < 17; j++) bw[j] = bp[j];
+    unsigned ow[17];
+    unsigned d16o[2];
+    unsigned pq[2][8];
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const float da = blk ? h2f((uint16_t)(aw[8] >> 16)) : h2f((uint16_t)(aw[0] & 0xffffu));
+        const float db = blk ? h2f((uint16_t)(bw[8] >> 16)) : h2f((uint16_t)(bw[0] & 0xffffu));
+        float v[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned qa = blk ? aw[9 + j] : __builtin_amdgcn_alignbit(aw[j + 1], aw[j], 16);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float xa = (float)(int)(int8_t)(qa >> (8 * i)) * da;
+                const float o = xa / (1.0f + expf(-xa));
+                v[4 * j + i] = o;
+                amax = fmaxf(amax, fabsf(o));
+            }
+        }
+        const Q8Scale s1 = q8_scale_from_absmax(amax);
+        const float ds = s1.ddeq;
+        amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned qb = blk ? bw[9 + j] : __builtin_amdgcn_alignbit(bw[j + 1], bw[j], 16);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float xs = (float)q8_round(v[4 * j + i], s1.scale) * ds;
+                const float o = xs * ((float)(int)(int8_t)(qb >> (8 * i)) * db);
+                v[4 * j + i] = o;
+                amax = fmaxf(amax, fabsf(o));
+            }
+        }
+        const Q8Scale sc = q8_scale_from_absmax(amax);
+        d16o[blk] = sc.d16;
+        unsigned hw[16];                                          // the block as f16(quant * delta), elements 0,2,1,3 of every four
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned w = 0;
+            unsigned short hq[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int qv = q8_round(v[4 * j + i], sc.scale);
+                w |= ((unsigned)qv & 0xffu) << (8 * i);
+                hq[i] = f2h((float)qv * sc.ddeq);
+            }
+            pq[blk][j] = w;
+            hw[2 * j] = (unsigned)hq[0] | ((unsigned)hq[2] << 16);
+            hw[2 * j + 1] = (unsigned)hq[1] | ((unsigned)hq[3] << 16);
+        }
+        if (a16) {
+            uint4* dst = a16 + ((size_t)(gid / pairs_per_row) * (2 * pairs_per_row) + 2 * pr + blk) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) dst[j] = make_uint4(hw[4 * j], hw[4 * j + 1], hw[4 * j + 2], hw[4 * j + 3]);
+        }
+    }
+    ow[0] = d16o[0] | (pq[0][0] << 16);
+#pragma unroll
+    for (int j = 1; j < 8; j++) ow[j] = (pq[0][j - 1] >> 16) | (pq[0][j] << 16);
+    ow[8] = (pq[0][7] >> 16) | (d16o[1] << 16);
+#pragma unroll
+    for (int j = 0; j < 8; j++) ow[9 + j] = pq[1][j];
+    unsigned* op = (unsigned*)(gate + off);
 #pragma unroll
     for (int j = 0; j < 17; j++) op[j] = ow[j];
 }
@@ -524,8 +735,14 @@ int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f1
     GTR_NEED_INIT();
     if (int rc = check_rowwise("rms_norm", x, out, dtype, x_pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(w_f16 && out_pitch >= gten_hip_row_bytes(dtype, d), "rms_norm: bad weight/output");
+    static const bool no_w = [] { const char* e = std::getenv("GTEN_HIP_NO_WAVE_NORM"); return e && e[0] == '1'; }();
+    if (!no_w && n - start_pos >= 4 && rms_norm_q8w_ok(x, x_pitch, w_f16, out, out_pitch, dtype, d)) {
+        GTR_LAUNCH(KT_RMSNORM, k_rms_norm_q8w, dim3(n - start_pos), dim3(64), 0, (const uint8_t*)x, x_pitch, (const uint16_t*)w_f16, (uint8_t*)out, out_pitch,
+                   start_pos, (uint4*)nullptr);
+        return 0;
+    }
     GTR_LAUNCH(KT_RMSNORM, k_rms_norm, dim3(n - start_pos), dim3(256), 64 + (size_t)d * 4,
-                       (const uint8_t*)x, dtype, x_pitch, (const uint16_t*)w_f16, (uint8_t*)out, out_pitch, d, start_pos);
+                       (const uint8_t*)x, dtype, x_pitch, (const uint16_t*)w_f16, (uint8_t*)out, out_pitch, d, start_pos, (_Float16*)nullptr);
     return 0;
 }
 
@@ -603,6 +820,98 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
     GTR_LAUNCH(KT_ATTN, k_attn, dim3(n_heads, n - start_pos), dim3(256), smem,
                        (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v, (uint8_t*)out, dtype,
                        q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, d_head, start_pos, p_cap);
+    return 0;
+}
+
+static bool g_block_rows = [] { const char* e = std::getenv("GTEN_HIP_NO_BLOCK_ROWS"); return !(e && e[0] == '1'); }();
+
+int gten_hip_set_block_rows(int on)
+{
+    g_block_rows = on != 0;
+    return 0;
+}
+
+// One AttentionBlock over MANY new rows (gten/modules.cpp:224-254) in 9 launches (12 in the exact form) instead of the 23 of the module-by-module
+// sequence: the f16 copy of an input is made once for the matrices that share it, q | k | v and gate | up are one W.x launch
+// each, q and k are rotated in one launch, silu and the product are one pass, and the two residual sums ride in the
+// epilogues of the o and down projections.  Every buffer ends with the bytes the module sequence leaves in it.
+int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(b, "block_rows: null descriptor");
+    const int E = b->n_embd, F = b->n_ffn, rows = n - start_pos;
+    const int dh = b->n_heads > 0 ? E / b->n_heads : 0, KV = dh * b->n_kv_heads;
+    const bool off = !g_block_rows;
+    static const bool no_mfma = [] { const char* e = std::getenv("GTEN_HIP_NO_MFMA"); return e && e[0] == '1'; }();
+    static const bool no_tiled = [] { const char* e = std::getenv("GTEN_HIP_NO_TILED_ATTN"); return e && e[0] == '1'; }();
+    // what this path computes; everything else stays with the operators (the caller falls back on GTEN_HIP_NOT_HANDLED)
+    if (off || no_mfma || no_tiled || b->adtype != GTEN_Q8 || (b->wdtype != GTEN_Q8 && b->wdtype != GTEN_Q4) || rows < GTEN_MFMA_MIN_ROWS ||
+        rows > 65535 || n > GTEN_ROPE_MAX_POS || start_pos < 0 || dh != 64 || E % 128 != 0 || F % 128 != 0 || KV % 32 != 0 || (F / 32) % 2 != 0 ||
+        b->n_heads % b->n_kv_heads != 0)
+        return GTEN_HIP_NOT_HANDLED;
+    const void* ptrs[] = {b->attn_norm_w, b->wq, b->wk, b->wv, b->wo, b->ffn_norm_w, b->wgate, b->wup, b->wdown, b->inp, b->attn_norm_out,
+                          b->q, b->k, b->v, b->attn_out, b->o, b->h, b->ffn_norm_out, b->gate, b->up, b->down, b->out};
+    for (const void* p : ptrs) GTR_REQUIRE(p && ((uintptr_t)p & 3) == 0, "block_rows: null or unaligned pointer");
+    const size_t pE = gten_hip_row_bytes(GTEN_Q8, E), pKV = gten_hip_row_bytes(GTEN_Q8, KV), pF = gten_hip_row_bytes(GTEN_Q8, F);
+    int rc;
+    // fast form: the producers of the W.x inputs write the f16 copy themselves (one launch less per projection input);
+    // exact form: the copy is integers + a delta table, made by its own launch
+    const bool fold = !prefill_exact();
+    _Float16* a16 = nullptr;
+    if (fold && (rc = gten_mfma_scratch(rows, E > F ? E : F, (uint8_t**)&a16))) return rc;
+    auto norm = [&](const void* x, const void* w, void* out) -> int {
+        if (!fold) {
+            if (int e = gten_hip_rms_norm(x, GTEN_Q8, pE, w, out, pE, n, E, start_pos)) return e;
+            return gten_mfma_convert(out, pE, n, E, start_pos);
+        }
+        if (rms_norm_q8w_ok(x, pE, w, out, pE, GTEN_Q8, E))
+            GTR_LAUNCH(KT_RMSNORM, k_rms_norm_q8w, dim3(rows), dim3(64), 0, (const uint8_t*)x, pE, (const uint16_t*)w, (uint8_t*)out, pE, start_pos, (uint4*)a16);
+        else
+            GTR_LAUNCH(KT_RMSNORM, k_rms_norm, dim3(rows), dim3(256), 64 + (size_t)E * 4, (const uint8_t*)x, GTEN_Q8, pE, (const uint16_t*)w, (uint8_t*)out,
+                       pE, E, start_pos, a16);
+        return 0;
+    };
+    // attention half
+    if ((rc = norm(b->inp, b->attn_norm_w, b->attn_norm_out))) return rc;
+    {
+        MfmaMats m;
+        m.n = 3;
+        m.w[0] = b->wq; m.out[0] = b->q; m.out_pitch[0] = pE; m.d_out[0] = E;
+        m.w[1] = b->wk; m.out[1] = b->k; m.out_pitch[1] = pKV; m.d_out[1] = KV;
+        m.w[2] = b->wv; m.out[2] = b->v; m.out_pitch[2] = pKV; m.d_out[2] = KV;
+        if ((rc = gten_launch_matmul_mfma_multi(b->attn_norm_out, pE, b->wdtype, m, GTEN_Q8, n, E, start_pos, true))) return rc;
+    }
+    {
+        const float2* table = nullptr;
+        if ((rc = rope_table(dh, &table))) return rc;
+        GTR_LAUNCH(KT_ROPE, k_rope2, dim3(rows, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q, pE, E, (uint8_t*)b->k, pKV, KV, GTEN_Q8, dh, start_pos, table);
+    }
+    if ((rc = gten_launch_attn_tiled(b->q, b->k, b->v, b->attn_out, pE, pKV, pE, n, b->n_heads, b->n_kv_heads, start_pos, fold ? a16 : nullptr))) return rc;
+    {
+        MfmaMats m;
+        m.n = 1; m.w[0] = b->wo; m.out[0] = b->o; m.out_pitch[0] = pE; m.d_out[0] = E;
+        m.resid = b->inp; m.sum_out = b->h; m.resid_pitch = pE;
+        if ((rc = gten_launch_matmul_mfma_multi(b->attn_out, pE, b->wdtype, m, GTEN_Q8, n, E, start_pos, fold))) return rc;
+    }
+    // feed-forward half
+    if ((rc = norm(b->h, b->ffn_norm_w, b->ffn_norm_out))) return rc;
+    {
+        MfmaMats m;
+        m.n = 2;
+        m.w[0] = b->wgate; m.out[0] = b->gate; m.out_pitch[0] = pF; m.d_out[0] = F;
+        m.w[1] = b->wup; m.out[1] = b->up; m.out_pitch[1] = pF; m.d_out[1] = F;
+        if ((rc = gten_launch_matmul_mfma_multi(b->ffn_norm_out, pE, b->wdtype, m, GTEN_Q8, n, E, start_pos, true))) return rc;
+    }
+    {
+        const int ppr = F / 64, total = rows * ppr;
+        GTR_LAUNCH(KT_ELEMWISE, k_silu_mul_q8x2, dim3((total + 255) / 256), dim3(256), 0, (uint8_t*)b->gate, (const uint8_t*)b->up, pF, ppr, start_pos, total, fold ? (uint4*)a16 : (uint4*)nullptr);
+    }
+    {
+        MfmaMats m;
+        m.n = 1; m.w[0] = b->wdown; m.out[0] = b->down; m.out_pitch[0] = pE; m.d_out[0] = E;
+        m.resid = b->h; m.sum_out = b->out; m.resid_pitch = pE;
+        if ((rc = gten_launch_matmul_mfma_multi(b->gate, pF, b->wdtype, m, GTEN_Q8, n, F, start_pos, fold))) return rc;
+    }
     return 0;
 }
 

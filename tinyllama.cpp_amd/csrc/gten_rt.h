@@ -51,11 +51,32 @@ enum {
 #define GTEN_MFMA_MIN_ROWS 16
 int gten_launch_matmul_mfma(const void* x, int x_dtype, size_t x_pitch, const void* w, int w_dtype,
                             void* out, int out_dtype, size_t out_pitch, int n, int d_in, int d_out, int start_pos);
+// ... up to three matrices sharing the input in ONE launch (q | k | v, gate | up), optionally with the residual sum behind a
+// single Q8 projection (sum_out = Q8(resid + Q8(W x)), ops::add's arithmetic).  `converted`: the f16 copy of exactly these
+// input rows is already in the library's scratch (gten_mfma_convert was the last conversion) -- quantized weights only.
+namespace gtr {
+struct MfmaMats {
+    int n = 1;
+    const void* w[3] = {nullptr, nullptr, nullptr};
+    void* out[3] = {nullptr, nullptr, nullptr};
+    size_t out_pitch[3] = {0, 0, 0};
+    int d_out[3] = {0, 0, 0};
+    const void* resid = nullptr;
+    void* sum_out = nullptr;
+    size_t resid_pitch = 0;
+};
+}
+int gten_launch_matmul_mfma_multi(const void* x, size_t x_pitch, int w_dtype, const gtr::MfmaMats& m, int out_dtype,
+                                  int n, int d_in, int start_pos, bool converted);
+int gten_mfma_convert(const void* x, size_t x_pitch, int n, int d_in, int start_pos);
+// room for the f16 copy of `rows` rows of up to d_max elements; producers that write the copy themselves fill it from row 0
+int gten_mfma_scratch(int rows, int d_max, uint8_t** a16);
 
 // gten_attn_tiled.hip: ops::qkv_attn for >= GTEN_ATTN_TILED_MIN_ROWS new rows (Q8 activations, d_head 64)
 #define GTEN_ATTN_TILED_MIN_ROWS 16
+// (a16, fast form only: also write the rows as the f16 copy the o projection reads -- gten_mfma_scratch)
 int gten_launch_attn_tiled(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
-                           size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos);
+                           size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos, void* a16 = nullptr);
 // ... and for f16 activations (f16 MFMA scores: agrees with the row kernel to f32 summation order, not byte for byte)
 int gten_launch_attn_tiled_f16(const void* q, const void* k, const void* v, void* out, size_t q_pitch, size_t kv_pitch,
                                size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos);

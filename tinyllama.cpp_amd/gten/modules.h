@@ -469,8 +469,55 @@ public:
 private:
     Tensor forward_now(Tensor& inp, const int start_pos)
     {
+        if (inp.dimsize(0) - start_pos >= 16 && forward_rows(inp, start_pos)) return attn_res.acv;
         Tensor h = inp_res.forward(inp, attn.forward(attn_norm.forward(inp, start_pos), start_pos), start_pos);
         return attn_res.forward(h, ffn_forward(ffn_norm.forward(h, start_pos), start_pos), start_pos);
+    }
+
+    // Prompt-sized calls: the whole block as one library call (gten_hip_block_rows: the same kernels composed so that
+    // matrices sharing an input share its launch, 12 launches instead of 23).  Every activation tensor of the modules --
+    // the K / V caches among them -- ends with the bytes the module-by-module sequence above leaves in it.  Returns false
+    // when the library does not take the configuration (fp16 activations, ...): the modules then run one by one.
+    bool forward_rows(Tensor& inp, const int start_pos)
+    {
+        const int n = inp.dimsize(0), E = inp.dimsize(1), F = ffn_gate_proj.weight.dimsize(0), H = attn.n_heads();
+        const Dtype adt = inp.dtype(), wdt = attn.query.weight.dtype();
+        if (!inp.is_2d() || H <= 0 || E % H != 0 || ffn_silu.inplace_ == false) return false;
+        const int dh = E / H, KV = attn.key.weight.dimsize(0);
+        const Linear* lin[] = {&attn.query, &attn.key, &attn.value, &attn.qkv_proj, &ffn_gate_proj, &ffn_up_proj, &ffn_down_proj};
+        for (const Linear* l : lin)
+            if (l->weight.dtype() != wdt || l->acv.dtype() != adt) return false;
+        if (attn_norm.acv.dtype() != adt || ffn_norm.acv.dtype() != adt || inp_res.acv.dtype() != adt || attn_res.acv.dtype() != adt ||
+            attn.qkv_acv.dtype() != adt || KV % dh != 0 || attn.value.weight.dimsize(0) != KV)
+            return false;
+        if (!attn.query.weight.shape_eq({E, E}) || !attn.key.weight.shape_eq({KV, E}) || !attn.qkv_proj.weight.shape_eq({E, E}) ||
+            !ffn_up_proj.weight.shape_eq({F, E}) || !ffn_down_proj.weight.shape_eq({E, F}) || attn_norm.weight.numel() != E || ffn_norm.weight.numel() != E)
+            return false;
+        if (adt != kQint8 || (wdt != kQint8 && wdt != kQint4)) return false;
+        Timer timer{&attn.qkv_proj.exec_time};
+        // the shapes the modules give their outputs
+        attn_norm.acv.resize({n, E}); attn.query.acv.resize({n, E}); attn.key.acv.resize({n, KV}); attn.value.acv.resize({n, KV});
+        attn.qk_acv.resize({H, n, n}); attn.qkv_acv.resize({n, E}); attn.qkv_proj.acv.resize({n, E}); inp_res.acv.resize({n, E});
+        ffn_norm.acv.resize({n, E}); ffn_gate_proj.acv.resize({n, F}); ffn_up_proj.acv.resize({n, F}); ffn_down_proj.acv.resize({n, E});
+        attn_res.acv.resize({n, E});
+        gten_hip_block_desc b{};
+        b.adtype = dtype_code(adt); b.wdtype = dtype_code(wdt);
+        b.n_embd = E; b.n_heads = H; b.n_kv_heads = KV / dh; b.n_ffn = F;
+        b.attn_norm_w = attn_norm.weight.device_weight(); b.ffn_norm_w = ffn_norm.weight.device_weight();
+        b.wq = attn.query.weight.device_weight(); b.wk = attn.key.weight.device_weight(); b.wv = attn.value.weight.device_weight();
+        b.wo = attn.qkv_proj.weight.device_weight();
+        b.wgate = ffn_gate_proj.weight.device_weight(); b.wup = ffn_up_proj.weight.device_weight(); b.wdown = ffn_down_proj.weight.device_weight();
+        b.inp = inp.device_ptr();
+        b.attn_norm_out = attn_norm.acv.device_ptr_mut();
+        b.q = attn.query.acv.device_ptr_mut(); b.k = attn.key.acv.device_ptr_mut(); b.v = attn.value.acv.device_ptr_mut();
+        b.attn_out = attn.qkv_acv.device_ptr_mut(); b.o = attn.qkv_proj.acv.device_ptr_mut(); b.h = inp_res.acv.device_ptr_mut();
+        b.ffn_norm_out = ffn_norm.acv.device_ptr_mut();
+        b.gate = ffn_gate_proj.acv.device_ptr_mut(); b.up = ffn_up_proj.acv.device_ptr_mut(); b.down = ffn_down_proj.acv.device_ptr_mut();
+        b.out = attn_res.acv.device_ptr_mut();
+        const int rc = gten_hip_block_rows(&b, n, start_pos);
+        if (rc == GTEN_HIP_NOT_HANDLED) return false;
+        GTEN_HIP_OK(rc);
+        return true;
     }
 
 public:

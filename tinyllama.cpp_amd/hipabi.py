@@ -69,6 +69,13 @@ class DeviceBuffer:
             pass
 
 
+class BlockDesc(C.Structure):
+    """gten_hip_block_desc (include/gten_hip.h)"""
+    _fields_ = ([(k, C.c_int) for k in ("adtype", "wdtype", "n_embd", "n_heads", "n_kv_heads", "n_ffn")] +
+                [(k, C.c_void_p) for k in ("attn_norm_w", "wq", "wk", "wv", "wo", "ffn_norm_w", "wgate", "wup", "wdown", "inp",
+                                           "attn_norm_out", "q", "k", "v", "attn_out", "o", "h", "ffn_norm_out", "gate", "up", "down", "out")])
+
+
 class GtenHip:
     """Loaded libgten_hip.so with every symbol of include/gten_hip.h bound."""
 
@@ -77,7 +84,7 @@ class GtenHip:
         "gten_hip_malloc", "gten_hip_free", "gten_hip_memset", "gten_hip_memcpy_h2d", "gten_hip_memcpy_d2h",
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
         "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
-        "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
+        "gten_hip_block_rows", "gten_hip_set_block_rows", "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
         "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact",
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
         # the export check covers the whole header
@@ -121,6 +128,8 @@ class GtenHip:
         self._add = _sig(L, "gten_hip_add", ci, [vp, vp, vp, ci, sz, ci, ci, ci])
         self._attn = _sig(L, "gten_hip_qkv_attn", ci, [vp, vp, vp, vp, ci, sz, sz, sz, ci, ci, ci, ci, ci])
         self._prefill_exact = _sig(L, "gten_hip_set_prefill_exact", ci, [ci])
+        self._block_rows = _sig(L, "gten_hip_block_rows", ci, [C.POINTER(BlockDesc), ci, ci])
+        self._set_block_rows = _sig(L, "gten_hip_set_block_rows", ci, [ci])
         self.initialised = False
 
     # -- runtime
@@ -154,6 +163,24 @@ class GtenHip:
     def set_prefill_exact(self, on):
         """prompt-sized W.x with quantized weights: exact form (scalar-build order, bit for bit) instead of the fast one"""
         self._check(self._prefill_exact(1 if on else 0))
+
+    def set_block_rows(self, on):
+        """prompt-sized AttentionBlock calls as one composed call (default) or module by module"""
+        self._check(self._set_block_rows(1 if on else 0))
+
+    def block_rows(self, n, start_pos, ints, bufs):
+        """gten_hip_block_rows: `ints` the six integers of the descriptor, `bufs` name -> DeviceBuffer.
+        Returns False when the library does not take the configuration (GTEN_HIP_NOT_HANDLED)."""
+        d = BlockDesc()
+        for k, v in ints.items():
+            setattr(d, k, int(v))
+        for k, v in bufs.items():
+            setattr(d, k, v.ptr)
+        rc = self._block_rows(C.byref(d), n, start_pos)
+        if rc == 1:
+            return False
+        self._check(rc)
+        return True
 
     def prof_enable(self, on):
         self._check(self._prof_enable(1 if on else 0))
