@@ -28,8 +28,9 @@
 // block is two adjacent 16-wide tiles of the same wave (DPP row maximum).
 //
 // FAST form (the default for quantized weights; gten_hip_set_prefill_exact(1) selects the exact form above): the block
-// deltas are folded into the f16 operands -- activations are expanded once per call to f16(q * da), a weight fragment
-// is multiplied by its block's dw as it leaves LDS (four v_pk_mul_f16) -- and the products accumulate ACROSS the K
+// deltas are folded into the f16 operands -- activations are expanded once per call to f16(q * da), the weight tile is
+// expanded ONCE PER WORKGROUP to f16(q * dw) as its pieces come back from memory and lies in LDS in the activation rows'
+// layout, so the K loop is fragment reads and matrix instructions only -- and the products accumulate ACROSS the K
 // blocks inside the matrix core.  No per-block rescale (12 of the exact form's 21 VALU instructions per MFMA), no
 // separate block-sum registers (so the 4 x 4 register tile fits).  What it costs: each operand element carries one
 // fp16 rounding (relative 2^-11, a fifth of the Q8 quantization step's own noise) and the sum is no longer in the
@@ -130,6 +131,11 @@ struct MfmaCfg {
     static constexpr int A_PIECES = BM * KB * 4 / 256;     // 16-byte pieces of the activation tile per thread
     static constexpr int W_PIECES = QUANT ? (BN * WROW / 16 + 255) / 256 : 0;
     static constexpr size_t smem() { return (size_t)2 * STAGE; }
+    // fast form: the weight tile lies in LDS EXPANDED, f16(quant * delta), rows of KB blocks like the activation rows --
+    // each element is expanded once per workgroup (as its piece comes back from memory), not once per wave and K block
+    static constexpr int W16PITCH = KB * 64 + 16;
+    static constexpr int STAGE_FAST = A_BYTES + BN * W16PITCH;
+    static constexpr size_t smem_fast() { return (size_t)2 * STAGE_FAST; }
 };
 
 // Q8 activation rows [start_pos, n) -> f16 rows in the fragment order (q0,q2,q1,q3 per 4) + f32 block deltas.
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr bool QUANT = C::QUANT;
     constexpr bool EXACT = QUANT && !FAST;                   // per-block rescale in the scalar build's order
     static_assert(QUANT || !FAST, "the fast form is about quantized weights");
+    constexpr int STAGE = FAST ? C::STAGE_FAST : C::STAGE, W16PITCH = C::W16PITCH;
 
     // which of the (up to three) matrices sharing this input the workgroup's column tile belongs to
     int mi = 0;
@@ -303,8 +310,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     // weight deltas: thread -> feature t: KB halves per stage (threads past BN fill padding slots)
     const unsigned dw_src = (unsigned)min(colw + (int)threadIdx.x, d_out - 1) * nb * 2;
+    // fast form: the delta of every PIECE's block (one dword holding it; which half: pd_hi), and where the piece's
+    // expanded elements go
+    unsigned pd_src[WP], pd_hi[WP], w16_dst[WP];
+#pragma unroll
+    for (int k = 0; k < C::W_PIECES; k++) {
+        const int p = threadIdx.x + 256 * k, pr = WROW / 16, f = p / pr, c = p % pr;
+        const unsigned frow = (unsigned)min(colw + f, d_out - 1);
+        const int blk = (WT == GTEN_Q4) ? c : c % KB, pl = (WT == GTEN_Q4) ? 0 : c / KB;
+        const unsigned di = frow * nb + blk;                 // + s * KB per stage: KB is even, the parity is the piece's own
+        pd_src[k] = (di & ~1u) * 2;
+        pd_hi[k] = di & 1u;
+        w16_dst[k] = f * W16PITCH + blk * 64 + pl * 32;
+    }
 
-    struct Raw { v4i_t a[C::A_PIECES]; v4i_t w[WP]; float da[DA_PIECES]; v2i_t dw; };
+    struct Raw { v4i_t a[C::A_PIECES]; v4i_t w[WP]; float da[DA_PIECES]; v2i_t dw; int pd[FAST ? WP : 1]; };
     auto load_stage = [&](int s, Raw& r) {
 #pragma unroll
         for (int k = 0; k < C::A_PIECES; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_src[k], s * (KB * 64), 0);
@@ -315,15 +335,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int k = 0; k < DA_PIECES; k++) r.da[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_da, da_src[k], s * (KB * 4), 0));
             }
-            if (KB == 4) r.dw = __builtin_amdgcn_raw_buffer_load_b64(rs_dw, dw_src, s * (KB * 2), 0);
+            if (FAST) {
+#pragma unroll
+                for (int k = 0; k < C::W_PIECES; k++) r.pd[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_dw, pd_src[k], s * (KB * 2), 0);
+            } else if (KB == 4) r.dw = __builtin_amdgcn_raw_buffer_load_b64(rs_dw, dw_src, s * (KB * 2), 0);
             else r.dw[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_dw, dw_src, s * (KB * 2), 0);
         }
     };
     auto store_stage = [&](const Raw& r, int buf) {
-        uint8_t* sa = g_smem + buf * C::STAGE;
+        uint8_t* sa = g_smem + buf * STAGE;
 #pragma unroll
         for (int k = 0; k < C::A_PIECES; k++) *(v4i_t*)(sa + a_dst[k]) = r.a[k];
-        if (QUANT) {
+        if (FAST) {
+            // a piece = 16 bytes of quants of ONE block: expanded to f16, times the block's delta (one fp16 rounding per
+            // element), in the fragment order of the activation rows
+            uint8_t* sw16 = sa + C::A_BYTES;
+#pragma unroll
+            for (int k = 0; k < C::W_PIECES; k++) {
+                const unsigned dbits = pd_hi[k] ? ((unsigned)r.pd[k] >> 16) : ((unsigned)r.pd[k] & 0xffffu);
+                const unsigned d2 = dbits | (dbits << 16);
+                const uint2 lo = make_uint2((unsigned)r.w[k][0], (unsigned)r.w[k][1]), hi = make_uint2((unsigned)r.w[k][2], (unsigned)r.w[k][3]);
+                half8 e[WT == GTEN_Q4 ? 4 : 2];
+                if (WT == GTEN_Q4) {
+                    e[0] = weight_frag<WT>(lo, 4, nib_mask); e[1] = weight_frag<WT>(hi, 4, nib_mask);      // elements 0..15: high nibbles
+                    e[2] = weight_frag<WT>(lo, 0, nib_mask); e[3] = weight_frag<WT>(hi, 0, nib_mask);      // elements 16..31: low nibbles
+                } else {
+                    e[0] = weight_frag<WT>(lo, 0, nib_mask); e[1] = weight_frag<WT>(hi, 0, nib_mask);
+                }
+#pragma unroll
+                for (int q = 0; q < (WT == GTEN_Q4 ? 4 : 2); q++) {
+                    unsigned u[4];
+                    __builtin_memcpy(u, &e[q], 16);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) u[i] = pk_mul_f16(u[i], d2);
+                    *(v4i_t*)(sw16 + w16_dst[k] + 16 * q) = (v4i_t){(int)u[0], (int)u[1], (int)u[2], (int)u[3]};
+                }
+            }
+        } else if (QUANT) {
             float* sda = (float*)(sa + C::A_BYTES);
             uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
             float* sdw = (float*)(sw + C::W_BYTES);
@@ -366,11 +414,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     auto stage_body = [&](int s, Raw& fetch, const Raw& land) {
         const int buf = s & 1;
-        const uint8_t* sa = g_smem + buf * C::STAGE;
+        const uint8_t* sa = g_smem + buf * STAGE;
         const float* sda = (const float*)(sa + C::A_BYTES);
-        const uint8_t* sw = sa + C::A_BYTES + C::DA_BYTES;
+        const uint8_t* sw = sa + C::A_BYTES + (FAST ? 0 : C::DA_BYTES);      // (fast form: the expanded tile, rows of W16PITCH bytes)
         const float* sdw = (const float*)(sw + C::W_BYTES);
         load_stage(s0 + s + 2, fetch);
+        if constexpr (FAST) {
+            // Fast form: nothing but fragment reads and matrix instructions in the K loop.  The fragments of block kb + 1 are
+            // requested before the matrix instructions of block kb are issued, and the NEXT stage's expansion (store_stage:
+            // vector instructions + LDS writes into the other buffer, last read two barriers ago) sits in front of them, so
+            // the scheduler can slide it into the matrix pipe's shadow instead of running it behind the last MFMA.
+            half8 af[2][WM], bf[2][WN];
+            auto frags = [&](int kb, half8 (&a)[WM], half8 (&b)[WN]) {
+#pragma unroll
+                for (int j = 0; j < WN; j++) b[j] = *(const half8*)(sw + (wc * 16 * WN + 16 * j + l16) * W16PITCH + kb * 64 + g * 16);
+#pragma unroll
+                for (int t = 0; t < WM; t++) a[t] = *(const half8*)(sa + (wr * 16 * WM + 16 * t + l16) * APITCH + kb * 64 + g * 16);
+            };
+            frags(0, af[0], bf[0]);
+            if (s + 1 < nstage) store_stage(land, buf ^ 1);
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) {
+                if (kb + 1 < KB) frags(kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
+#pragma unroll
+                for (int t = 0; t < WM; t++)
+#pragma unroll
+                    for (int j = 0; j < WN; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb & 1][t], bf[kb & 1][j], acc[t][j], 0, 0, 0);
+            }
+            // (measured and not kept: the expansion made unconditional -- one basic block -- and woven between the matrix
+            //  instructions with sched_group_barrier: 2048-id prompt 13.2 -> 15.1 ms)
+            __syncthreads();
+            return;
+        }
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) {
             // ---- operands of this quant block
@@ -378,17 +453,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             float dw[WN];
 #pragma unroll
             for (int j = 0; j < WN; j++) {
-                if (QUANT) {
+                if (FAST) {
+                    bf[j] = *(const half8*)(sw + (wc * 16 * WN + 16 * j + l16) * W16PITCH + kb * 64 + g * 16);
+                } else if (QUANT) {
                     const int f = wc * 16 * WN + 16 * j + l16;
                     const uint2 by = (WT == GTEN_Q4) ? *(const uint2*)(sw + f * WPITCH + kb * 16 + (g & 1) * 8)
                                                      : *(const uint2*)(sw + f * WPITCH + (g >> 1) * (KB * 16) + kb * 16 + (g & 1) * 8);
                     bf[j] = weight_frag<WT>(by, nibble_shift, nib_mask);
                     dw[j] = sdw[kb * 256 + f];
-                    if (FAST) {
-                        // the block's weight delta folded into the fragment (exact f16 value, one rounding per element)
-                        const _Float16 dh = (_Float16)dw[j];
-                        bf[j] = bf[j] * (half8){dh, dh, dh, dh, dh, dh, dh, dh};
-                    }
                 } else {
                     bf[j] = *(const half8*)((const uint16_t*)w + wrow16[j] + (size_t)((s0 + s) * KB + kb) * 32);
                 }
@@ -623,7 +695,7 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
     using C = MfmaCfg<WT, WM, WN, KB_>;
     static bool attr_set = false;
     if (!attr_set) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::smem()));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FAST ? C::smem_fast() : C::smem())));
         attr_set = true;
     }
     const int rows = n - start_pos;
@@ -661,12 +733,12 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
         float* planes = nullptr;
         if (int rc = partial_scratch((size_t)ks * rows * cols * 4, &planes)) return rc;
         ms.partial = planes; ms.part_pitch = cols;
-        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, FAST ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
         const int blocks = rows * (cols / 32);
         GTR_LAUNCH(KT_MATMUL_MFMA, k_splitk_finish, dim3((blocks + 7) / 8), dim3(256), 0, ms, ks, rows, start_pos);
         return 0;
     }
-    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, FAST ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
     return 0;
 }
 
@@ -683,13 +755,16 @@ static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int 
         for (int k = 0; k < m.n; k++) t += (m.d_out[k] + bn - 1) / bn;
         return t * ((rows + bm - 1) / bm);
     };
-#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted)
+    // (fast form: two-block stages for the 128-feature tiles -- the expanded weight tile is four times the packed one)
+#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST, ((FAST && WN_ == 4) ? 2 : 4)>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted)
     // (exact form, measured at 2048 rows, q4, W.x total: <2,4> 14.2 ms | <2,2> 15.3 | <4,2> 19.3 | <4,4> 26.2 | <2,4> with
     //  2-block stages 15.3: the 4-row-tile variants fit one workgroup per CU only, and occupancy matters more than the
     //  amortised nibble expansion once the kernel is VALU-bound at 2 waves per SIMD)
     if constexpr (FAST) {
         // 128 x 128 outputs per workgroup on two-block stages (two workgroups per CU): 2048 rows, q4, W.x total 10.7 ms against
         // 11.6 for <2,4> on four-block stages and 12.5 for <4,4> on four-block stages (one workgroup per CU)
+        // (the 2048-wide projections give exactly 256 of these tiles, one workgroup per CU; 64 x 128 tiles -- 512 workgroups --
+        //  measured the same: 13.0 against 13.2 ms for a 2048-id prompt)
         if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
     }
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
