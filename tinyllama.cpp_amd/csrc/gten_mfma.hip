@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr bool QUANT = C::QUANT;
     constexpr bool EXACT = QUANT && !FAST;                   // per-block rescale in the scalar build's order
     static_assert(QUANT || !FAST, "the fast form is about quantized weights");
-    constexpr int STAGE = FAST ? C::STAGE_FAST : C::STAGE, W16PITCH = C::W16PITCH;
+    // the weight tile lies in LDS as f16 rows in the activation rows' layout: fast form (expanded) and f16 weights (copied)
+    constexpr bool LDSW = FAST || !QUANT;
+    constexpr int STAGE = LDSW ? C::STAGE_FAST : C::STAGE, W16PITCH = C::W16PITCH;
 
     // which of the (up to three) matrices sharing this input the workgroup's column tile belongs to
     int mi = 0;
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     typedef int v2i_t __attribute__((ext_vector_type(2)));
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a16, 0, (int)((size_t)rows * a_pitch), 0x00020000);
     const auto rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)da_rows, 0, QUANT ? rows * nb * 4 : 0, 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)pw.qs, 0, QUANT ? (int)((size_t)d_out * nb * (WT == GTEN_Q4 ? 16 : 32)) : 0, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(QUANT ? (void*)pw.qs : (void*)w, 0,
+                                                        QUANT ? (int)((size_t)d_out * nb * (WT == GTEN_Q4 ? 16 : 32)) : (int)((size_t)d_out * d_in * 2), 0x00020000);
     const auto rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)pw.ds, 0, QUANT ? d_out * nb * 2 : 0, 0x00020000);
     // activations: piece p -> (row p / (KB*4), piece-in-row p % (KB*4)); a stage of a row is KB * 64 contiguous bytes
     unsigned a_src[C::A_PIECES], a_dst[C::A_PIECES];
@@ -297,16 +300,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         da_dst[k] = (p < BM * KB) ? b * BM + r : p;
     }
     // weights: piece p -> (feature p / (WROW/16), piece-in-row); Q8 rows are two planes of nb * 16 bytes
-    constexpr int WP = C::W_PIECES > 0 ? C::W_PIECES : 1;
+    // (f16 weights: a feature's stage is KB * 64 contiguous bytes = KB * 4 pieces, copied as they are)
+    constexpr int NWP = QUANT ? C::W_PIECES : BN * KB * 4 / 256;
+    constexpr int WP = NWP > 0 ? NWP : 1;
     static_assert(!QUANT || BN * (WROW / 16) == C::W_PIECES * 256, "weight tile must be a whole number of pieces per thread");
+    static_assert(QUANT || BN * KB * 4 == NWP * 256, "weight tile must be a whole number of pieces per thread");
     unsigned w_src[WP], w_dst[WP];
 #pragma unroll
-    for (int k = 0; k < C::W_PIECES; k++) {
-        const int p = threadIdx.x + 256 * k, pr = WROW / 16, f = p / pr, c = p % pr;
+    for (int k = 0; k < NWP; k++) {
+        const int p = threadIdx.x + 256 * k, pr = QUANT ? WROW / 16 : KB * 4, f = p / pr, c = p % pr;
         const unsigned frow = (unsigned)min(colw + f, d_out - 1);
         if (WT == GTEN_Q4) w_src[k] = frow * nb * 16 + c * 16;
-        else w_src[k] = frow * nb * 32 + (c / KB) * nb * 16 + (c % KB) * 16;     // plane c / KB, block c % KB
-        w_dst[k] = f * WPITCH + c * 16;
+        else if (WT == GTEN_Q8) w_src[k] = frow * nb * 32 + (c / KB) * nb * 16 + (c % KB) * 16;     // plane c / KB, block c % KB
+        else w_src[k] = frow * (unsigned)d_in * 2 + c * 16;
+        w_dst[k] = QUANT ? f * WPITCH + c * 16 : f * W16PITCH + c * 16;
     }
     // weight deltas: thread -> feature t: KB halves per stage (threads past BN fill padding slots)
     const unsigned dw_src = (unsigned)min(colw + (int)threadIdx.x, d_out - 1) * nb * 2;
@@ -328,6 +335,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     auto load_stage = [&](int s, Raw& r) {
 #pragma unroll
         for (int k = 0; k < C::A_PIECES; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_src[k], s * (KB * 64), 0);
+        if (!QUANT) {
+#pragma unroll
+            for (int k = 0; k < NWP; k++) r.w[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_src[k], s * (KB * 64), 0);
+        }
         if (QUANT) {
 #pragma unroll
             for (int k = 0; k < C::W_PIECES; k++) r.w[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_src[k], s * (KB * 16), 0);
@@ -346,7 +357,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         uint8_t* sa = g_smem + buf * STAGE;
 #pragma unroll
         for (int k = 0; k < C::A_PIECES; k++) *(v4i_t*)(sa + a_dst[k]) = r.a[k];
-        if (FAST) {
+        if (!QUANT) {
+            uint8_t* sw16 = sa + C::A_BYTES;
+#pragma unroll
+            for (int k = 0; k < NWP; k++) *(v4i_t*)(sw16 + w_dst[k]) = r.w[k];
+        } else if (FAST) {
             // a piece = 16 bytes of quants of ONE block: expanded to f16, times the block's delta (one fp16 rounding per
             // element), in the fragment order of the activation rows
             uint8_t* sw16 = sa + C::A_BYTES;
@@ -399,11 +414,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int j = 0; j < WN; j++) acc[t][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    // f16 weights: fragments straight from global memory (16 bytes per lane, 64-byte runs per row)
-    size_t wrow16[WN];
-#pragma unroll
-    for (int j = 0; j < WN; j++) wrow16[j] = (size_t)min(col0 + 16 * j + l16, d_out - 1) * d_in + g * 8;
-
     // Stage s is computed from LDS buffer s & 1 while stage s + 1 waits in registers (stored behind the compute)
     // and stage s + 2 is requested: two stages of memory latency are covered by one stage of work each.
     Raw raw0, raw1;
@@ -416,11 +426,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int buf = s & 1;
         const uint8_t* sa = g_smem + buf * STAGE;
         const float* sda = (const float*)(sa + C::A_BYTES);
-        const uint8_t* sw = sa + C::A_BYTES + (FAST ? 0 : C::DA_BYTES);      // (fast form: the expanded tile, rows of W16PITCH bytes)
+        const uint8_t* sw = sa + C::A_BYTES + (LDSW ? 0 : C::DA_BYTES);      // (fast form / f16 weights: the f16 tile, rows of W16PITCH bytes)
         const float* sdw = (const float*)(sw + C::W_BYTES);
         load_stage(s0 + s + 2, fetch);
-        if constexpr (FAST) {
-            // Fast form: nothing but fragment reads and matrix instructions in the K loop.  The fragments of block kb + 1 are
+        if constexpr (LDSW) {
+            // Fast form (and f16 weights): nothing but fragment reads and matrix instructions in the K loop.  The fragments of block kb + 1 are
             // requested before the matrix instructions of block kb are issued, and the NEXT stage's expansion (store_stage:
             // vector instructions + LDS writes into the other buffer, last read two barriers ago) sits in front of them, so
             // the scheduler can slide it into the matrix pipe's shadow instead of running it behind the last MFMA.
@@ -461,8 +471,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                                                      : *(const uint2*)(sw + f * WPITCH + (g >> 1) * (KB * 16) + kb * 16 + (g & 1) * 8);
                     bf[j] = weight_frag<WT>(by, nibble_shift, nib_mask);
                     dw[j] = sdw[kb * 256 + f];
-                } else {
-                    bf[j] = *(const half8*)((const uint16_t*)w + wrow16[j] + (size_t)((s0 + s) * KB + kb) * 32);
                 }
             }
             half8 af[WM];
@@ -695,7 +703,7 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
     using C = MfmaCfg<WT, WM, WN, KB_>;
     static bool attr_set = false;
     if (!attr_set) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FAST ? C::smem_fast() : C::smem())));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FAST || !C::QUANT) ? C::smem_fast() : C::smem())));
         attr_set = true;
     }
     const int rows = n - start_pos;
@@ -733,12 +741,12 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
         float* planes = nullptr;
         if (int rc = partial_scratch((size_t)ks * rows * cols * 4, &planes)) return rc;
         ms.partial = planes; ms.part_pitch = cols;
-        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, FAST ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, (FAST || !C::QUANT) ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
         const int blocks = rows * (cols / 32);
         GTR_LAUNCH(KT_MATMUL_MFMA, k_splitk_finish, dim3((blocks + 7) / 8), dim3(256), 0, ms, ks, rows, start_pos);
         return 0;
     }
-    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, FAST ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, (FAST || !C::QUANT) ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
     return 0;
 }
 
@@ -756,11 +764,11 @@ static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int 
         return t * ((rows + bm - 1) / bm);
     };
     // (fast form: two-block stages for the 128-feature tiles -- the expanded weight tile is four times the packed one)
-#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST, ((FAST && WN_ == 4) ? 2 : 4)>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted)
+#define MF_GO(WM_, WN_) return launch_cfg<WT, WM_, WN_, FAST, (((FAST || WT == GTEN_F16) && WN_ == 4) ? 2 : 4)>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted)
     // (exact form, measured at 2048 rows, q4, W.x total: <2,4> 14.2 ms | <2,2> 15.3 | <4,2> 19.3 | <4,4> 26.2 | <2,4> with
     //  2-block stages 15.3: the 4-row-tile variants fit one workgroup per CU only, and occupancy matters more than the
     //  amortised nibble expansion once the kernel is VALU-bound at 2 waves per SIMD)
-    if constexpr (FAST) {
+    if constexpr (FAST || WT == GTEN_F16) {
         // 128 x 128 outputs per workgroup on two-block stages (two workgroups per CU): 2048 rows, q4, W.x total 10.7 ms against
         // 11.6 for <2,4> on four-block stages and 12.5 for <4,4> on four-block stages (one workgroup per CU)
         // (the 2048-wide projections give exactly 256 of these tiles, one workgroup per CU; 64 x 128 tiles -- 512 workgroups --
