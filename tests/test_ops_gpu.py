@@ -175,6 +175,34 @@ def test_rowwise_ops_many_rows_block_pair_kernel(hip, oracle, d):
         compare_rows(buf.download(shape=x.shape), want, Q8, d, "silu_inplace", min_exact=0.995)
 
 
+@pytest.mark.parametrize("d", [2048, 5632])
+def test_rowwise_ops_many_rows_f16_vector_kernel(hip, oracle, d):
+    """prompt-sized calls of silu / mul / add on f16 rows take k_elementwise_f16x8 (8 elements per thread): mul and add are
+    one rounding of an exact f32 result -- the oracle's bytes; silu inside its tolerance; in place and from a start row"""
+    r = rng(9 * d)
+    n = 24
+    x, _ = act_rows(oracle, r, n, d, F16)
+    y, _ = act_rows(oracle, r, n, d, F16)
+    xd, yd = hip.upload(x), hip.upload(y)
+    for sp in (0, 5):
+        for name, ofn, hfn in (("mul", oracle.mul, hip.mul), ("add", oracle.add, hip.add)):
+            want = np.zeros_like(x)
+            out = hip.upload(np.zeros_like(x))
+            ofn(x, y, want, F16, n, d, sp)
+            hfn(xd, yd, out, F16, n, d, sp)
+            assert np.array_equal(out.download(shape=x.shape), want), name + " must be bit-exact"
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.mul(want, y, want, F16, n, d, sp)
+        hip.mul(buf, yd, buf, F16, n, d, sp)
+        assert np.array_equal(buf.download(shape=x.shape), want), "mul_inplace must be bit-exact"
+        want = x.copy()
+        buf = hip.upload(x)
+        oracle.silu(want, want, F16, n, d, sp)
+        hip.silu(buf, buf, F16, n, d, sp)
+        compare_rows(buf.download(shape=x.shape), want, F16, d, "silu_inplace f16", min_exact=0.995)
+
+
 def test_rope_last_position(hip, oracle):
     """position 2047: the angle table comes from host libm like the reference's"""
     r = rng(13)

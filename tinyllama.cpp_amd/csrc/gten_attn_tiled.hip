@@ -407,6 +407,10 @@ __device__ __forceinline__ void tile_scores_f16(const QFragH& q, const uint8_t* 
     }
 }
 
+// FAST (the default): p.V on the matrix cores as in k_attn_tiled_q8<true> -- the f16 probabilities and the f16 V elements
+// ARE the operands (no extra rounding at all: only the order of the f32 additions differs from the four stride-4
+// accumulators), the V sub-tile staged transposed, one v_mfma_f32_16x16x32_f16 per 32 positions of 16 rows x 16 elements.
+template <bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_attn_tiled_f16(const uint8_t* __restrict__ q, const uint8_t* __restrict__ k,
                                                         const uint8_t* __restrict__ v, uint8_t* __restrict__ out,
                                                         size_t q_pitch, size_t kv_pitch, size_t out_pitch,
@@ -414,6 +418,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 {
     __shared__ __attribute__((aligned(16))) float s_p[AT_ROWS * AT_PPITCH];
     __shared__ __attribute__((aligned(16))) float s_v[AT_VSUB * 64];
+    _Float16* s_ph = (_Float16*)s_p;                                     // fast: f16 probability rows [32][AT_PHPITCH] ...
+    float* s_o = s_p + AT_ROWS * AT_PHPITCH / 2;                         // ... and behind them the output tile [32][64]
+    _Float16* s_vt = (_Float16*)s_v;                                     // fast: the V sub-tile transposed [element][position]
+    static_assert(AT_ROWS * AT_PHPITCH / 2 + AT_ROWS * 64 <= AT_ROWS * AT_PPITCH && 64 * AT_VTPITCH * 2 <= AT_VSUB * 64 * 4, "fast-form tiles fit");
     __shared__ float s_red[4 * AT_ROWS];
     __shared__ float s_row[AT_ROWS];
 
@@ -527,6 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int rr = 0; rr < 4; rr++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[rr][j] = (v2f){0.f, 0.f};
+    v4f macc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // fast: [row tile], rows 16 rt + 4 lq + i, element 16 w + lc
 
     for (int t = 0; t < ntile; t++) {
 #pragma unroll
@@ -540,7 +549,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const float pr = (any && c <= row_base + 16 * rg + i) ? expf(s[rg][i] - mx[rg][i]) / tot[rg][i] : 0.f;
-                    s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * cg + lc] = h2f(f2h(pr));
+                    if (FAST) ((uint16_t*)s_ph)[(16 * rg + 4 * lq + i) * AT_PHPITCH + 64 * w + 16 * cg + lc] = f2h(pr);
+                    else s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * cg + lc] = h2f(f2h(pr));
                 }
         }
         __syncthreads();
@@ -555,6 +565,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const uint4 r0w = *(const uint4*)vs_, r1w = *(const uint4*)(vs_ + 16);
                 const unsigned raw[8] = {r0w.x, r0w.y, r0w.z, r0w.w, r1w.x, r1w.y, r1w.z, r1w.w};
                 float* dst = s_v + pos * 64 + 16 * qtr;
+                if (FAST) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) ((uint16_t*)s_vt)[(16 * qtr + e) * AT_VTPITCH + pos] = (uint16_t)(raw[e >> 1] >> (16 * (e & 1)));
+                } else
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     v4f o4;
@@ -564,6 +578,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 }
             }
             __syncthreads();
+            if (FAST) {
+                // wave w: elements 16 w .. 16 w + 15 of both 16-row tiles (positions past r_last meet p = 0)
+#pragma unroll
+                for (int ks = 0; ks < AT_VSUB / 32; ks++) {
+                    const h8 bv = *(const h8*)(s_vt + (16 * w + lc) * AT_VTPITCH + 32 * ks + 8 * lq);
+#pragma unroll
+                    for (int rt2 = 0; rt2 < 2; rt2++) {
+                        const h8 av = *(const h8*)(s_ph + (16 * rt2 + lc) * AT_PHPITCH + vs * AT_VSUB + 32 * ks + 8 * lq);
+                        macc[rt2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, macc[rt2], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
             const int lim = min(AT_VSUB, r_last - c0 + 1);
 #pragma unroll 4
             for (int c4 = 0; c4 < lim; c4 += 4) {
@@ -582,9 +610,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 
     // ---- output rows as f16
+    if (FAST) {
+#pragma unroll
+        for (int rt2 = 0; rt2 < 2; rt2++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) s_o[(16 * rt2 + 4 * lq + i) * 64 + 16 * w + lc] = macc[rt2][i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         v2f o = (v2f){0.f, 0.f};
+        if (FAST) o = *(const v2f*)(s_o + (4 * rq + rr) * 64 + 2 * ep);
+        else
 #pragma unroll
         for (int j = 0; j < 4; j++) o += acc[rr][j];
         const int row = r0 + 4 * rq + rr;
@@ -600,8 +637,12 @@ int gten_launch_attn_tiled_f16(const void* q, const void* k, const void* v, void
 {
     const int rows = n - start_pos;
     const dim3 grid(n_heads, (rows + AT_ROWS - 1) / AT_ROWS);
-    GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_f16, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
-               (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+    if (gtr::prefill_exact())
+        GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_f16<false>, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
+                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
+    else
+        GTR_LAUNCH(KT_ATTN_TILED, k_attn_tiled_f16<true>, grid, dim3(256), 0, (const uint8_t*)q, (const uint8_t*)k, (const uint8_t*)v,
+                   (uint8_t*)out, q_pitch, kv_pitch, out_pitch, n_heads, n_kv_heads, n, start_pos);
     return 0;
 }
 

@@ -488,6 +488,50 @@ __global__ __launch_bounds__(256) void k_silu_mul_q8x2(uint8_t* gate, const uint
     for (int j = 0; j < 17; j++) op[j] = ow[j];
 }
 
+// ... and for f16 rows: one thread per 8 elements (16 bytes each way); per element k_elementwise's arithmetic
+template <int OP>
+__global__ __launch_bounds__(256) void k_elementwise_f16x8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* out,
+                                                           size_t pitch, int groups_per_row, int start_pos, int total_groups)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_groups) return;
+    const int r = start_pos + gid / groups_per_row, gr = gid % groups_per_row;
+    const size_t off = (size_t)r * pitch + (size_t)gr * 16;
+    const uint4 av = *(const uint4*)(a + off);
+    uint4 bv = make_uint4(0, 0, 0, 0);
+    if (OP != EW_SILU) bv = *(const uint4*)(b + off);
+    const unsigned aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        unsigned o2 = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float xa = h2f((uint16_t)(aw[j] >> (16 * i)));
+            float o;
+            if (OP == EW_SILU) o = xa / (1.0f + expf(-xa));
+            else if (OP == EW_MUL) o = xa * h2f((uint16_t)(bw[j] >> (16 * i)));
+            else o = xa + h2f((uint16_t)(bw[j] >> (16 * i)));
+            o2 |= (unsigned)f2h(o) << (16 * i);
+        }
+        ow[j] = o2;
+    }
+    *(uint4*)(out + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+static bool elementwise_f16x8_ok(const void* a, const void* b, const void* out, int dtype, size_t pitch, int rows, int d)
+{
+    const auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    return dtype == GTEN_F16 && d % 8 == 0 && pitch % 16 == 0 && al(a) && al(out) && (!b || al(b)) && (size_t)rows * d >= 32768;
+}
+template <int OP>
+static int launch_elementwise_f16x8(const void* a, const void* b, void* out, size_t pitch, int n, int d, int start_pos)
+{
+    const int gpr = d / 8, total = (n - start_pos) * gpr;
+    GTR_LAUNCH(KT_ELEMWISE, (k_elementwise_f16x8<OP>), dim3((total + 255) / 256), dim3(256), 0,
+               (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, pitch, gpr, start_pos, total);
+    return 0;
+}
+
 // rows x blocks big enough for the block-pair kernel, and everything 4-byte aligned
 static bool elementwise_q8x2_ok(const void* a, const void* b, const void* out, int dtype, size_t pitch, int rows, int d)
 {
@@ -763,6 +807,7 @@ int gten_hip_silu(const void* x, void* out, int dtype, size_t pitch, int n, int 
     GTR_NEED_INIT();
     if (int rc = check_rowwise("silu", x, out, dtype, pitch, n, d, start_pos)) return rc;
     if (elementwise_q8x2_ok(x, nullptr, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_SILU>(x, nullptr, out, pitch, n, d, start_pos);
+    if (elementwise_f16x8_ok(x, nullptr, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_f16x8<EW_SILU>(x, nullptr, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_SILU>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)x, (const uint8_t*)nullptr, (uint8_t*)out, dtype, pitch, d, start_pos);
     return 0;
@@ -774,6 +819,7 @@ int gten_hip_mul(const void* a, const void* b, void* out, int dtype, size_t pitc
     if (int rc = check_rowwise("mul", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "mul: null pointer");
     if (elementwise_q8x2_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_MUL>(a, b, out, pitch, n, d, start_pos);
+    if (elementwise_f16x8_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_f16x8<EW_MUL>(a, b, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_MUL>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
     return 0;
@@ -785,6 +831,7 @@ int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitc
     if (int rc = check_rowwise("add", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "add: null pointer");
     if (elementwise_q8x2_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_ADD>(a, b, out, pitch, n, d, start_pos);
+    if (elementwise_f16x8_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_f16x8<EW_ADD>(a, b, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_ADD>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
                        (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, dtype, pitch, d, start_pos);
     return 0;
