@@ -151,11 +151,11 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
  * q and k are rotated together, silu and the product are one pass and the residual sums ride in the epilogues of the o and
  * down projections -- 12 launches instead of 23.  Every buffer named here ends with exactly the bytes the module-by-module
  * sequence leaves in it (tests/test_block_rows_gpu.py).  Activation buffers are dense rows in `adtype`; k and v are the
- * K / V caches.  Returns GTEN_HIP_NOT_HANDLED (no error recorded) for configurations this path does not compute (fp16
- * activations, fewer than 16 new rows, d_head != 64): the caller then runs the operators. */
+ * K / V caches.  Returns GTEN_HIP_NOT_HANDLED (no error recorded) for configurations this path does not compute (fewer than
+ * 16 new rows, d_head != 64, mixed dtypes): the caller then runs the operators. */
 #define GTEN_HIP_NOT_HANDLED 1
 typedef struct {
-    int adtype, wdtype;         /* GTEN_Q8 activations, GTEN_Q8 / GTEN_Q4 weights */
+    int adtype, wdtype;         /* GTEN_Q8 activations with GTEN_Q8 / GTEN_Q4 weights, or GTEN_F16 with GTEN_F16 */
     int n_embd, n_heads, n_kv_heads, n_ffn;
     const void *attn_norm_w, *wq, *wk, *wv, *wo, *ffn_norm_w, *wgate, *wup, *wdown;
     const void* inp;            /* [.][n_embd]: the block's input rows */

@@ -26,16 +26,16 @@ def make_block(hip, oracle, r, wd, E, H, KVH, F, max_ctx):
     return w, widths
 
 
-def alloc_acts(hip, widths, max_ctx, fill):
+def alloc_acts(hip, widths, max_ctx, fill, ad=Q8):
     bufs = {}
     for k, d in widths.items():
-        bufs[k] = hip.alloc(max_ctx * row_bytes(Q8, d))
+        bufs[k] = hip.alloc(max_ctx * row_bytes(ad, d))
         bufs[k].zero(fill)
     return bufs
 
 
-def modules_sequence(hip, w, a, inp, wd, n, s, E, H, KVH, F):
-    """gten/modules.cpp:198-253, operator by operator"""
+def modules_sequence(hip, w, a, inp, wd, n, s, E, H, KVH, F, Q8=Q8):
+    """gten/modules.cpp:198-253, operator by operator (Q8 here = the activation dtype of the run)"""
     dh = E // H
     KV = dh * KVH
     hip.rms_norm(inp, Q8, w["attn_norm_w"], a["attn_norm_out"], n, E, s)
@@ -65,33 +65,34 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("wd", [Q8, Q4])
+@pytest.mark.parametrize("wd", [Q8, Q4, F16])
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_block_rows_equals_module_sequence(hip, oracle, wd, exact, case):
     E, H, KVH, F, max_ctx, calls = CASES[case]
     if E == 2048 and exact and wd == Q8:
         pytest.skip("one full-size exact case is enough")
+    ad = F16 if wd == F16 else Q8
     r = rng(100 + case)
     w, widths = make_block(hip, oracle, r, wd, E, H, KVH, F, max_ctx)
-    a_ref = alloc_acts(hip, widths, max_ctx, 0)
-    a_got = alloc_acts(hip, widths, max_ctx, 0)
-    xb, _ = act_rows(oracle, r, max_ctx, E, Q8, scale=1.0)
+    a_ref = alloc_acts(hip, widths, max_ctx, 0, ad)
+    a_got = alloc_acts(hip, widths, max_ctx, 0, ad)
+    xb, _ = act_rows(oracle, r, max_ctx, E, ad, scale=1.0)
     inp = hip.upload(xb)
     hip.set_prefill_exact(exact)
     try:
         for n, s in calls:
             hip.set_block_rows(False)
-            modules_sequence(hip, w, a_ref, inp, wd, n, s, E, H, KVH, F)
+            modules_sequence(hip, w, a_ref, inp, wd, n, s, E, H, KVH, F, Q8=ad)
             hip.set_block_rows(True)
-            ints = dict(adtype=Q8, wdtype=wd, n_embd=E, n_heads=H, n_kv_heads=KVH, n_ffn=F)
+            ints = dict(adtype=ad, wdtype=wd, n_embd=E, n_heads=H, n_kv_heads=KVH, n_ffn=F)
             bufs = dict(w)
             bufs.update(a_got)
             bufs["inp"] = inp
             assert hip.block_rows(n, s, ints, bufs), "the composed call refused a configuration it is meant for"
             hip.sync()
             for k in ACTS:
-                nb = n * row_bytes(Q8, widths[k])
+                nb = n * row_bytes(ad, widths[k])
                 want = a_ref[k].download(nbytes=nb)
                 got = a_got[k].download(nbytes=nb)
                 assert np.array_equal(got, want), (k, n, s, int((got != want).sum()), "bytes differ")
@@ -112,7 +113,7 @@ def test_block_rows_declines_what_it_does_not_compute(hip, oracle):
     bufs["inp"] = inp
     ints = dict(adtype=Q8, wdtype=Q8, n_embd=E, n_heads=H, n_kv_heads=KVH, n_ffn=F)
     assert not hip.block_rows(8, 0, ints, bufs)                      # fewer than 16 new rows: the row kernels' business
-    assert not hip.block_rows(64, 0, dict(ints, adtype=F16, wdtype=F16), bufs)
+    assert not hip.block_rows(64, 0, dict(ints, adtype=F16, wdtype=Q8), bufs)  # a pair the reference does not dispatch
     assert not hip.block_rows(64, 0, dict(ints, n_heads=8), bufs)    # d_head 32
     hip.set_block_rows(False)
     try:

@@ -576,8 +576,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                         if (ok0 && l16 == 0) *(uint16_t*)sb = ss.d16;
                     }
                 } else if (out_dtype == GTEN_F16) {
-                    if (ok0) ((uint16_t*)orow)[c0] = f2h(v0);
-                    if (ok1) ((uint16_t*)orow)[c1] = f2h(v1);
+                    const uint16_t h0 = f2h(v0), h1 = f2h(v1);
+                    if (ok0) ((uint16_t*)orow)[c0] = h0;
+                    if (ok1) ((uint16_t*)orow)[c1] = h1;
+                    if (ms.resid) {
+                        // ops::add on the f16 values just stored: both operands from their stored halves, f32 sum, one rounding
+                        const size_t ro = (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch;
+                        const uint16_t* rr16 = (const uint16_t*)(ms.resid + ro);
+                        uint16_t* so16 = (uint16_t*)(ms.sum_out + ro);
+                        if (ok0) so16[c0] = f2h(h2f(rr16[c0]) + h2f(h0));
+                        if (ok1) so16[c1] = f2h(h2f(rr16[c1]) + h2f(h1));
+                    }
                 } else {
                     if (ok0) ((float*)orow)[c0] = v0;
                     if (ok1) ((float*)orow)[c1] = v1;

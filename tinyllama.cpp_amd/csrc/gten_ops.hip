@@ -518,6 +518,32 @@ __global__ __launch_bounds__(256) void k_elementwise_f16x8(const uint8_t* __rest
     }
     *(uint4*)(out + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
+// silu_inplace(gate) then mul_inplace(gate, up) on f16 rows in one pass: the silu value is rounded to f16 as the first
+// operator stores it, widened again, multiplied and rounded as the second stores it
+__global__ __launch_bounds__(256) void k_silu_mul_f16x8(uint8_t* gate, const uint8_t* __restrict__ up, size_t pitch, int groups_per_row,
+                                                        int start_pos, int total_groups)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_groups) return;
+    const int r = start_pos + gid / groups_per_row, gr = gid % groups_per_row;
+    const size_t off = (size_t)r * pitch + (size_t)gr * 16;
+    const uint4 av = *(const uint4*)(gate + off), bv = *(const uint4*)(up + off);
+    const unsigned aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        unsigned o2 = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float xa = h2f((uint16_t)(aw[j] >> (16 * i)));
+            const float sv = h2f(f2h(xa / (1.0f + expf(-xa))));
+            o2 |= (unsigned)f2h(sv * h2f((uint16_t)(bw[j] >> (16 * i)))) << (16 * i);
+        }
+        ow[j] = o2;
+    }
+    *(uint4*)(gate + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
 static bool elementwise_f16x8_ok(const void* a, const void* b, const void* out, int dtype, size_t pitch, int rows, int d)
 {
     const auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
@@ -892,13 +918,60 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     static const bool no_mfma = [] { const char* e = std::getenv("GTEN_HIP_NO_MFMA"); return e && e[0] == '1'; }();
     static const bool no_tiled = [] { const char* e = std::getenv("GTEN_HIP_NO_TILED_ATTN"); return e && e[0] == '1'; }();
     // what this path computes; everything else stays with the operators (the caller falls back on GTEN_HIP_NOT_HANDLED)
-    if (off || no_mfma || no_tiled || b->adtype != GTEN_Q8 || (b->wdtype != GTEN_Q8 && b->wdtype != GTEN_Q4) || rows < GTEN_MFMA_MIN_ROWS ||
+    const bool q8cfg = b->adtype == GTEN_Q8 && (b->wdtype == GTEN_Q8 || b->wdtype == GTEN_Q4);
+    const bool f16cfg = b->adtype == GTEN_F16 && b->wdtype == GTEN_F16;
+    if (off || no_mfma || no_tiled || !(q8cfg || f16cfg) || rows < GTEN_MFMA_MIN_ROWS ||
         rows > 65535 || n > GTEN_ROPE_MAX_POS || start_pos < 0 || dh != 64 || E % 128 != 0 || F % 128 != 0 || KV % 32 != 0 || (F / 32) % 2 != 0 ||
         b->n_heads % b->n_kv_heads != 0)
         return GTEN_HIP_NOT_HANDLED;
     const void* ptrs[] = {b->attn_norm_w, b->wq, b->wk, b->wv, b->wo, b->ffn_norm_w, b->wgate, b->wup, b->wdown, b->inp, b->attn_norm_out,
                           b->q, b->k, b->v, b->attn_out, b->o, b->h, b->ffn_norm_out, b->gate, b->up, b->down, b->out};
-    for (const void* p : ptrs) GTR_REQUIRE(p && ((uintptr_t)p & 3) == 0, "block_rows: null or unaligned pointer");
+    for (const void* p : ptrs) GTR_REQUIRE(p && ((uintptr_t)p & 15) == 0, "block_rows: null or unaligned pointer");
+    if (f16cfg) {
+        // the f16 configuration: no f16 copies to make (the rows are the operands), otherwise the same composition
+        const size_t hE = (size_t)E * 2, hKV = (size_t)KV * 2, hF = (size_t)F * 2;
+        int rc;
+        if ((rc = gten_hip_rms_norm(b->inp, GTEN_F16, hE, b->attn_norm_w, b->attn_norm_out, hE, n, E, start_pos))) return rc;
+        {
+            MfmaMats m;
+            m.n = 3;
+            m.w[0] = b->wq; m.out[0] = b->q; m.out_pitch[0] = hE; m.d_out[0] = E;
+            m.w[1] = b->wk; m.out[1] = b->k; m.out_pitch[1] = hKV; m.d_out[1] = KV;
+            m.w[2] = b->wv; m.out[2] = b->v; m.out_pitch[2] = hKV; m.d_out[2] = KV;
+            if ((rc = gten_launch_matmul_mfma_multi(b->attn_norm_out, hE, GTEN_F16, m, GTEN_F16, n, E, start_pos, false))) return rc;
+        }
+        {
+            const float2* table = nullptr;
+            if ((rc = rope_table(dh, &table))) return rc;
+            GTR_LAUNCH(KT_ROPE, k_rope2, dim3(rows, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q, hE, E, (uint8_t*)b->k, hKV, KV, GTEN_F16, dh, start_pos, table);
+        }
+        if ((rc = gten_launch_attn_tiled_f16(b->q, b->k, b->v, b->attn_out, hE, hKV, hE, n, b->n_heads, b->n_kv_heads, start_pos))) return rc;
+        {
+            MfmaMats m;
+            m.n = 1; m.w[0] = b->wo; m.out[0] = b->o; m.out_pitch[0] = hE; m.d_out[0] = E;
+            m.resid = b->inp; m.sum_out = b->h; m.resid_pitch = hE;
+            if ((rc = gten_launch_matmul_mfma_multi(b->attn_out, hE, GTEN_F16, m, GTEN_F16, n, E, start_pos, false))) return rc;
+        }
+        if ((rc = gten_hip_rms_norm(b->h, GTEN_F16, hE, b->ffn_norm_w, b->ffn_norm_out, hE, n, E, start_pos))) return rc;
+        {
+            MfmaMats m;
+            m.n = 2;
+            m.w[0] = b->wgate; m.out[0] = b->gate; m.out_pitch[0] = hF; m.d_out[0] = F;
+            m.w[1] = b->wup; m.out[1] = b->up; m.out_pitch[1] = hF; m.d_out[1] = F;
+            if ((rc = gten_launch_matmul_mfma_multi(b->ffn_norm_out, hE, GTEN_F16, m, GTEN_F16, n, E, start_pos, false))) return rc;
+        }
+        {
+            const int gpr = F / 8, total = rows * gpr;
+            GTR_LAUNCH(KT_ELEMWISE, k_silu_mul_f16x8, dim3((total + 255) / 256), dim3(256), 0, (uint8_t*)b->gate, (const uint8_t*)b->up, hF, gpr, start_pos, total);
+        }
+        {
+            MfmaMats m;
+            m.n = 1; m.w[0] = b->wdown; m.out[0] = b->down; m.out_pitch[0] = hE; m.d_out[0] = E;
+            m.resid = b->h; m.sum_out = b->out; m.resid_pitch = hE;
+            if ((rc = gten_launch_matmul_mfma_multi(b->gate, hF, GTEN_F16, m, GTEN_F16, n, F, start_pos, false))) return rc;
+        }
+        return 0;
+    }
     const size_t pE = gten_hip_row_bytes(GTEN_Q8, E), pKV = gten_hip_row_bytes(GTEN_Q8, KV), pF = gten_hip_row_bytes(GTEN_Q8, F);
     int rc;
     // fast form: the producers of the W.x inputs write the f16 copy themselves (one launch less per projection input);

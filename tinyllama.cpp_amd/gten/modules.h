@@ -477,7 +477,7 @@ private:
     // Prompt-sized calls: the whole block as one library call (gten_hip_block_rows: the same kernels composed so that
     // matrices sharing an input share its launch, 12 launches instead of 23).  Every activation tensor of the modules --
     // the K / V caches among them -- ends with the bytes the module-by-module sequence above leaves in it.  Returns false
-    // when the library does not take the configuration (fp16 activations, ...): the modules then run one by one.
+    // when the library does not take the configuration (an unusual head width, ...): the modules then run one by one.
     bool forward_rows(Tensor& inp, const int start_pos)
     {
         const int n = inp.dimsize(0), E = inp.dimsize(1), F = ffn_gate_proj.weight.dimsize(0), H = attn.n_heads();
@@ -493,7 +493,7 @@ private:
         if (!attn.query.weight.shape_eq({E, E}) || !attn.key.weight.shape_eq({KV, E}) || !attn.qkv_proj.weight.shape_eq({E, E}) ||
             !ffn_up_proj.weight.shape_eq({F, E}) || !ffn_down_proj.weight.shape_eq({E, F}) || attn_norm.weight.numel() != E || ffn_norm.weight.numel() != E)
             return false;
-        if (adt != kQint8 || (wdt != kQint8 && wdt != kQint4)) return false;
+        if (!((adt == kQint8 && (wdt == kQint8 || wdt == kQint4)) || (adt == kFloat16 && wdt == kFloat16))) return false;
         Timer timer{&attn.qkv_proj.exec_time};
         // the shapes the modules give their outputs
         attn_norm.acv.resize({n, E}); attn.query.acv.resize({n, E}); attn.key.acv.resize({n, KV}); attn.value.acv.resize({n, KV});
