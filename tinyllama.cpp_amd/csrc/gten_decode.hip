@@ -134,6 +134,7 @@ struct Gemv8Args {
     // k_dec_gemvm + EPI_SILUMUL: where the FFN activation is staged (its INPUT stage is act_*)
     int8_t* out_q; float* out_d; int* out_sum; float* out_f;
     int frag_rt;                  // EPI_STAGE_FRAG: row tiles (of 16 sequences) of the fragment-major staging (k_dec_mmv)
+    int frag_h16;                 // ... as f16(quant * delta) fragments (k_dec_mmvh) instead of int8 + delta table
     // PRO_EMBED (the step's first launch) copies the RoPE rotation of the current position where the score
     // kernels find it without knowing the position: rope_now[seq][rope_half]
     const float2* rope; float2* rope_now; int rope_half;
@@ -211,6 +212,7 @@ template <int EPT> __device__ __forceinline__ void q8_stageN(const float (&v)[EP
 struct ActFrag {
     int8_t* q; float* d; int* sum;
     int rt, row;
+    int h16;                      // k_dec_mmvh: the fragments as f16(quant * delta) instead (16 bytes per lane, elements 0,2,1,3 of every four)
 };
 template <int EPT> __device__ __forceinline__ void q8_stage_frag(const float (&v)[EPT], int b, int sub, ActFrag a)
 {
@@ -222,6 +224,18 @@ template <int EPT> __device__ __forceinline__ void q8_stage_frag(const float (&v
 #pragma unroll
     for (int i = 0; i < EPT; i++) { q[i] = q8_round(v[i], s.scale); sum += q[i]; }
     const int k = sub * EPT;                                   // first element of this thread inside the block
+    if (a.h16) {
+        uint16_t* hd = (uint16_t*)a.q + ((((size_t)b * a.rt + (a.row >> 4)) * 64 + (k >> 3) * 16 + (a.row & 15)) * 8 + (k & 7));
+        unsigned hw[EPT / 2];
+#pragma unroll
+        for (int i = 0; i < EPT; i += 4) {
+            hw[i / 2] = (unsigned)f2h((float)q[i] * s.ddeq) | ((unsigned)f2h((float)q[i + 2] * s.ddeq) << 16);
+            hw[i / 2 + 1] = (unsigned)f2h((float)q[i + 1] * s.ddeq) | ((unsigned)f2h((float)q[i + 3] * s.ddeq) << 16);
+        }
+        if (EPT == 8) *(uint4*)hd = make_uint4(hw[0], hw[1], hw[EPT / 2 - 2], hw[EPT / 2 - 1]);
+        else *(uint2*)hd = make_uint2(hw[0], hw[1]);
+        return;
+    }
     int8_t* dst = a.q + ((((size_t)b * a.rt + (a.row >> 4)) * 64 + (k >> 3) * 16 + (a.row & 15)) * 8 + (k & 7));
     const int lo = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
     if (EPT == 8) {
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
                 }
             } else if (on) stN<EPT>(s.row + base, v);     // staged as f32 (exact f16 values)
         } else if (on) {
-            if (EPI == EPI_STAGE_FRAG) q8_stage_frag<EPT>(v, blk, sub, ActFrag{a.act_q, a.act_d, a.act_sum, a.frag_rt, seq});
+            if (EPI == EPI_STAGE_FRAG) q8_stage_frag<EPT>(v, blk, sub, ActFrag{a.act_q, a.act_d, a.act_sum, a.frag_rt, seq, a.frag_h16});
             else q8_stageN<EPT>(v, blk, sub, s.q8);
         }
         __syncthreads();
@@ -1068,12 +1082,186 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
     }
 }
 
+// ---- k_dec_mmvh: k_dec_mmv with the block deltas folded into f16 operands (the fast form of gten_mfma.hip).
+// k_dec_mmv spends 25 vector instructions per matrix instruction (PMC at 64 sequences) -- the i32 block sums of every
+// (row tile, feature tile, quant block) converted and scaled (isum * da) * dw on the VALU.  Here the staging launches leave
+// the activations as f16(q * da) fragments, a weight fragment becomes f16((n - 7) * dw) as it leaves the slab (once per
+// block and feature tile, shared by the row tiles), and v_mfma_f32_16x16x32_f16 accumulates ACROSS the blocks of a wave's K
+// slice: no delta table, no per-block arithmetic on the outputs.  One fp16 rounding per operand element (relative 2^-11);
+// the sequences' logits stay inside the wide path's band (tests/test_multiseq_oracle_gpu.py).  GTEN_HIP_MMV_EXACT=1: k_dec_mmv.
+typedef _Float16 mmvh_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mmvh_h8 __attribute__((ext_vector_type(8)));
+typedef float mmvh_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned mmvh_scale(unsigned biased_pair, float bias, unsigned d2)
+{
+    mmvh_h2 h, d;
+    __builtin_memcpy(&h, &biased_pair, 4);
+    __builtin_memcpy(&d, &d2, 4);
+    const mmvh_h2 b = {(_Float16)bias, (_Float16)bias};
+    h = (h - b) * d;
+    unsigned out;
+    __builtin_memcpy(&out, &h, 4);
+    return out;
+}
+
+template <int WT, int RT, int FT>
+__global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a_ah, const void* __restrict__ a_w0, float* __restrict__ a_out,
+                                                  const int a_d_in, const int a_d_out0, const int a_out_cols, const int a_S, const int a_n_mats,
+                                                  const MmvRest rest)
+{
+    constexpr int SP = 16 * RT, FR = 16 * FT, CB = 4;
+    constexpr int NPF = MMV_MAXP / FT;
+    const int nb = a_d_in >> 5;
+    const int nbs = nb / (int)gridDim.y, b_lo = (int)blockIdx.y * nbs;
+    const int nbw = nbs >> 3;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const int rowb = nb * (WT == GTEN_Q4 ? 16 : 32);
+    const int rowl = nbs * (WT == GTEN_Q4 ? 16 : 32);
+    uint8_t* wl = g_smem;                                     // [FR][rowl], 16-byte pieces swizzled: slot = piece ^ (row & 7)
+    float* red = (float*)g_smem;                              // [8][SP][16] -- over the slab, once the K loop is done
+    uint16_t* dwl = (uint16_t*)(wl + max((size_t)FR * rowl, (size_t)8 * SP * 64));   // [FR][nbs] weight deltas
+
+    int colw = blockIdx.x * FR, colbase = 0, m = 0;
+    if (a_n_mats > 1 && colw >= a_d_out0) {
+        colw -= a_d_out0; colbase = a_d_out0; m = 1;
+        if (a_n_mats > 2 && colw >= rest.d_out1) { colw -= rest.d_out1; colbase += rest.d_out1; m = 2; }
+    }
+    const void* w = (m == 0) ? a_w0 : (m == 1) ? rest.w1 : rest.w2;
+    const int d_out = (m == 0) ? a_d_out0 : (m == 1) ? rest.d_out1 : rest.d_out2;
+    const PackedW pw = packed_view(w, WT, d_out, a_d_in);
+
+    // ---- 1. the slab, its deltas and this wave's first activation fragments: one memory round trip
+    const int ppr = rowl >> 4;
+    const int sr = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+    uint4 wp[FT][NPF];
+#pragma unroll
+    for (int f = 0; f < FT; f++)
+#pragma unroll
+        for (int k = 0; k < NPF; k++) wp[f][k] = make_uint4(0, 0, 0, 0);
+    unsigned dwv[FT][3];
+#pragma unroll
+    for (int f = 0; f < FT; f++) {
+        const size_t frow = (size_t)min(colw + 16 * f + sr, d_out - 1);
+        const uint8_t* srow = pw.qs + frow * rowb;
+#pragma unroll
+        for (int k = 0; k < NPF; k++)
+            if (32 * k < ppr) {
+                const int lp = min(c0 + 32 * k, ppr - 1);
+                const int gp = (WT == GTEN_Q4) ? b_lo + lp : (lp < nbs ? b_lo + lp : nb + b_lo + (lp - nbs));
+                wp[f][k] = *(const uint4*)(srow + (size_t)gp * 16);
+            }
+        const unsigned* drow = (const unsigned*)(pw.ds + frow * nb + b_lo);
+#pragma unroll
+        for (int k = 0; k < 3; k++) dwv[f][k] = drow[min(c0 + 32 * k, (nbs >> 1) - 1)];
+    }
+    const int b0 = b_lo + wid * nbw;
+    const uint16_t* afr = a_ah + (size_t)lane * 8;            // fragment order: 1024 contiguous bytes per (block, row tile)
+    uint4 araw[RT][CB];
+    auto request = [&](int bb) {
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+#pragma unroll
+            for (int t = 0; t < RT; t++) araw[t][c] = *(const uint4*)(afr + ((size_t)min(bb + c, nb - 1) * RT + t) * 512);
+    };
+    request(b0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. park the slab and its deltas in LDS
+#pragma unroll
+    for (int f = 0; f < FT; f++) {
+        const int r = 16 * f + sr;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int c = c0 + 32 * k;
+            if (c < ppr) *(uint4*)(wl + (size_t)r * rowl + (size_t)(c ^ (r & 7)) * 16) = wp[f][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int c = c0 + 32 * k;
+            if (c < (nbs >> 1)) ((unsigned*)dwl)[r * (nbs >> 1) + c] = dwv[f][k];
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. this wave's K slice, accumulated inside the matrix core
+    const int nshift = (g < 2) ? 4 : 0;
+    mmvh_f4 acc[FT][RT];
+#pragma unroll
+    for (int f = 0; f < FT; f++)
+#pragma unroll
+        for (int t = 0; t < RT; t++) acc[f][t] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
+    const uint8_t* wrow = wl + (size_t)l16 * rowl + (g & 1) * 8;
+    for (int bb = b0; bb < b0 + nbw; bb += CB) {
+        uint4 aqv[RT][CB];
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+#pragma unroll
+            for (int t = 0; t < RT; t++) aqv[t][c] = araw[t][c];
+        if (bb + CB < b0 + nbw) request(bb + CB);
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const int b = min(bb + c, b_lo + nbs - 1) - b_lo;
+            const bool live = bb + c < b0 + nbw;                 // blocks past this wave's slice meet a zero delta
+            mmvh_h8 bh[FT];
+#pragma unroll
+            for (int f = 0; f < FT; f++) {
+                const unsigned dbits = live ? (unsigned)dwl[(16 * f + l16) * nbs + b] : 0u;
+                const unsigned d2 = dbits | (dbits << 16);
+                const uint8_t* wr = wrow + (size_t)16 * f * rowl;
+                unsigned u[4];
+                if (WT == GTEN_Q4) {
+                    const uint2 by = *(const uint2*)(wr + (size_t)(b ^ (l16 & 7)) * 16);
+                    const unsigned x = by.x >> nshift, y = by.y >> nshift;
+                    u[0] = mmvh_scale((x & 0x000f000fu) | 0x64006400u, 1031.0f, d2);            // nibbles of bytes 0, 2: elements (0, 2)
+                    u[1] = mmvh_scale(((x >> 8) & 0x000f000fu) | 0x64006400u, 1031.0f, d2);     // bytes 1, 3: (1, 3)
+                    u[2] = mmvh_scale((y & 0x000f000fu) | 0x64006400u, 1031.0f, d2);
+                    u[3] = mmvh_scale(((y >> 8) & 0x000f000fu) | 0x64006400u, 1031.0f, d2);
+                } else {
+                    const int piece = (g >> 1) * nbs + b;
+                    const uint2 by = *(const uint2*)(wr + (size_t)(piece ^ (l16 & 7)) * 16);
+                    u[0] = mmvh_scale((by.x & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);         // int8 + 128 in the low bits of 1024 + ...
+                    u[1] = mmvh_scale(((by.x >> 8) & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                    u[2] = mmvh_scale((by.y & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                    u[3] = mmvh_scale(((by.y >> 8) & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                }
+                __builtin_memcpy(&bh[f], u, 16);
+            }
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                mmvh_h8 ah;
+                __builtin_memcpy(&ah, &aqv[t][c], 16);
+#pragma unroll
+                for (int f = 0; f < FT; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[f], acc[f][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- 4. the eight K slices, added in wave order
+#pragma unroll
+    for (int f = 0; f < FT; f++) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) red[(wid * SP + 16 * t + 4 * g + i) * 16 + l16] = acc[f][t][i];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < SP * 16; idx += 512) {
+            const int r = idx >> 4, c = idx & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) v += red[(q * SP + r) * 16 + c];
+            if (r < a_S && colw + 16 * f + c < d_out)
+                a_out[(size_t)blockIdx.y * rest.plane + (size_t)r * a_out_cols + colbase + colw + 16 * f + c] = v;
+        }
+    }
+}
+
 // silu(write(gate)) * write(up) for S staged rows (wide multi-sequence decode: the gate and up projections come
 // from k_dec_mmv as raw f32 rows [gate | up]); written in the fragment-major staging for the down projection.
 // Same chain as the EPI_SILUMUL epilogues above (gten/modules.cpp:238-247).  One thread per element, 32 lanes =
 // one Q8 block.
 __global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restrict__ gu_raw, int n_ffn, int rt, int plane,
-                                                          int8_t* __restrict__ out_q, float* __restrict__ out_d, int* __restrict__ out_sum)
+                                                          int8_t* __restrict__ out_q, float* __restrict__ out_d, int* __restrict__ out_sum, int h16)
 {
     const int q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;         // n_ffn % 256 == 0
     const float* row = gu_raw + (size_t)q * 2 * n_ffn;
@@ -1087,6 +1275,11 @@ __global__ __launch_bounds__(256) void k_dec_silumul_rows(const float* __restric
     const int qv = q8_round(v, sc.scale);
     const int qs = sum32_i(qv);
     const int b = e >> 5, k = e & 31;
+    if (h16) {                                                             // k_dec_mmvh's f16 fragments (elements 0,2,1,3 of every four)
+        const int kp = (k & ~3) | ((k & 1) << 1) | ((k >> 1) & 1);
+        ((uint16_t*)out_q)[(((size_t)b * rt + (q >> 4)) * 64 + (kp >> 3) * 16 + (q & 15)) * 8 + (kp & 7)] = f2h((float)qv * sc.ddeq);
+        return;
+    }
     out_q[(((size_t)b * rt + (q >> 4)) * 64 + (k >> 3) * 16 + (q & 15)) * 8 + (k & 7)] = (int8_t)qv;
     if (k == 0) { out_d[(size_t)b * 16 * rt + q] = sc.ddeq; out_sum[(size_t)b * 16 * rt + q] = qs; }
 }
@@ -3545,6 +3738,66 @@ static int launch_mmv_rt(int tag, const MmvArgs& a)
     return 0;
 }
 
+// k_dec_mmvh (f16 fragments): four feature tiles per workgroup for the wide outputs (Q4; two for Q8), else one
+struct MmvhArgs {
+    const uint16_t* ah;
+    const void* w[3]; int d_out[3]; int n_mats;
+    float* out; int out_cols;
+    int S, d_in, ks, plane;
+};
+template <int WT, int RT>
+static int launch_mmvh_rt(int tag, const MmvhArgs& a)
+{
+    constexpr int FTW = (WT == GTEN_Q4 && RT <= 2) ? 4 : 2;
+    const int cols = a.d_out[0] + (a.n_mats > 1 ? a.d_out[1] : 0) + (a.n_mats > 2 ? a.d_out[2] : 0);
+    const int ppr = (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) / 16;
+    bool wide_out = cols >= 4096 && ppr <= 32 * (MMV_MAXP / FTW);
+    for (int k = 0; k + 1 < a.n_mats; k++) wide_out = wide_out && a.d_out[k] % (16 * FTW) == 0;
+    const int ft = wide_out ? FTW : 1;
+    const int ks = a.ks > 1 ? a.ks : 1;
+    GTR_REQUIRE((a.d_in / 32) % (8 * ks) == 0, "decoder: %d K slices do not divide the %d quant blocks into eight waves", ks, a.d_in / 32);
+    const size_t nbs = (size_t)a.d_in / 32 / ks, fr = 16 * (size_t)ft;
+    const size_t smem = std::max(fr * nbs * (WT == GTEN_Q4 ? 16 : 32), (size_t)8 * 16 * RT * 64) + fr * nbs * 2;
+    GTR_REQUIRE(smem <= 150 * 1024, "decoder: the weight slab of d_in %d does not fit LDS", a.d_in);
+    const dim3 grid((cols + 16 * ft - 1) / (16 * ft), ks);
+    const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2], a.plane};
+    if (ft > 1)
+        DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, FTW>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
+    else
+        DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, 1>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
+    return 0;
+}
+template <int WT>
+static int launch_mmvh(int tag, const MmvhArgs& a)
+{
+    GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && a.S <= 64, "decoder: skinny W.x wants d_in %% 256 == 0 and <= 64 rows");
+    GTR_REQUIRE((size_t)16 * (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) <= (size_t)MMV_MAXP * 512 * 16, "decoder: d_in %d too long for the weight slab", a.d_in);
+    for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
+    constexpr int WQ = (WT == GTEN_F16) ? GTEN_Q8 : WT;
+    switch ((a.S + 15) / 16) {
+    case 1: return launch_mmvh_rt<WQ, 1>(tag, a);
+    case 2: return launch_mmvh_rt<WQ, 2>(tag, a);
+    case 3: return launch_mmvh_rt<WQ, 3>(tag, a);
+    default: return launch_mmvh_rt<WQ, 4>(tag, a);
+    }
+}
+template <int WT>
+static int mmvh_prepare()
+{
+    constexpr int FTA = (WT == GTEN_Q4) ? 4 : 2;        // <= 32 rows
+#define MMVH_ATTR(RT_, FT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmvh<WT, RT_, FT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+    MMVH_ATTR(1, 1); MMVH_ATTR(2, 1); MMVH_ATTR(3, 1); MMVH_ATTR(4, 1);
+    MMVH_ATTR(1, FTA); MMVH_ATTR(2, FTA); MMVH_ATTR(3, 2); MMVH_ATTR(4, 2);
+#undef MMVH_ATTR
+    return 0;
+}
+// the wide path's W.x form: f16 fragments with folded deltas (k_dec_mmvh) unless GTEN_HIP_MMV_EXACT=1
+static bool mmv_folded()
+{
+    static const bool on = [] { const char* e = std::getenv("GTEN_HIP_MMV_EXACT"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 // (before the first launch, outside any stream capture: the slab may need more than 64 KB of LDS)
 template <int WT>
 static int mmv_prepare()
@@ -3613,8 +3866,19 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
     Gemv8Args base{};
     base.step = dc->step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
     base.best_stride = dc->n_best;
+    const bool folded = WT != GTEN_F16 && mmv_folded();
+    base.frag_h16 = folded ? 1 : 0;
+    auto mmh = [&](int tag, const int8_t* aq, float* out, int out_cols, int d_in, int ks, const void* w, int d_out,
+                   const void* w1, int d1, const void* w2, int d2) -> int {
+        MmvhArgs a{};
+        a.ah = (const uint16_t*)aq; a.w[0] = w; a.w[1] = w1; a.w[2] = w2; a.d_out[0] = d_out; a.d_out[1] = d1; a.d_out[2] = d2;
+        a.n_mats = w2 ? 3 : (w1 ? 2 : 1); a.out = out; a.out_cols = out_cols; a.S = S; a.d_in = d_in;
+        a.ks = ks; a.plane = S * out_cols;
+        return launch_mmvh<WT>(tag, a);
+    };
     auto mm = [&](int tag, const int8_t* aq, const float* ad, const int*, float* out, int out_cols, int d_in, const void* w, int d_out,
                   const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0) -> int {
+        if (folded) return mmh(tag, aq, out, out_cols, d_in, 1, w, d_out, w1, d1, w2, d2);
         MmvArgs a{};
         a.aq = aq; a.ad = ad; a.w[0] = w; a.w[1] = w1; a.w[2] = w2; a.d_out[0] = d_out; a.d_out[1] = d1; a.d_out[2] = d2;
         a.n_mats = w2 ? 3 : (w1 ? 2 : 1); a.out = out; a.out_cols = out_cols; a.S = S; a.d_in = d_in;
@@ -3626,6 +3890,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
     const int ksplit = (kse && atoi(kse) == 1) ? 1 : 2;
     auto mmk = [&](int tag, const int8_t* aq, const float* ad, float* out, int out_cols, int d_in, int ks, const void* w, int d_out,
                    const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0) -> int {
+        if (folded) return mmh(tag, aq, out, out_cols, d_in, ks, w, d_out, w1, d1, w2, d2);
         MmvArgs a{};
         a.aq = aq; a.ad = ad; a.w[0] = w; a.w[1] = w1; a.w[2] = w2; a.d_out[0] = d_out; a.d_out[1] = d1; a.d_out[2] = d2;
         a.n_mats = w2 ? 3 : (w1 ? 2 : 1); a.out = out; a.out_cols = out_cols; a.S = S; a.d_in = d_in;
@@ -3685,7 +3950,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
                        ks_gu > 1 ? S * 2 * F : 0, (uint16_t*)dc->act_q);
         else
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16,
-                       ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum);
+                       ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum, folded ? 1 : 0);
         if ((rc = mmk(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
@@ -3799,7 +4064,8 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     GTR_CHECK(hipMalloc((void**)&dc->xbuf, S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->hbuf, S * (size_t)E * 4));
     // (wide f16 decode keeps its staged rows as f16 matrices of 16-row tiles: 2 bytes per element, rows padded to the tile)
-    const size_t stage_rows = (wide && d.wdtype == GTEN_F16) ? 2 * ((S + 15) / 16 * 16) : S;
+    // (... and the quantized wide path stages f16(q * delta) fragments for k_dec_mmvh: 2 bytes per element as well)
+    const size_t stage_rows = wide ? 2 * ((S + 15) / 16 * 16) : S;
     GTR_CHECK(hipMalloc((void**)&dc->act_q, stage_rows * (size_t)F));
     GTR_CHECK(hipMemset(dc->act_q, 0, stage_rows * (size_t)F));
     GTR_CHECK(hipMalloc((void**)&dc->act_d, S * (size_t)(F / 32) * 4));
@@ -3822,7 +4088,10 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
         if (wide) {
             GTR_CHECK(hipMalloc((void**)&dc->gu_raw, planes * S * (size_t)2 * F * 4));
             if (d.wdtype != GTEN_F16)
+            {
                 if (int rc = (d.wdtype == GTEN_Q4) ? mmv_prepare<GTEN_Q4>() : mmv_prepare<GTEN_Q8>()) return rc;
+                if (int rc = (d.wdtype == GTEN_Q4) ? mmvh_prepare<GTEN_Q4>() : mmvh_prepare<GTEN_Q8>()) return rc;
+            }
         }
         std::vector<const void*> tab(S * d.n_layers * 2);
         for (size_t q = 0; q < S; q++)
