@@ -107,6 +107,9 @@ int  gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const 
  * {prompt tokens, new tokens, shared steps, admissions, seconds in prompt processing, seconds in shared steps}. */
 int  gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
                            int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats);
+/* tests: k > 0 fixes the admission schedule of gten_host_batch_serve -- exactly k prompts are processed beside every slice
+ * (as far as free slots and the queue allow) instead of as many as fit while it runs; 0 restores the default */
+int  gten_host_batch_set_serve_schedule(gten_host_batch* b, int k);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
 int  gten_host_batch_decode_steps(gten_host_batch* b, int n_first, int count, int use_graph);   /* asynchronous: count consecutive steps, four per graph replay */

@@ -118,3 +118,36 @@ def test_slot_api_errors_are_reported(hip):
     got, st = b.serve([[1, 2, 3]], 64, -1, 16)
     assert len(got[0]) == 64
     b.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", [m for m in MODES() if m[0] == "q4"])
+def test_every_admission_schedule_gives_the_same_ids(hip, name, wd, ad):
+    """How many prompts get processed beside a slice depends on timing; the ids must not.  Fixed schedules (k prompts per
+    slice) x slice lengths walk through many (membership, steps-per-slice) patterns, each compared with generating alone."""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 31337, i) for i in range(len(cfg.weight_shapes()))]
+    lengths = [5, 40, 1, 17, 260, 9, 33, 100, 2, 64, 300, 319, 12, 250, 7, 21, 255, 256, 257, 130]
+    prompts = make_prompts(host, cfg, lengths, 1000)
+    total = 320
+    m = host.model(cfg)
+    for i, w in enumerate(weights):
+        m.set_weight(i, w)
+    alone = [m.generate(p, total) for p in prompts]
+    eos = int(alone[0][30])
+    want = [m.generate(p, total, eos) for p in prompts]
+    m.close()
+    b = host.batch(cfg, 8)
+    for i, w in enumerate(weights):
+        b.set_weight(i, w)
+    try:
+        for k in (1, 2, 3, 8):
+            for slice_steps in (16, 7, 4, 3):
+                b.set_serve_schedule(k)
+                got, _ = b.serve(prompts, total, eos, slice_steps)
+                for j in range(len(prompts)):
+                    assert got[j].tolist() == want[j].tolist(), (k, slice_steps, j, len(prompts[j]))
+    finally:
+        b.set_serve_schedule(0)
+    b.close()

@@ -1104,7 +1104,10 @@ __device__ __forceinline__ unsigned mmvh_scale(unsigned biased_pair, float bias,
     return out;
 }
 
-template <int WT, int RT, int FT>
+// SILU (gate | up, FT = 4): the workgroup owns ONE 32-wide slice of the FFN -- tiles 0, 1 its gate rows, tiles 2, 3 its up
+// rows, the whole K range -- and runs the slice's silu(gate) * up chain (k_dec_silumul_rows' arithmetic: every rounding the
+// modules make) in its epilogue, writing the f16 fragments the down projection reads: one launch instead of two.
+template <int WT, int RT, int FT, bool SILU>
 __global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a_ah, const void* __restrict__ a_w0, float* __restrict__ a_out,
                                                   const int a_d_in, const int a_d_out0, const int a_out_cols, const int a_S, const int a_n_mats,
                                                   const MmvRest rest)
@@ -1121,14 +1124,17 @@ __global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a
     float* red = (float*)g_smem;                              // [8][SP][16] -- over the slab, once the K loop is done
     uint16_t* dwl = (uint16_t*)(wl + max((size_t)FR * rowl, (size_t)8 * SP * 64));   // [FR][nbs] weight deltas
 
+    static_assert(!SILU || FT == 4, "the fused FFN epilogue owns two gate and two up tiles");
     int colw = blockIdx.x * FR, colbase = 0, m = 0;
-    if (a_n_mats > 1 && colw >= a_d_out0) {
+    if (!SILU && a_n_mats > 1 && colw >= a_d_out0) {
         colw -= a_d_out0; colbase = a_d_out0; m = 1;
         if (a_n_mats > 2 && colw >= rest.d_out1) { colw -= rest.d_out1; colbase += rest.d_out1; m = 2; }
     }
+    if (SILU) colw = blockIdx.x * 32;                         // the FFN slice (rows of both matrices)
     const void* w = (m == 0) ? a_w0 : (m == 1) ? rest.w1 : rest.w2;
     const int d_out = (m == 0) ? a_d_out0 : (m == 1) ? rest.d_out1 : rest.d_out2;
     const PackedW pw = packed_view(w, WT, d_out, a_d_in);
+    const PackedW pwu = packed_view(SILU ? rest.w1 : w, WT, d_out, a_d_in);      // (SILU: the up matrix, as wide as the gate matrix)
 
     // ---- 1. the slab, its deltas and this wave's first activation fragments: one memory round trip
     const int ppr = rowl >> 4;
@@ -1141,8 +1147,9 @@ __global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a
     unsigned dwv[FT][3];
 #pragma unroll
     for (int f = 0; f < FT; f++) {
-        const size_t frow = (size_t)min(colw + 16 * f + sr, d_out - 1);
-        const uint8_t* srow = pw.qs + frow * rowb;
+        const size_t frow = SILU ? (size_t)min(colw + 16 * (f & 1) + sr, d_out - 1) : (size_t)min(colw + 16 * f + sr, d_out - 1);
+        const PackedW& pm = (SILU && f >= 2) ? pwu : pw;
+        const uint8_t* srow = pm.qs + frow * rowb;
 #pragma unroll
         for (int k = 0; k < NPF; k++)
             if (32 * k < ppr) {
@@ -1150,7 +1157,7 @@ __global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a
                 const int gp = (WT == GTEN_Q4) ? b_lo + lp : (lp < nbs ? b_lo + lp : nb + b_lo + (lp - nbs));
                 wp[f][k] = *(const uint4*)(srow + (size_t)gp * 16);
             }
-        const unsigned* drow = (const unsigned*)(pw.ds + frow * nb + b_lo);
+        const unsigned* drow = (const unsigned*)(pm.ds + frow * nb + b_lo);
 #pragma unroll
         for (int k = 0; k < 3; k++) dwv[f][k] = drow[min(c0 + 32 * k, (nbs >> 1) - 1)];
     }
@@ -1237,6 +1244,39 @@ __global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a
     }
 
     // ---- 4. the eight K slices, added in wave order
+    if (SILU) {
+        float* fin = (float*)(dwl + (size_t)FR * nbs);        // [4][SP][16]: the slice's gate and up sums
+#pragma unroll
+        for (int f = 0; f < FT; f++) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < RT; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) red[(wid * SP + 16 * t + 4 * g + i) * 16 + l16] = acc[f][t][i];
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < SP * 16; idx += 512) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; q++) v += red[q * SP * 16 + idx];
+                fin[f * SP * 16 + idx] = v;
+            }
+        }
+        __syncthreads();
+        // 32 lanes = the 32 elements of one sequence's slice = one Q8 block
+        uint16_t* oh = (uint16_t*)a_out;
+        for (int idx = threadIdx.x; idx < SP * 32; idx += 512) {
+            const int r = idx >> 5, k = idx & 31;
+            float gv = act_round32(fin[((k >> 4) * SP + r) * 16 + (k & 15)], false);           // gate projection written in the activation dtype
+            gv = act_round32(gv / (1.0f + expf(-gv)), false);                                    // silu in place
+            const float uv = act_round32(fin[((2 + (k >> 4)) * SP + r) * 16 + (k & 15)], false);    // up projection written
+            const float v = gv * uv;                                                             // mul in place, then written:
+            const Q8Scale sc = q8_scale_from_absmax(max32(fabsf(v)));
+            const int qv = q8_round(v, sc.scale);
+            const int kp = (k & ~3) | ((k & 1) << 1) | ((k >> 1) & 1);
+            if (r < a_S) oh[(((size_t)blockIdx.x * RT + (r >> 4)) * 64 + (kp >> 3) * 16 + (r & 15)) * 8 + (kp & 7)] = f2h((float)qv * sc.ddeq);
+        }
+        return;
+    }
 #pragma unroll
     for (int f = 0; f < FT; f++) {
         __syncthreads();
@@ -3762,11 +3802,33 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
     const dim3 grid((cols + 16 * ft - 1) / (16 * ft), ks);
     const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2], a.plane};
     if (ft > 1)
-        DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, FTW>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
+        DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, FTW, false>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
     else
-        DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, 1>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
+        DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, 1, false>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
     return 0;
 }
+// gate | up with the silu * mul chain in the epilogue: one workgroup per 32-wide FFN slice, fragments for the down projection
+template <int WT>
+static int launch_mmvh_silu(int tag, const uint16_t* ah, const void* wgate, const void* wup, int n_ffn, int d_in, int S, uint16_t* out_frag)
+{
+    constexpr int WQ = (WT == GTEN_F16) ? GTEN_Q8 : WT;
+    GTR_REQUIRE(n_ffn % 32 == 0 && d_in % 256 == 0, "decoder: FFN %d x %d does not tile", n_ffn, d_in);
+    const size_t nbs = (size_t)d_in / 32, rt = (S + 15) / 16;
+    const size_t smem = std::max((size_t)64 * nbs * (WQ == GTEN_Q4 ? 16 : 32), (size_t)8 * 16 * rt * 64) + 64 * nbs * 2 + 4 * 16 * rt * 16 * 4;
+    GTR_REQUIRE(smem <= 150 * 1024 && nbs * (WQ == GTEN_Q4 ? 1 : 2) <= (size_t)32 * (MMV_MAXP / 4), "decoder: the FFN slab of d_in %d does not fit", d_in);
+    const MmvRest rest{wup, nullptr, n_ffn, 0, 0};
+    const dim3 grid(n_ffn / 32, 1);
+#define MMVH_S(RT_) DEC_LAUNCH(tag, (k_dec_mmvh<WQ, RT_, 4, true>), grid, dim3(512), smem, ah, wgate, (float*)out_frag, d_in, n_ffn, 0, S, 2, rest)
+    switch ((int)rt) {
+    case 1: MMVH_S(1); break;
+    case 2: MMVH_S(2); break;
+    case 3: MMVH_S(3); break;
+    default: MMVH_S(4); break;
+    }
+#undef MMVH_S
+    return 0;
+}
+
 template <int WT>
 static int launch_mmvh(int tag, const MmvhArgs& a)
 {
@@ -3785,9 +3847,12 @@ template <int WT>
 static int mmvh_prepare()
 {
     constexpr int FTA = (WT == GTEN_Q4) ? 4 : 2;        // <= 32 rows
-#define MMVH_ATTR(RT_, FT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmvh<WT, RT_, FT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+#define MMVH_ATTR(RT_, FT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmvh<WT, RT_, FT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
     MMVH_ATTR(1, 1); MMVH_ATTR(2, 1); MMVH_ATTR(3, 1); MMVH_ATTR(4, 1);
     MMVH_ATTR(1, FTA); MMVH_ATTR(2, FTA); MMVH_ATTR(3, 2); MMVH_ATTR(4, 2);
+#define MMVH_ATTR_S(RT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmvh<WT, RT_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+    MMVH_ATTR_S(1); MMVH_ATTR_S(2); MMVH_ATTR_S(3); MMVH_ATTR_S(4);
+#undef MMVH_ATTR_S
 #undef MMVH_ATTR
     return 0;
 }
@@ -3944,6 +4009,11 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         // gate|up has 176-352 workgroups already; the split measured +4 % at 16 sequences, +2 % at 64, -2 % at 32
         const char* kge = std::getenv("GTEN_HIP_MMV_KSPLIT_GU");
         const int ks_gu = (kge ? atoi(kge) == 2 : (S + 15) / 16 != 2) ? ks_of(E) : 1;
+        static const bool no_fuse = [] { const char* e = std::getenv("GTEN_HIP_MMV_NO_SILU_FUSE"); return e && e[0] == '1'; }();
+        const bool fuse_ffn = folded && !no_fuse && WT == GTEN_Q4 && E / 32 <= 32 * (MMV_MAXP / 4);      // (a tile's slab: <= 2 pieces per thread)
+        if (fuse_ffn) {
+            if ((rc = launch_mmvh_silu<WT>(KT_DEC_GEMV_GATEUP, (const uint16_t*)dc->stg_q, L.wgate, L.wup, F, E, S, (uint16_t*)dc->act_q))) return rc;
+        } else {
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows_f16, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F,
@@ -3951,6 +4021,7 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         else
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16,
                        ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum, folded ? 1 : 0);
+        }
         if ((rc = mmk(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;

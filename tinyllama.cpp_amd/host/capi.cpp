@@ -300,6 +300,13 @@ int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const i
     return 0;
 }
 
+int gten_host_batch_set_serve_schedule(gten_host_batch* b, int k)
+{
+    if (!b || k < 0) return -4;
+    b->batch->set_serve_schedule(k);
+    return 0;
+}
+
 int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
                           int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats)
 {

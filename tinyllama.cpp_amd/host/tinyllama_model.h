@@ -502,10 +502,12 @@ public:
         // One host thread: prompts are processed back to back on stream 1; between two prompts the slice on stream 0 is
         // polled, and when it has finished its ids are read and the next slice (with the slots that became ready) starts.
         bool queue_left = true;
+        int prepared_this_slice = 0;
         for (;;) {
             if (cnt > 0) {
                 int idle = 0;
-                GTEN_HIP_OK(gten_hip_stream_idle(0, &idle));
+                if (serve_schedule_ > 0) idle = prepared_this_slice >= serve_schedule_;   // fixed schedule (tests): k prompts per slice
+                else GTEN_HIP_OK(gten_hip_stream_idle(0, &idle));
                 int free_q = -1;
                 if (!idle && queue_left)
                     for (int q = 0; q < S && free_q < 0; q++)
@@ -514,9 +516,11 @@ public:
                     GTEN_HIP_OK(gten_hip_select_stream(1));
                     queue_left = prepare(free_q);
                     GTEN_HIP_OK(gten_hip_select_stream(0));
+                    prepared_this_slice++;
                     continue;
                 }
                 harvest();                                                  // (waits when nothing is left to prepare)
+                prepared_this_slice = 0;
             }
             if (n_live == 0 && n_ready == 0) {                              // nothing to decode: a prompt first
                 int free_q = -1;
@@ -533,10 +537,15 @@ public:
         return st;
     }
 
+    // Tests: k > 0 fixes the admission schedule -- exactly k prompts are processed beside every slice (as far as slots and
+    // queue allow) instead of "as many as fit while the slice runs", so that a run is repeatable slice by slice.
+    void set_serve_schedule(int k) { serve_schedule_ = k; }
+
 private:
     std::vector<std::unique_ptr<TinyLlama>> seqs_;
     gten_hip_decoder* dec_ = nullptr;
     int n_ctx_;
+    int serve_schedule_ = 0;
 
     void ensure_decoder()
     {
