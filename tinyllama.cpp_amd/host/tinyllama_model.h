@@ -464,6 +464,9 @@ public:
         auto t_slice = clock::now();
         // ready slots join, then the next slice starts (stream 0, asynchronous)
         auto launch_slice = [&]() {
+            // (the caches of the joining slots were filled on stream 1: the host has waited for that, and the explicit
+            //  stream-to-stream dependency makes the next launch on stream 0 acquire what another queue has written)
+            if (n_ready > 0) GTEN_HIP_OK(gten_hip_stream_wait(0, 1));
             for (int q = 0; q < S && n_ready > 0; q++)
                 if (job[(size_t)q] >= 0 && !live[(size_t)q]) {
                     const std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
@@ -498,6 +501,7 @@ public:
             }
             st.decode_s += std::chrono::duration<double>(clock::now() - t_slice).count();
             cnt = 0;
+            GTEN_HIP_OK(gten_hip_stream_wait(1, 0));            // (... and the other way round for the caches the parked slots leave)
         };
         // One host thread: prompts are processed back to back on stream 1; between two prompts the slice on stream 0 is
         // polled, and when it has finished its ids are read and the next slice (with the slots that became ready) starts.
