@@ -626,6 +626,135 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const MatArgs ms, int n_p
     }
 }
 
+// a lane's Q8 block (32 quants as 8 dwords + its stored delta) into a row of 34-byte blocks, lane L = block L: the
+// pair's 17 dwords are written by the even lane ([d0 | q0 | d1], dwords 0..8) and the odd lane (its quants, dwords 9..16)
+__device__ __forceinline__ void store_q8_block_lane(uint8_t* row, int L, const unsigned (&pq)[8], unsigned d16)
+{
+    const unsigned d_next = (unsigned)__shfl_down((int)d16, 1, 64);
+    unsigned* op = (unsigned*)(row + (size_t)(L >> 1) * 68);
+    if (!(L & 1)) {
+        op[0] = d16 | (pq[0] << 16);
+#pragma unroll
+        for (int j = 1; j < 8; j++) op[j] = (pq[j - 1] >> 16) | (pq[j] << 16);
+        op[8] = (pq[7] >> 16) | (d_next << 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) op[9 + j] = pq[j];
+    }
+}
+
+// k_splitk_finish for ONE 2048-wide projection with its residual sum, one WAVE per row (lane L = block L), continued into
+// the RMSNorm that reads the sum (gten/modules.cpp:236-240: inp_res, then ffn_norm): the planes are added in order and the
+// row is rounded (the projection's module tensor), the residual sum is rounded (the Residual's tensor), and RMSNorm runs on
+// the values it would read back -- k_rms_norm_q8w's arithmetic, tree and all -- leaving its Q8 row and, for the next W.x,
+// the f16 copy.  The bytes of three launches (plane sums, RMSNorm, conversion) from one.
+__global__ __launch_bounds__(64) void k_splitk_finish_norm(const MatArgs ms, int n_planes, int rows, int start_pos, const uint16_t* __restrict__ nw,
+                                                           uint8_t* __restrict__ nout, size_t nout_pitch, uint4* __restrict__ a16)
+{
+    constexpr int D = 2048;
+    const int L = threadIdx.x, odd = L & 1, r = blockIdx.x;
+    const float* p = ms.partial + (size_t)r * ms.part_pitch + ms.part_col0[0] + L * 32;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float4 t = ((const float4*)p)[j];
+        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+    for (int z = 1; z < n_planes; z++) {
+        const float* pz = p + (size_t)z * rows * ms.part_pitch;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float4 t = ((const float4*)pz)[j];
+            v[4 * j] = v[4 * j] + t.x; v[4 * j + 1] = v[4 * j + 1] + t.y; v[4 * j + 2] = v[4 * j + 2] + t.z; v[4 * j + 3] = v[4 * j + 3] + t.w;
+        }
+    }
+    // the residual row's block (nine dwords) and the norm weights, requested beside the planes
+    const unsigned* rp = (const unsigned*)(ms.resid + (size_t)(start_pos + r) * ms.resid_pitch + (size_t)(L >> 1) * 68) + (odd ? 8 : 0);
+    unsigned rw[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) rw[j] = rp[j];
+    uint4 wq[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wq[j] = ((const uint4*)(nw + L * 32))[j];
+    // 1. the projection's row
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) amax = fmaxf(amax, fabsf(v[i]));
+    const Q8Scale sc = q8_scale_from_absmax(amax);
+    const float dr = odd ? h2f((uint16_t)(rw[0] >> 16)) : h2f((uint16_t)(rw[0] & 0xffffu));
+    unsigned pq[8];
+    float amax2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned qr = odd ? rw[1 + j] : __builtin_amdgcn_alignbit(rw[j + 1], rw[j], 16);
+        unsigned wd = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int qv = q8_round(v[4 * j + i], sc.scale);
+            wd |= ((unsigned)qv & 0xffu) << (8 * i);
+            // 2. ops::add on the stored values (k_splitk_finish's expression)
+            v[4 * j + i] = (float)(int)(int8_t)(qr >> (8 * i)) * dr + (float)qv * sc.ddeq;
+            amax2 = fmaxf(amax2, fabsf(v[4 * j + i]));
+        }
+        pq[j] = wd;
+    }
+    store_q8_block_lane(ms.out[0] + (size_t)(start_pos + r) * ms.out_pitch[0], L, pq, sc.d16);
+    const Q8Scale ss = q8_scale_from_absmax(amax2);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        unsigned wd = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int qv = q8_round(v[4 * j + i], ss.scale);
+            wd |= ((unsigned)qv & 0xffu) << (8 * i);
+            v[4 * j + i] = (float)qv * ss.ddeq;                 // what RMSNorm reads back from the stored sum
+        }
+        pq[j] = wd;
+    }
+    store_q8_block_lane(ms.sum_out + (size_t)(start_pos + r) * ms.resid_pitch, L, pq, ss.d16);
+    // 3. RMSNorm of the sum (k_rms_norm_q8w)
+    float part[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float t8[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t8[i] = v[8 * k + i];
+        part[k] = sumsq_tree8(t8);
+    }
+    const float sq = wave_sum((part[0] + part[1]) + (part[2] + part[3]));
+    const float inv = recip_rn(sqrtf(sq / (float)D) + 1e-6f);
+    const unsigned* wh = (const unsigned*)wq;
+    float amax3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint16_t wb = (uint16_t)((i & 1) ? (wh[i >> 1] >> 16) : (wh[i >> 1] & 0xffffu));
+        v[i] = v[i] * inv * h2f(wb);
+        amax3 = fmaxf(amax3, fabsf(v[i]));
+    }
+    const Q8Scale sn = q8_scale_from_absmax(amax3);
+    unsigned hw[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        unsigned wd = 0;
+        unsigned short hq[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int qv = q8_round(v[4 * j + i], sn.scale);
+            wd |= ((unsigned)qv & 0xffu) << (8 * i);
+            hq[i] = f2h((float)qv * sn.ddeq);
+        }
+        pq[j] = wd;
+        hw[2 * j] = (unsigned)hq[0] | ((unsigned)hq[2] << 16);
+        hw[2 * j + 1] = (unsigned)hq[1] | ((unsigned)hq[3] << 16);
+    }
+    store_q8_block_lane(nout + (size_t)(start_pos + r) * nout_pitch, L, pq, sn.d16);
+    if (a16) {
+        uint4* dst = a16 + ((size_t)r * 64 + L) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[j] = make_uint4(hw[4 * j], hw[4 * j + 1], hw[4 * j + 2], hw[4 * j + 3]);
+    }
+}
+
 // f16 copy of the new Q8 activation rows, owned by the library and reused call after call (one stream)
 static int act_scratch(size_t a_bytes, size_t d_bytes, uint8_t** a16, float** da)
 {
@@ -751,6 +880,14 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
         if (int rc = partial_scratch((size_t)ks * rows * cols * 4, &planes)) return rc;
         ms.partial = planes; ms.part_pitch = cols;
         GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, (FAST || !C::QUANT) ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+        const auto al4 = [](const void* q, size_t pitch) { return ((uintptr_t)q & 3) == 0 && pitch % 4 == 0; };
+        if (m.norm_w && m.n == 1 && m.resid && m.d_out[0] == 2048 && al4(m.out[0], m.out_pitch[0]) && al4(m.resid, m.resid_pitch) &&
+            al4(m.sum_out, m.resid_pitch) && al4(m.norm_out, m.norm_out_pitch) && ((uintptr_t)m.norm_w & 15) == 0) {
+            GTR_LAUNCH(KT_MATMUL_MFMA, k_splitk_finish_norm, dim3(rows), dim3(64), 0, ms, ks, rows, start_pos, (const uint16_t*)m.norm_w,
+                       (uint8_t*)m.norm_out, m.norm_out_pitch, (uint4*)m.norm_a16);
+            if (m.norm_done) *m.norm_done = true;
+            return 0;
+        }
         const int blocks = rows * (cols / 32);
         GTR_LAUNCH(KT_MATMUL_MFMA, k_splitk_finish, dim3((blocks + 7) / 8), dim3(256), 0, ms, ks, rows, start_pos);
         return 0;

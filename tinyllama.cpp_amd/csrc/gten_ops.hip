@@ -991,6 +991,7 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
                        pE, E, start_pos, a16);
         return 0;
     };
+    bool normed = false;
     // attention half
     if ((rc = norm(b->inp, b->attn_norm_w, b->attn_norm_out))) return rc;
     {
@@ -1011,10 +1012,12 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
         MfmaMats m;
         m.n = 1; m.w[0] = b->wo; m.out[0] = b->o; m.out_pitch[0] = pE; m.d_out[0] = E;
         m.resid = b->inp; m.sum_out = b->h; m.resid_pitch = pE;
+        // (fast form: the plane sums of a shared K loop continue into the FFN's RMSNorm -- k_splitk_finish_norm)
+        if (fold) { m.norm_w = b->ffn_norm_w; m.norm_out = b->ffn_norm_out; m.norm_out_pitch = pE; m.norm_a16 = a16; m.norm_done = &normed; }
         if ((rc = gten_launch_matmul_mfma_multi(b->attn_out, pE, b->wdtype, m, GTEN_Q8, n, E, start_pos, fold))) return rc;
     }
     // feed-forward half
-    if ((rc = norm(b->h, b->ffn_norm_w, b->ffn_norm_out))) return rc;
+    if (!normed && (rc = norm(b->h, b->ffn_norm_w, b->ffn_norm_out))) return rc;
     {
         MfmaMats m;
         m.n = 2;

@@ -64,6 +64,14 @@ struct MfmaMats {
     const void* resid = nullptr;
     void* sum_out = nullptr;
     size_t resid_pitch = 0;
+    // optional: the RMSNorm that reads sum_out next (weights, its Q8 output rows, the f16 copy for the W.x after it or
+    // null).  Taken when the launch shares its K loop and the projection is 2048 wide (the plane sums then run one wave
+    // per row and continue into the norm); *norm_done tells the caller whether it was.
+    const void* norm_w = nullptr;
+    void* norm_out = nullptr;
+    size_t norm_out_pitch = 0;
+    void* norm_a16 = nullptr;
+    bool* norm_done = nullptr;
 };
 }
 int gten_launch_matmul_mfma_multi(const void* x, size_t x_pitch, int w_dtype, const gtr::MfmaMats& m, int out_dtype,
