@@ -353,3 +353,23 @@ def test_rms_norm_wave_kernel_is_bit_identical_to_the_row_kernel(hip, oracle):
     want = np.zeros_like(x)
     oracle.rms_norm(x, Q8, w, want, n, d, 0)
     compare_rows(many.download(shape=x.shape), want, Q8, d, "rms_norm wave kernel")
+
+
+@pytest.mark.parametrize("d", [2048, 256])
+def test_rope_wave_kernel_is_bit_identical_to_the_row_kernel(hip, oracle, d):
+    """Q8 rows with 64-wide heads, four or more at a time, take the one-wave-per-row kernel (lane = block, the partner half
+    of a head from the neighbouring lane): the bytes of the workgroup-per-row kernel that single rows take"""
+    r = rng(91 + d)
+    n = 41
+    x, _ = act_rows(oracle, r, n, d, Q8, scale=2.0)
+    many = hip.upload(x)
+    one = hip.upload(x)
+    hip.rotary_emb(many, Q8, n, d, 64, 3)
+    for row in range(3, n):
+        hip.rotary_emb(one, Q8, row + 1, d, 64, row)
+    got = many.download(shape=x.shape)
+    assert np.array_equal(got, one.download(shape=x.shape))
+    assert np.array_equal(got[:3], x[:3]), "rows before start_pos must not be touched"
+    want = x.copy()
+    oracle.rotary_emb(want, Q8, n, d, 64, 3)
+    compare_rows(got, want, Q8, d, "rope wave kernel", min_exact=0.999)

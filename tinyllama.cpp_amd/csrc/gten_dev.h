@@ -318,6 +318,23 @@ __device__ __forceinline__ int q8_round(float x, float scale)
     return (int)(int8_t)(int)round_half_away(x * scale);
 }
 
+// a lane's Q8 block (32 quants as 8 dwords + its stored delta) into a row of 34-byte blocks, lane L = block L: the
+// pair's 17 dwords are written by the even lane ([d0 | q0 | d1], dwords 0..8) and the odd lane (its quants, dwords 9..16)
+__device__ __forceinline__ void store_q8_block_lane(uint8_t* row, int L, const unsigned (&pq)[8], unsigned d16)
+{
+    const unsigned d_next = (unsigned)__shfl_down((int)d16, 1, 64);
+    unsigned* op = (unsigned*)(row + (size_t)(L >> 1) * 68);
+    if (!(L & 1)) {
+        op[0] = d16 | (pq[0] << 16);
+#pragma unroll
+        for (int j = 1; j < 8; j++) op[j] = (pq[j - 1] >> 16) | (pq[j] << 16);
+        op[8] = (pq[7] >> 16) | (d_next << 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) op[9 + j] = pq[j];
+    }
+}
+
 // ---- storage rows -> f32 in LDS ----
 // Q8 rows are 34-byte blocks (2-byte aligned only): byte loads keep it simple
 // and coalesce (32 consecutive lanes read 32 consecutive bytes).

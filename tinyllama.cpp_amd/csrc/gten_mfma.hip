@@ -626,23 +626,6 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const MatArgs ms, int n_p
     }
 }
 
-// a lane's Q8 block (32 quants as 8 dwords + its stored delta) into a row of 34-byte blocks, lane L = block L: the
-// pair's 17 dwords are written by the even lane ([d0 | q0 | d1], dwords 0..8) and the odd lane (its quants, dwords 9..16)
-__device__ __forceinline__ void store_q8_block_lane(uint8_t* row, int L, const unsigned (&pq)[8], unsigned d16)
-{
-    const unsigned d_next = (unsigned)__shfl_down((int)d16, 1, 64);
-    unsigned* op = (unsigned*)(row + (size_t)(L >> 1) * 68);
-    if (!(L & 1)) {
-        op[0] = d16 | (pq[0] << 16);
-#pragma unroll
-        for (int j = 1; j < 8; j++) op[j] = (pq[j - 1] >> 16) | (pq[j] << 16);
-        op[8] = (pq[7] >> 16) | (d_next << 16);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) op[9 + j] = pq[j];
-    }
-}
-
 // k_splitk_finish for ONE 2048-wide projection with its residual sum, one WAVE per row (lane L = block L), continued into
 // the RMSNorm that reads the sum (gten/modules.cpp:236-240: inp_res, then ffn_norm): the planes are added in order and the
 // row is rounded (the projection's module tensor), the residual sum is rounded (the Residual's tensor), and RMSNorm runs on

@@ -313,6 +313,56 @@ __global__ __launch_bounds__(256) void k_rope2(uint8_t* __restrict__ x0, size_t 
     store_row(v, dtype, d, row);
 }
 
+// ... and for Q8 rows with 64-wide heads, ONE WAVE per (row, matrix): lane L owns block L -- the first (even L) or second
+// (odd L) half of head L / 2 -- and takes its partner's 32 values from the neighbouring lane; k_rope's arithmetic per
+// element, the row in registers, dword loads and stores (8 -> 4 us per launch on a 256-id prompt).
+__global__ __launch_bounds__(64) void k_rope2_q8w(uint8_t* __restrict__ x0, size_t pitch0, int nblk0, uint8_t* __restrict__ x1, size_t pitch1, int nblk1,
+                                                  int start_pos, const float2* __restrict__ table)
+{
+    const int L = threadIdx.x, odd = L & 1, r = start_pos + blockIdx.x;
+    const bool second = blockIdx.y != 0;
+    if (L >= (second ? nblk1 : nblk0)) return;
+    uint8_t* row = second ? x1 + (size_t)r * pitch1 : x0 + (size_t)r * pitch0;
+    const unsigned* pw = (const unsigned*)(row + (size_t)(L >> 1) * 68) + (odd ? 8 : 0);
+    unsigned dw[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) dw[j] = pw[j];
+    float4 cs[16];                                              // (cos, sin) of this position for j = 0 .. 31, two per load
+#pragma unroll
+    for (int j = 0; j < 16; j++) cs[j] = ((const float4*)(table + (size_t)r * 32))[j];
+    const float dx = odd ? h2f((uint16_t)(dw[0] >> 16)) : h2f((uint16_t)(dw[0] & 0xffffu));
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned q = odd ? dw[1 + j] : __builtin_amdgcn_alignbit(dw[j + 1], dw[j], 16);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[4 * j + i] = (float)(int)(int8_t)(q >> (8 * i)) * dx;
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const float other = __shfl_xor(v[j], 1, 64);
+        const float c = (j & 1) ? cs[j >> 1].z : cs[j >> 1].x, sn = (j & 1) ? cs[j >> 1].w : cs[j >> 1].y;
+        // even lane: x0 * cos - x1 * sin with x1 the partner's; odd lane: x0 * sin + x1 * cos with x0 the partner's
+        v[j] = odd ? other * sn + v[j] * c : v[j] * c - other * sn;
+        amax = fmaxf(amax, fabsf(v[j]));
+    }
+    const Q8Scale sc = q8_scale_from_absmax(amax);
+    unsigned pq[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        unsigned wd = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wd |= ((unsigned)q8_round(v[4 * j + i], sc.scale) & 0xffu) << (8 * i);
+        pq[j] = wd;
+    }
+    store_q8_block_lane(row, L, pq, sc.d16);
+}
+static bool rope_q8w_ok(const void* x, size_t pitch, int dtype, int d, int d_head)
+{
+    return dtype == GTEN_Q8 && d_head == 64 && d % 64 == 0 && d <= 2048 && pitch % 4 == 0 && ((uintptr_t)x & 3) == 0;
+}
+
 enum { EW_SILU = 0, EW_MUL = 1, EW_ADD = 2 };
 
 // ops::silu / mul / add, gten/ops.h:673-711, 816-910
@@ -409,7 +459,7 @@ __global__ __launch_bounds__(256) void k_elementwise_q8x2(const uint8_t* __restr
 __global__ __launch_bounds__(256) void k_silu_mul_q8x2(uint8_t* gate, const uint8_t* __restrict__ up, size_t pitch, int pairs_per_row,
                                                        int start_pos, int total_pairs, uint4* __restrict__ a16)
 {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_pairs) return;
     const int r = start_pos + gid / pairs_per_row, pr = gid % pairs_per_row;
     const size_t off = (size_t)r * pitch + (size_t)pr * 68;
@@ -824,6 +874,10 @@ int gten_hip_rotary_emb(void* x, int dtype, size_t pitch, int n, int d, int d_he
     GTR_REQUIRE(n <= GTEN_ROPE_MAX_POS, "rotary_emb: position %d beyond the table (%d)", n, GTEN_ROPE_MAX_POS);
     const float2* table = nullptr;
     if (int rc = rope_table(d_head, &table)) return rc;
+    if (n - start_pos >= 4 && rope_q8w_ok(x, pitch, dtype, d, d_head)) {
+        GTR_LAUNCH(KT_ROPE, k_rope2_q8w, dim3(n - start_pos, 1), dim3(64), 0, (uint8_t*)x, pitch, d / 32, (uint8_t*)x, pitch, 0, start_pos, table);
+        return 0;
+    }
     GTR_LAUNCH(KT_ROPE, k_rope, dim3(n - start_pos), dim3(256), (size_t)d * 4, (uint8_t*)x, dtype, pitch, d, d_head, start_pos, table);
     return 0;
 }
@@ -1005,7 +1059,10 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     {
         const float2* table = nullptr;
         if ((rc = rope_table(dh, &table))) return rc;
-        GTR_LAUNCH(KT_ROPE, k_rope2, dim3(rows, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q, pE, E, (uint8_t*)b->k, pKV, KV, GTEN_Q8, dh, start_pos, table);
+        if (rope_q8w_ok(b->q, pE, GTEN_Q8, E, dh) && rope_q8w_ok(b->k, pKV, GTEN_Q8, KV, dh))
+            GTR_LAUNCH(KT_ROPE, k_rope2_q8w, dim3(rows, 2), dim3(64), 0, (uint8_t*)b->q, pE, E / 32, (uint8_t*)b->k, pKV, KV / 32, start_pos, table);
+        else
+            GTR_LAUNCH(KT_ROPE, k_rope2, dim3(rows, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q, pE, E, (uint8_t*)b->k, pKV, KV, GTEN_Q8, dh, start_pos, table);
     }
     if ((rc = gten_launch_attn_tiled(b->q, b->k, b->v, b->attn_out, pE, pKV, pE, n, b->n_heads, b->n_kv_heads, start_pos, fold ? a16 : nullptr))) return rc;
     {
@@ -1027,7 +1084,9 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     }
     {
         const int ppr = F / 64, total = rows * ppr;
-        GTR_LAUNCH(KT_ELEMWISE, k_silu_mul_q8x2, dim3((total + 255) / 256), dim3(256), 0, (uint8_t*)b->gate, (const uint8_t*)b->up, pF, ppr, start_pos, total, fold ? (uint4*)a16 : (uint4*)nullptr);
+        // (a thread walks 64 elements: short prompts get one-wave workgroups so that every CU has one)
+        const int nt = total < 256 * 256 ? 64 : 256;
+        GTR_LAUNCH(KT_ELEMWISE, k_silu_mul_q8x2, dim3((total + nt - 1) / nt), dim3(nt), 0, (uint8_t*)b->gate, (const uint8_t*)b->up, pF, ppr, start_pos, total, fold ? (uint4*)a16 : (uint4*)nullptr);
     }
     {
         MfmaMats m;
