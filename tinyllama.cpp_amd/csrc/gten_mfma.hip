@@ -905,8 +905,9 @@ static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int 
         if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
     }
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
-    static const int small_t = [] { const char* e = std::getenv("GTEN_HIP_MFMA_SMALL"); return e ? atoi(e) : 0; }();
-    if (rows > 32 && wgs(64, 64) >= small_t) MF_GO(2, 2);
+    // (measured and not kept: 32-row tiles for launches of fewer than 256 / 512 of the 64 x 64 tiles -- a 256-id prompt 5.10 ->
+    //  5.32 ms: the few workgroups wait for their loads, not for the matrix pipe; sharing the K loop is what helps, splitk_factor)
+    if (rows > 32) MF_GO(2, 2);
     MF_GO(1, 2);
 #undef MF_GO
 }
