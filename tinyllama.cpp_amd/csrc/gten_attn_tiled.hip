@@ -143,8 +143,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     const int row_base = r0 + 4 * lq;                      // this lane's rows: row_base + 16 rg + i
 
+    float mx[2][4], tot[2][4];
+    if (FAST) {
+        // ---- fast form, passes 0 and 1 in one walk: every lane keeps a running maximum and a running sum of exponentials
+        //      for the positions it visits (rescaled when its maximum grows), and the lanes' pairs are joined at the end --
+        //      M = max m, L = sum l exp(m - M).  One score computation and one K walk less; the hardware exponential.
+        float rm[2][4], rl[2][4];
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { rm[rg][i] = -INFINITY; rl[rg][i] = 0.f; }
+        for (int t = 0; t < ntile; t++) {
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+                if (c - lc > r_last) continue;
+                float s[2][4];
+                tile_scores(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (c <= row_base + 16 * rg + i) {
+                            const float mn = fmaxf(rm[rg][i], s[rg][i]);
+                            rl[rg][i] = rl[rg][i] * __expf(rm[rg][i] - mn) + __expf(s[rg][i] - mn);     // (exp(-inf) = 0 on the first visit)
+                            rm[rg][i] = mn;
+                        }
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float m16 = row16_max(rm[rg][i]);
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = m16;
+            }
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS)
+            s_row[threadIdx.x] = fmaxf(fmaxf(s_red[threadIdx.x], s_red[AT_ROWS + threadIdx.x]),
+                                       fmaxf(s_red[2 * AT_ROWS + threadIdx.x], s_red[3 * AT_ROWS + threadIdx.x]));
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) mx[rg][i] = s_row[16 * rg + 4 * lq + i];
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // (a lane that saw nothing of the row holds (-inf, 0): its term is 0 * exp(-inf) = 0)
+                const float ws = row16_sum(rl[rg][i] * __expf(rm[rg][i] - mx[rg][i]));
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = ws;
+            }
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS) {
+            float t = 0.f;
+            for (int i = 0; i < 4; i++) t += s_red[i * AT_ROWS + threadIdx.x];
+            s_row[threadIdx.x] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) tot[rg][i] = recip_rn(s_row[16 * rg + 4 * lq + i]);
+    } else {
     // ---- pass 0: row maxima
-    float mx[2][4];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++)
 #pragma unroll
@@ -182,7 +246,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     __syncthreads();
 
     // ---- pass 1: sums of exponentials, one running sum per (row, position mod 256)
-    float tot[2][4];
     {
         float ls[2][4][4];
 #pragma unroll
@@ -226,18 +289,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int i = 0; i < 4; i++) tot[rg][i] = s_row[16 * rg + 4 * lq + i];
     }
-    // fast form: the hardware exponential (above and below) and one reciprocal per row instead of a division per
-    // probability -- a few ulp on values that are about to be rounded to 8 bits.  (Measured and not kept: the scores as f16
-    // matrix products with the deltas folded into f16 copies of q and K -- no per-score scaling arithmetic, 13.9 -> 13.2 ms
-    // for a 2048-id prompt -- moves the outputs beyond the operator's band: a score error of 2^-11 relative is an error of
-    // the same size in EVERY probability of the row, tests/test_ops_gpu.py.)
-    if (FAST) {
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) tot[rg][i] = recip_rn(tot[rg][i]);
     }
-
+    // (fast form above: the hardware exponential and one reciprocal per row instead of a division per probability -- a few ulp on
+    //  values that are about to be rounded to 8 bits.  Measured and not kept: the scores as f16 matrix products with the deltas
+    //  folded into f16 copies of q and K -- no per-score scaling arithmetic, 13.9 -> 13.2 ms for a 2048-id prompt -- moves the
+    //  outputs beyond the operator's band: a score error of 2^-11 relative is an error of the same size in EVERY probability of
+    //  the row, tests/test_ops_gpu.py.)
     // ---- pass 2: probabilities in the activation dtype, times V
     const int ep = threadIdx.x & 31, rq = threadIdx.x >> 5;      // outputs: rows 4 rq .. 4 rq + 3, elements 2 ep, 2 ep + 1
     v2f acc[4][4];
