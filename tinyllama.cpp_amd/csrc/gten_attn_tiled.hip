@@ -501,8 +501,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     const int row_base = r0 + 4 * lq;
 
+    float mx[2][4], tot[2][4];
+    if (FAST) {
+        // ---- fast form: maxima and sums of exponentials in one walk (running pairs per lane, joined at the end), the
+        //      hardware exponential, one reciprocal per row -- as in k_attn_tiled_q8<true>
+        float rm[2][4], rl[2][4];
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { rm[rg][i] = -INFINITY; rl[rg][i] = 0.f; }
+        for (int t = 0; t < ntile; t++) {
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
+                if (c - lc > r_last) continue;
+                float s[2][4];
+                tile_scores_f16(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
+#pragma unroll
+                for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (c <= row_base + 16 * rg + i) {
+                            const float mn = fmaxf(rm[rg][i], s[rg][i]);
+                            rl[rg][i] = rl[rg][i] * __expf(rm[rg][i] - mn) + __expf(s[rg][i] - mn);
+                            rm[rg][i] = mn;
+                        }
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float m16 = row16_max(rm[rg][i]);
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = m16;
+            }
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS)
+            s_row[threadIdx.x] = fmaxf(fmaxf(s_red[threadIdx.x], s_red[AT_ROWS + threadIdx.x]),
+                                       fmaxf(s_red[2 * AT_ROWS + threadIdx.x], s_red[3 * AT_ROWS + threadIdx.x]));
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) mx[rg][i] = s_row[16 * rg + 4 * lq + i];
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float ws = row16_sum(rl[rg][i] * __expf(rm[rg][i] - mx[rg][i]));
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = ws;
+            }
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS) {
+            float t = 0.f;
+            for (int i = 0; i < 4; i++) t += s_red[i * AT_ROWS + threadIdx.x];
+            s_row[threadIdx.x] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) tot[rg][i] = recip_rn(s_row[16 * rg + 4 * lq + i]);
+    } else {
     // ---- pass 0: row maxima
-    float mx[2][4];
 #pragma unroll
     for (int rg = 0; rg < 2; rg++)
 #pragma unroll
@@ -540,7 +602,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     __syncthreads();
 
     // ---- pass 1: sums of exponentials (k_attn's 256 running sums per row and its tree, as in the Q8 kernel)
-    float tot[2][4];
     {
         float ls[2][4][4];
 #pragma unroll
@@ -585,6 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int i = 0; i < 4; i++) tot[rg][i] = s_row[16 * rg + 4 * lq + i];
     }
 
+    }
     // ---- pass 2: probabilities rounded to f16, times V
     const int ep = threadIdx.x & 31, rq = threadIdx.x >> 5;
     v2f acc[4][4];
@@ -605,7 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int rg = 0; rg < 2; rg++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const float pr = (any && c <= row_base + 16 * rg + i) ? expf(s[rg][i] - mx[rg][i]) / tot[rg][i] : 0.f;
+                    const float pr = (any && c <= row_base + 16 * rg + i) ? (FAST ? __expf(s[rg][i] - mx[rg][i]) * tot[rg][i] : expf(s[rg][i] - mx[rg][i]) / tot[rg][i]) : 0.f;
                     if (FAST) ((uint16_t*)s_ph)[(16 * rg + 4 * lq + i) * AT_PHPITCH + 64 * w + 16 * cg + lc] = f2h(pr);
                     else s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * cg + lc] = h2f(f2h(pr));
                 }
