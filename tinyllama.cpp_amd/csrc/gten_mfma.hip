@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     for (int j = 0; j < WN; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb & 1][t], bf[kb & 1][j], acc[t][j], 0, 0, 0);
             }
             // (measured and not kept: the expansion made unconditional -- one basic block -- and woven between the matrix
-            //  instructions with sched_group_barrier: 2048-id prompt 13.2 -> 15.1 ms)
+            //  instructions with sched_group_barrier: 2048-id prompt 13.2 -> 15.1 ms; woven by hand, one 8-element unit behind
+            //  every row of four matrix instructions, pinned with scheduling barriers: 12.4 -> 12.9 ms.  The two waves of a
+            //  SIMD already overlap each other's expansion and matrix phases.)
             __syncthreads();
             return;
         }
