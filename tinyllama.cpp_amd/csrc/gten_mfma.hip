@@ -454,7 +454,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // (measured and not kept: the expansion made unconditional -- one basic block -- and woven between the matrix
             //  instructions with sched_group_barrier: 2048-id prompt 13.2 -> 15.1 ms; woven by hand, one 8-element unit behind
             //  every row of four matrix instructions, pinned with scheduling barriers: 12.4 -> 12.9 ms.  The two waves of a
-            //  SIMD already overlap each other's expansion and matrix phases.)
+            //  SIMD already overlap each other's expansion and matrix phases.  Nor does expanding the whole matrix once per call
+            //  into an f16 scratch and running the f16-weights kernel pay, even at 2048 rows: 12.4 -> 13.4 ms -- the expansion
+            //  launch and the 3.5 x larger weight stream cost more than the per-workgroup expansion they replace.)
             __syncthreads();
             return;
         }
