@@ -145,68 +145,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     float mx[2][4], tot[2][4];
     if (FAST) {
-        // ---- fast form, passes 0 and 1 in one walk: every lane keeps a running maximum and a running sum of exponentials
-        //      for the positions it visits (rescaled when its maximum grows), and the lanes' pairs are joined at the end --
-        //      M = max m, L = sum l exp(m - M).  One score computation and one K walk less; the hardware exponential.
-        float rm[2][4], rl[2][4];
+        // ---- fast form: ONE walk over the K / V prefix.  The row maximum runs along (mx); a tile's probabilities are formed
+        //      against the maximum so far, e = exp(s - mx), rounded to Q8 blocks (the quants are scale-free; the stored block
+        //      delta is rounded at the tile's scale instead of the row's: relative 2^-11, the decode path's deviation 4) and
+        //      multiplied into V at once; when the maximum grows, the sums so far and the output accumulators are rescaled by
+        //      exp(old - new).  The row sum (lsum, per lane over the positions it owns) divides the output at the end.
 #pragma unroll
         for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) { rm[rg][i] = -INFINITY; rl[rg][i] = 0.f; }
-        for (int t = 0; t < ntile; t++) {
-#pragma unroll
-            for (int cg = 0; cg < 4; cg++) {
-                const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
-                if (c - lc > r_last) continue;
-                float s[2][4];
-                tile_scores(qf, kbase + (size_t)min(c, n - 1) * kv_pitch, lq, s);
-#pragma unroll
-                for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (c <= row_base + 16 * rg + i) {
-                            const float mn = fmaxf(rm[rg][i], s[rg][i]);
-                            rl[rg][i] = rl[rg][i] * __expf(rm[rg][i] - mn) + __expf(s[rg][i] - mn);     // (exp(-inf) = 0 on the first visit)
-                            rm[rg][i] = mn;
-                        }
-            }
-        }
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float m16 = row16_max(rm[rg][i]);
-                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = m16;
-            }
-        __syncthreads();
-        if (threadIdx.x < AT_ROWS)
-            s_row[threadIdx.x] = fmaxf(fmaxf(s_red[threadIdx.x], s_red[AT_ROWS + threadIdx.x]),
-                                       fmaxf(s_red[2 * AT_ROWS + threadIdx.x], s_red[3 * AT_ROWS + threadIdx.x]));
-        __syncthreads();
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) mx[rg][i] = s_row[16 * rg + 4 * lq + i];
-        __syncthreads();
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                // (a lane that saw nothing of the row holds (-inf, 0): its term is 0 * exp(-inf) = 0)
-                const float ws = row16_sum(rl[rg][i] * __expf(rm[rg][i] - mx[rg][i]));
-                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = ws;
-            }
-        __syncthreads();
-        if (threadIdx.x < AT_ROWS) {
-            float t = 0.f;
-            for (int i = 0; i < 4; i++) t += s_red[i * AT_ROWS + threadIdx.x];
-            s_row[threadIdx.x] = t;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) tot[rg][i] = recip_rn(s_row[16 * rg + 4 * lq + i]);
+            for (int i = 0; i < 4; i++) { mx[rg][i] = -INFINITY; tot[rg][i] = 1.0f; }
     } else {
     // ---- pass 0: row maxima
 #pragma unroll
@@ -303,6 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[rr][j] = (v2f){0.f, 0.f};
     v4f macc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // fast: [row tile], rows 16 rt + 4 lq + i, element 16 w + lc
+    float lsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // fast: this lane's share of the rows' sums of exponentials
 
     for (int t = 0; t < ntile; t++) {
         float p[2][4][4];
@@ -313,7 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) p[rg][cg][i] = 0.f;
+                    for (int i = 0; i < 4; i++) p[rg][cg][i] = FAST ? -INFINITY : 0.f;
                 continue;
             }
             float s[2][4];
@@ -321,8 +269,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int rg = 0; rg < 2; rg++)
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    p[rg][cg][i] = (c <= row_base + 16 * rg + i) ? (FAST ? __expf(s[rg][i] - mx[rg][i]) * tot[rg][i] : expf(s[rg][i] - mx[rg][i]) / tot[rg][i]) : 0.f;
+                for (int i = 0; i < 4; i++) {
+                    const bool vis = c <= row_base + 16 * rg + i;
+                    if (FAST) p[rg][cg][i] = vis ? s[rg][i] : -INFINITY;            // (the score; the probability below)
+                    else p[rg][cg][i] = vis ? expf(s[rg][i] - mx[rg][i]) / tot[rg][i] : 0.f;
+                }
+        }
+        if (FAST) {
+            // the tile's row maxima (16 lanes, then the four waves through LDS), the running maximum, the rescale
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float mt = row16_max(fmaxf(fmaxf(p[rg][0][i], p[rg][1][i]), fmaxf(p[rg][2][i], p[rg][3][i])));
+                    if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = mt;
+                }
+            __syncthreads();
+            if (threadIdx.x < AT_ROWS)
+                s_row[threadIdx.x] = fmaxf(fmaxf(s_red[threadIdx.x], s_red[AT_ROWS + threadIdx.x]),
+                                           fmaxf(s_red[2 * AT_ROWS + threadIdx.x], s_red[3 * AT_ROWS + threadIdx.x]));
+            __syncthreads();
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float mn = fmaxf(mx[rg][i], s_row[16 * rg + 4 * lq + i]);
+                    const float sc = __expf(mx[rg][i] - mn);                        // (0 on the first tile: exp(-inf))
+                    macc[rg][i] *= sc;
+                    lsum[rg][i] *= sc;
+                    mx[rg][i] = mn;
+#pragma unroll
+                    for (int cg = 0; cg < 4; cg++) {
+                        const float e = __expf(p[rg][cg][i] - mn);                  // (masked: exp(-inf) = 0)
+                        p[rg][cg][i] = e;
+                        lsum[rg][i] += e;
+                    }
+                }
         }
         // the probability row is stored as Q8 blocks along the context (gten/ops.h:996-997): a block = two
         // column groups x 16 lanes; masked entries are zeros, exactly what the partial tail block sees
@@ -408,9 +390,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     // ---- output rows in the activation dtype (store_row, gten/ops.h:73-96): a Q8 block = 16 lanes x 2 elements
     if (FAST) {
 #pragma unroll
+        for (int rg = 0; rg < 2; rg++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float ws = row16_sum(lsum[rg][i]);
+                if (lc == 0) s_red[w * AT_ROWS + 16 * rg + 4 * lq + i] = ws;
+            }
+#pragma unroll
         for (int rt2 = 0; rt2 < 2; rt2++)
 #pragma unroll
             for (int i = 0; i < 4; i++) s_o[(16 * rt2 + 4 * lq + i) * 64 + 16 * w + lc] = macc[rt2][i];
+        __syncthreads();
+        if (threadIdx.x < AT_ROWS) {
+            float t = 0.f;
+            for (int i = 0; i < 4; i++) t += s_red[i * AT_ROWS + threadIdx.x];
+            s_row[threadIdx.x] = recip_rn(t);
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -418,6 +413,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         v2f o = (v2f){0.f, 0.f};
         if (FAST) {
             o = *(const v2f*)(s_o + (4 * rq + rr) * 64 + 2 * ep);
+            const float rl = s_row[4 * rq + rr];
+            o.x *= rl; o.y *= rl;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) o += acc[rr][j];
