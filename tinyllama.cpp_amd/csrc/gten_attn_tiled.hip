@@ -252,8 +252,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     v4f macc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // fast: [row tile], rows 16 rt + 4 lq + i, element 16 w + lc
     float lsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // fast: this lane's share of the rows' sums of exponentials
 
+    // fast form: a V sub-tile's bytes are requested one sub-tile ahead (the first of a tile before its scores), so that the
+    // staging below never waits for memory
+    U4 vraw = {{0, 0, 0, 0}};
+    float vdel = 0.f;
+    auto vload = [&](int c0) {
+        const int pos = threadIdx.x >> 2, qtr = threadIdx.x & 3, b = qtr >> 1;
+        const uint8_t* vs_ = vbase + (size_t)min(c0 + pos, n - 1) * kv_pitch;
+        vraw = *(const U4*)(vs_ + 2 + 34 * b + 16 * (qtr & 1));
+        vdel = h2f(*(const uint16_t*)(vs_ + 34 * b));
+    };
     for (int t = 0; t < ntile; t++) {
         float p[2][4][4];
+        if (FAST) vload(t * AT_TILE);
 #pragma unroll
         for (int cg = 0; cg < 4; cg++) {
             const int c = t * AT_TILE + 64 * w + 16 * cg + lc;
@@ -333,8 +344,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 // stage 64 positions of this kv head's V slice as f32: thread = (position, quarter of the 64 elements)
                 const int pos = threadIdx.x >> 2, qtr = threadIdx.x & 3, b = qtr >> 1;
                 const uint8_t* vs_ = vbase + (size_t)min(c0 + pos, n - 1) * kv_pitch;
-                const U4 raw = *(const U4*)(vs_ + 2 + 34 * b + 16 * (qtr & 1));
-                const float d = h2f(*(const uint16_t*)(vs_ + 34 * b));
+                U4 raw = vraw;
+                float d = vdel;
+                if (!FAST) {
+                    raw = *(const U4*)(vs_ + 2 + 34 * b + 16 * (qtr & 1));
+                    d = h2f(*(const uint16_t*)(vs_ + 34 * b));
+                }
                 if (FAST) {
                     // the sub-tile transposed, as f16 values: element 16 qtr + 4 kk + j of this position
 #pragma unroll
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             s_vt[(16 * qtr + 4 * kk + j) * AT_VTPITCH + pos] = (_Float16)((float)(int8_t)(raw.v[kk] >> (8 * j)) * d);
+                    if (vs + 1 < AT_TILE / AT_VSUB && c0 + AT_VSUB <= r_last) vload(c0 + AT_VSUB);
                 } else {
                     float* dst = s_v + pos * 64 + 16 * qtr;
 #pragma unroll
