@@ -28,3 +28,24 @@ def test_host_code_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
     assert "host_sanitize ok" in r.stdout
+
+
+def test_modules_and_scheduler_under_sanitizers_against_a_stub_device(tmp_path):
+    """The host C++ ABOVE the HIP C-ABI -- gten modules (recorded single-row chains, the composed block call), TinyLlama /
+    TinyLlamaBatch, the continuous-batching scheduler, capi.cpp -- under ASan + UBSan, linked against tests/hip_stub.cpp (a
+    test-only stand-in for libgten_hip.so on host memory whose 'model' is a fixed next-id rule).  tests/host_sanitize_serve.cpp
+    checks that the reference's loop, the device sampler, the fixed batch and the queue through the slots (4 admission
+    schedules x 3 slice lengths, per-prompt budgets, 2 and 8 slots) all return the same ids."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_sanitize_serve")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tinyllama.cpp_amd"),
+           os.path.join(ROOT, "tests", "host_sanitize_serve.cpp"), os.path.join(ROOT, "tests", "hip_stub.cpp"),
+           os.path.join(ROOT, "tinyllama.cpp_amd", "host", "capi.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:protect_shadow_gap=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
+    assert "host_sanitize_serve ok" in r.stdout
