@@ -49,3 +49,30 @@ def test_modules_and_scheduler_under_sanitizers_against_a_stub_device(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
     assert "host_sanitize_serve ok" in r.stdout
+
+
+def test_stub_device_covers_the_whole_header(tmp_path):
+    """tests/hip_stub.cpp stands in for EVERY symbol include/gten_hip.h declares (so that new entry points cannot silently
+    fall out of the sanitizer run), and only tests/ refers to it"""
+    import ctypes
+    import re
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    so = str(tmp_path / "libhip_stub.so")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "hip_stub.cpp"), "-o", so], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = ctypes.CDLL(so)
+    text = open(os.path.join(ROOT, "include", "gten_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(gten_hip_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in include/gten_hip.h but tests/hip_stub.cpp does not define it"
+    # the product never refers to the stub
+    for base, _, files in os.walk(os.path.join(ROOT, "tinyllama.cpp_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                assert "hip_stub" not in open(os.path.join(base, f), errors="replace").read(), os.path.join(base, f)
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert "hip_stub" not in open(os.path.join(ROOT, f)).read()
