@@ -59,7 +59,7 @@ int         gten_hip_init(int device);               /* idempotent per process *
 const char* gten_hip_last_error(void);
 void*       gten_hip_stream(void);                   /* hipStream_t work is being queued on (the selected one) */
 int         gten_hip_sync(void);                     /* waits for the selected stream */
-/* The library owns two streams; every call queues on the selected one (0 at start).  Stream 1 exists so that the prompt of a
+/* The library owns two streams (the second is created when it is first selected); every call queues on the selected one (0 at start).  Stream 1 exists so that the prompt of a
  * NEW sequence can be processed beside the decode steps of the others (continuous batching, TinyLlamaBatch::serve): work on
  * different streams is unordered unless gten_hip_stream_wait(waiter, on) makes `waiter` wait for what `on` holds so far.
  * One calling thread; buffers touched on both streams are the caller's to order. */
@@ -175,7 +175,7 @@ int gten_hip_set_block_rows(int on);
  * model whose weights / K,V caches are the SAME device tensors the operators
  * above use (the caches are Linear::acv of the key / value projections,
  * gten/modules.cpp:188-201).  Results are the bytes the operator-by-operator
- * path produces (same rounding points); the work is fused into 6 launches per
+ * path produces (same rounding points); the work is fused into 5 launches per
  * block and replayed from one hipGraph, with the position n read from device
  * memory.  Rows < n-1 of the caches must already hold the context (from
  * earlier steps or from an operator-path prefill). */

@@ -14,7 +14,7 @@
 // One new row (decode): when forward() is called with exactly one new row on Embedding, then on each
 // AttentionBlock with the previous module's output, then on RMSNorm and EmbeddingLinear -- the sequence of
 // TinyLlama::logits (tinyllama.cpp:45-61) -- the calls are RECORDED and the whole row runs as one fused decoder
-// step (include/gten_hip.h "single-token decode fast path": 6 launches per block from one hipGraph instead of
+// step (include/gten_hip.h "single-token decode fast path": 5 launches per block from one hipGraph instead of
 // ~16 operator launches), on the same HBM tensors: weights, K/V caches (= attn.key.acv / attn.value.acv) and the
 // logits buffer (= EmbeddingLinear::acv).  Same bytes as the operator path for contexts up to 256 rows, f32
 // summation-order noise of the chunked softmax beyond (tests/test_dropin_gpu.py).  Any other use -- a different
