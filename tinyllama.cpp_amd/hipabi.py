@@ -164,6 +164,10 @@ class GtenHip:
         """prompt-sized W.x with quantized weights: exact form (scalar-build order, bit for bit) instead of the fast one"""
         self._check(self._prefill_exact(1 if on else 0))
 
+    def select_stream(self, idx):
+        """queue the following calls on the library's stream 0 or 1 (include/gten_hip.h)"""
+        self._check(self.lib.gten_hip_select_stream(int(idx)))
+
     def set_block_rows(self, on):
         """prompt-sized AttentionBlock calls as one composed call (default) or module by module"""
         self._check(self._set_block_rows(1 if on else 0))
