@@ -1,0 +1,42 @@
+"""not gpu: no kernel of libgten_hip.so may contain a packed-f32 VALU instruction (v_pk_mul_f32 / v_pk_add_f32 /
+v_pk_fma_f32 / v_pk_mov_b32).  Round 2 found them unsafe beside another stream's matrix-core kernel on the MI355X: with the
+SIMDs saturated by a neighbour's MFMA stream, their results came back wrong in the last 16 lanes of a wave (the fused
+decoder's RMSNorm prologue, profiles/README.md "packed f32 beside MFMA").  build.py switches them off in the code generator
+(-target-feature -packed-fp32-ops, -fno-slp-vectorize); this test compiles every kernel file to gfx950 assembly with the
+build's own flags and looks at what came out.  tests/test_neighbour_gpu.py is the run-time half."""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+PACKED = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32)\b", re.M)
+
+
+def test_generated_code_has_no_packed_f32_instructions(tmp_path):
+    from __graft_entry__ import load_package
+    b = load_package().build
+    if shutil.which(b.HIPCC) is None and not os.path.exists(b.HIPCC):
+        pytest.skip("no hipcc")
+    assert "-packed-fp32-ops" in b.HIP_FLAGS and "-fno-slp-vectorize" in b.HIP_FLAGS
+    flags = [f for f in b.HIP_FLAGS if f not in ("-shared", "-fPIC")]
+    srcs = b._sources(b.CSRC, (".hip",))
+    assert len(srcs) >= 5
+
+    def asm(src):
+        out = str(tmp_path / (os.path.basename(src) + ".s"))
+        r = subprocess.run([b.HIPCC] + flags + b.HIP_FILE_FLAGS.get(os.path.basename(src), []) + ["-S", "--cuda-device-only", "-o", out, src],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return open(out).read()
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        texts = list(pool.map(asm, srcs))
+    n_kernels = 0
+    for src, text in zip(srcs, texts):
+        n_kernels += text.count(".amdhsa_kernel ")
+        found = PACKED.findall(text)
+        assert not found, f"{os.path.basename(src)}: {len(found)} packed-f32 instructions ({sorted(set(found))})"
+    assert n_kernels > 100          # every template instance of the library went through the check

@@ -27,7 +27,18 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -amdgpu-kernarg-preload-count: the command processor loads the leading scalar kernel arguments into SGPRs while
 # the waves are created, so a kernel can form its first addresses without a scalar-load round trip (measured:
 # -0.3 us per dependent launch, tools/microbench_launch_floor.hip; 14 dwords fit beside the segment pointer).
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+# -fno-slp-vectorize, -packed-fp32-ops: NO packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in any kernel.  hipcc's
+# SLP vectorizer pairs neighbouring scalar f32 operations into them; on this chip they are half rate anyway, and -- found
+# in round 2 -- they are NOT SAFE beside another stream's matrix-core kernel: with the SIMDs saturated by a neighbour's
+# MFMA stream (a prompt's GEMMs beside the decode step), v_pk_*_f32 results of the fused decoder's RMSNorm prologue came
+# back wrong in the last 16 lanes of a wave (a deterministic "older" value, so 1 / rms was off by +0.3..0.5 % in ~25 % of
+# the workgroups of the q|k|v and lm_head launches; alone on the GPU every run was bit-identical).  Without the packed
+# instructions the same test is clean and the step is not slower (profiles/README.md, "packed f32 beside MFMA";
+# tests/test_no_packed_f32_cpu.py checks the generated code of every kernel).
+# (-target-feature -packed-fp32-ops makes the code generator itself refuse them -- float2 arithmetic in the sources and
+# the loop vectorizer produce them too; the host half of the compilation prints "not a recognized feature", harmless)
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+             "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-fPIC", "-shared",
              "-mllvm", "-amdgpu-kernarg-preload-count=16",
              "-Wall", "-Wno-unused-function", "-I" + INCLUDE]
 CXX_FLAGS = ["-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I" + INCLUDE, "-I" + PKG]
@@ -47,10 +58,8 @@ def _sources(d, exts):
     return sorted(out)
 
 
-# per-file additions.  Packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32) issues at half rate on gfx950 (and worse
-# beside MFMAs): the SLP vectorizer must not pair the per-block rescale / the p.V terms.
-HIP_FILE_FLAGS = {"gten_mfma.hip": ["-fno-slp-vectorize"], "gten_attn_tiled.hip": ["-fno-slp-vectorize"]}
-# (gten_decode.hip keeps the default: measured, no difference for its kernels)
+# per-file additions (none at present: -fno-slp-vectorize used to be one, for the MFMA kernels only)
+HIP_FILE_FLAGS = {}
 HIP_OBJ = os.path.join(CSRC, "_obj")
 
 
