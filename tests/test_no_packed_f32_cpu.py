@@ -3,7 +3,7 @@ v_pk_fma_f32 / v_pk_mov_b32).  Round 2 found them unsafe beside another stream's
 SIMDs saturated by a neighbour's MFMA stream, their results came back wrong in the last 16 lanes of a wave (the fused
 decoder's RMSNorm prologue, profiles/README.md "packed f32 beside MFMA").  build.py switches them off in the code generator
 (-target-feature -packed-fp32-ops, -fno-slp-vectorize); this test compiles every kernel file to gfx950 assembly with the
-build's own flags and looks at what came out.  tests/test_neighbour_gpu.py is the run-time half."""
+build's own flags and looks at what came out.  tests/test_zz_neighbour_gpu.py is the run-time half."""
 import os
 import re
 import shutil

@@ -1,4 +1,4 @@
-"""gpu: results must not depend on what ANOTHER stream is running on the chip.
+"""gpu: results must not depend on what ANOTHER stream is running on the chip.  (Named to run last: full-size models.)
 
 Round 2 found that they did: beside a kernel that keeps every SIMD's matrix core busy (a prompt's GEMMs on stream 1, or the
 register-only MFMA loop of tools/mfma_neighbour/neighbour.hip), the fused decoder's q|k|v and lm_head launches scaled their

@@ -8,7 +8,7 @@
 //   kind 6  k_mfma_i8  v_mfma_i32_16x16x64_i8 on registers only
 //   kind 7  k_mfma with 64-thread workgroups (one wave)
 // hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o libneighbour.so neighbour.hip ; ctypes: nb_init(), nb_run(kind, launches,
-// grid, spin), nb_sync().  tests/test_neighbour_gpu.py builds and uses it.
+// grid, spin), nb_sync().  tests/test_zz_neighbour_gpu.py builds and uses it.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 static hipStream_t g_s;
