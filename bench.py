@@ -715,6 +715,12 @@ def worker(args, rank, local_rank, world, dist):
                           "note": "sustained rates over the whole queue (256 prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
                                   "the library's second stream BESIDE the slices of 16 shared steps (prefill_s = host time spent in it, "
                                   "overlapped); slot_utilisation = new ids / (shared steps x slots)"}
+        try:
+            # the same queue once more, untimed: the ids must not depend on which prompt overlapped which slice
+            got2, _ = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
+            out["serving"]["same_ids_second_run"] = bool(len(got2) == len(got) and all(np.array_equal(a, b) for a, b in zip(got, got2)))
+        except Exception as e:                                       # a reporting extra: never costs the line
+            out["serving"]["same_ids_second_run"] = "not checked: %s" % type(e).__name__
         batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if secondary and args.prefill > 0:
