@@ -15,6 +15,28 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "oracle_parity: compares the HIP path with the oracle / the reference's goldens (collected first)")
+
+
+# Collection order of the -m gpu tests.  The driver runs `pytest -m gpu -x`: one failing HIP-against-HIP property must
+# not leave the comparisons with the oracle and the reference's goldens unmeasured (round 2: it did).  So: (0) the files
+# whose tests compare with the oracle / goldens, and single tests marked `oracle_parity`; (1) bit-identity and other
+# properties of the HIP path against itself; (2) the neighbour-stream tests (full-size models, slowest) last.
+_PARITY_FILES = ("test_golden_gpu", "test_ops_gpu", "test_model_gpu", "test_prefill_gpu", "test_multiseq_oracle_gpu")
+_LAST_FILES = ("test_zz_neighbour_gpu",)
+
+
+def _rank(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if mod in _LAST_FILES:
+        return 2
+    if mod in _PARITY_FILES or item.get_closest_marker("oracle_parity") is not None:
+        return 0
+    return 1
+
+
+def pytest_collection_modifyitems(session, config, items):
+    items.sort(key=_rank)                       # stable: the order inside a rank stays the collection order
 
 
 @pytest.fixture(scope="session")

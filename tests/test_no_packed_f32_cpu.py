@@ -13,6 +13,14 @@ from concurrent.futures import ThreadPoolExecutor
 import pytest
 
 PACKED = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32|v_pk_mov_b32)\b", re.M)
+# Mixed-precision fused forms with an fp16 RESULT (v_fma_mixlo_f16 / v_fma_mixhi_f16): ONE rounding of a product (+ addend)
+# where the sources -- and the reference, gten/ops.h:73-96 -- have a separate f32 operation and an fp16 convert.  Round 2
+# shipped a build whose fused decoder had them in its RMSNorm prologue while the operator kernel did not (a flag change
+# re-fused `v * inv * w` with the convert): fused != operator path by one fp16 ulp on ties.  gten_dev.h's f2hv() makes
+# the f32 value opaque ahead of every convert, so no flag can re-fuse it; this test reads the generated code.
+# (v_fma_mix_f32 -- f32 result, an fp16 source widened on the way in -- is exact widening + an fma the sources spell out
+# with __builtin_fmaf; -ffp-contract=off keeps the compiler from inventing others.  Not a rounding change, allowed.)
+MIXED = re.compile(r"^\s*(v_(?:fma|mad)_mix(?:lo|hi)_f16)\b", re.M)
 
 
 def test_generated_code_has_no_packed_f32_instructions(tmp_path):
@@ -39,4 +47,6 @@ def test_generated_code_has_no_packed_f32_instructions(tmp_path):
         n_kernels += text.count(".amdhsa_kernel ")
         found = PACKED.findall(text)
         assert not found, f"{os.path.basename(src)}: {len(found)} packed-f32 instructions ({sorted(set(found))})"
+        mixed = MIXED.findall(text)
+        assert not mixed, f"{os.path.basename(src)}: {len(mixed)} mixed-precision fused instructions ({sorted(set(mixed))})"
     assert n_kernels > 100          # every template instance of the library went through the check

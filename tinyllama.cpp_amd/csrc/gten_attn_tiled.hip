@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     for (int u = 0; u < 2; u++) {
                         const float x = p[rg][2 * bp + u][i];
                         const float pq = (float)q8_round(x, sc.scale) * sc.ddeq;
-                        if (FAST) s_ph[(16 * rg + 4 * lq + i) * AT_PHPITCH + 64 * w + 16 * (2 * bp + u) + lc] = (_Float16)pq;
+                        if (FAST) s_ph[(16 * rg + 4 * lq + i) * AT_PHPITCH + 64 * w + 16 * (2 * bp + u) + lc] = f2hv(pq);
                         else s_p[(16 * rg + 4 * lq + i) * AT_PPITCH + 64 * w + 16 * (2 * bp + u) + lc] = pq;
                     }
                 }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     for (int kk = 0; kk < 4; kk++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            s_vt[(16 * qtr + 4 * kk + j) * AT_VTPITCH + pos] = (_Float16)((float)(int8_t)(raw.v[kk] >> (8 * j)) * d);
+                            s_vt[(16 * qtr + 4 * kk + j) * AT_VTPITCH + pos] = f2hv((float)(int8_t)(raw.v[kk] >> (8 * j)) * d);
                     if (vs + 1 < AT_TILE / AT_VSUB && c0 + AT_VSUB <= r_last) vload(c0 + AT_VSUB);
                 } else {
                     float* dst = s_v + pos * 64 + 16 * qtr;
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             if (a16) {
                 // the f16 copy the o projection reads (gten_mfma.hip's fragment order: elements 0,2,1,3 of every four)
                 _Float16* ar = a16 + (size_t)(row - start_pos) * (n_heads * 64) + h * 64 + ((2 * ep) & ~3) + (ep & 1);
-                ar[0] = (_Float16)((float)(int)(int8_t)b0 * sc.ddeq);
-                ar[2] = (_Float16)((float)(int)(int8_t)b1 * sc.ddeq);
+                ar[0] = f2hv((float)(int)(int8_t)b0 * sc.ddeq);
+                ar[2] = f2hv((float)(int)(int8_t)b1 * sc.ddeq);
             }
         }
     }

@@ -3173,8 +3173,8 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const float pq = (float)q8_round(u ? p1 : p0, qs.scale) * qs.ddeq;
-            pl[(0 * 8 + 4 * hq + i) * PP + pl_[u]] = (_Float16)(live[u] ? pq * dvl[u][0] : 0.f);
-            pl[(1 * 8 + 4 * hq + i) * PP + pl_[u]] = (_Float16)(live[u] ? pq * dvl[u][1] : 0.f);
+            pl[(0 * 8 + 4 * hq + i) * PP + pl_[u]] = f2hv(live[u] ? pq * dvl[u][0] : 0.f);
+            pl[(1 * 8 + 4 * hq + i) * PP + pl_[u]] = f2hv(live[u] ? pq * dvl[u][1] : 0.f);
         }
     }
     __syncthreads();

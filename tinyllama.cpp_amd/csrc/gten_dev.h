@@ -24,9 +24,20 @@ __device__ __forceinline__ float h2f(uint16_t h)
     __builtin_memcpy(&x, &h, 2);
     return (float)x;
 }
+// The f32 value is made OPAQUE to the optimiser before the convert: the reference rounds to f32 first and to fp16
+// second (gten/ops.h:73-96 writes an f32 row through fp32_to_fp16).  Left transparent, the code generator folds a
+// preceding multiply / fma and the convert into ONE v_fma_mix{lo,hi}_f16 -- a single rounding of the exact product,
+// one fp16 ulp away on ties -- and whether it does depends on build flags and on the surrounding kernel (round 2: the
+// fused decoder's RMSNorm prologue got it, the operator kernel did not).  tests/test_no_packed_f32_cpu.py checks the
+// generated code: no v_fma_mix in any kernel.
+__device__ __forceinline__ _Float16 f2hv(float f)
+{
+    asm("" : "+v"(f));
+    return (_Float16)f;               // v_cvt_f16_f32, RNE, overflow -> inf
+}
 __device__ __forceinline__ uint16_t f2h(float f)
 {
-    const _Float16 x = (_Float16)f;   // v_cvt_f16_f32, RNE, overflow -> inf
+    const _Float16 x = f2hv(f);
     uint16_t h;
     __builtin_memcpy(&h, &x, 2);
     return h;

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_rms_norm(const uint8_t* __restrict__ x,
             uint8_t* blk = orow + (size_t)(i >> 5) * GTEN_Q8_BYTES;
             blk[2 + (i & 31)] = (uint8_t)(int8_t)qv;
             if ((i & 31) == 0) *(uint16_t*)blk = s.d16;
-            arow[(i & ~3) + ((i & 1) << 1) + ((i >> 1) & 1)] = (_Float16)((float)qv * s.ddeq);
+            arow[(i & ~3) + ((i & 1) << 1) + ((i >> 1) & 1)] = f2hv((float)qv * s.ddeq);
         }
         return;
     }
