@@ -100,16 +100,21 @@ def parse_args(argv=None):
 
 
 def csrc_fingerprint():
-    """sha256 (16 hex digits) over the kernel sources the in-tree libgten_hip.so is built from: what ties
-    profiles/traffic.json (PMC counters collected by tools/collect_traffic.sh) to the kernels being benched --
-    the GPU box has no .git, so a source hash rather than a commit id"""
+    """sha256 (16 hex digits) over what the in-tree libgten_hip.so is built from -- the kernel sources AND the compiler
+    flags (build.HIP_FLAGS, HIP_FILE_FLAGS: round 2 changed code generation of every kernel by a flag change alone):
+    what ties profiles/traffic.json (PMC counters collected by tools/collect_profiles.sh) to the kernels being
+    benched -- the GPU box has no .git, so a hash rather than a commit id"""
     import hashlib
+    from __graft_entry__ import load_package
+    b = load_package().build
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tinyllama.cpp_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
+    flags = [f for f in b.HIP_FLAGS if not f.startswith("-I")]          # (-I carries the checkout's absolute path)
+    h.update(repr((flags, sorted(b.HIP_FILE_FLAGS.items()))).encode())
     return h.hexdigest()[:16]
 
 
@@ -243,6 +248,80 @@ class StubDecoder:
 
     def close(self):
         pass
+
+
+class StubBatch:
+    """NOT a decoder (see StubDecoder): `serve` sleeps for the queue it is handed and returns prompt + filler ids, so the
+    CPU tests can drive the sharding of one global prompt queue over the replicas (--engine stub)."""
+    per_token_s = 2e-6
+
+    def serve(self, prompts, max_tokens, eos=-1, slice_steps=16, max_new=0, max_new_each=None):
+        import numpy as np
+        each = [max_new] * len(prompts) if max_new_each is None else [int(x) for x in max_new_each]
+        new = [min(e, max_tokens - len(p)) for p, e in zip(prompts, each)]
+        time.sleep(self.per_token_s * (sum(len(p) for p in prompts) + 8 * sum(new)))
+        got = [np.concatenate([np.asarray(p, np.int32), np.full(k, 7, np.int32)]) for p, k in zip(prompts, new)]
+        if os.environ.get("GTEN_BENCH_STUB_DROP_RANK") == os.environ.get("RANK", "0") and len(got) > 1:
+            got[1] = got[1][:len(prompts[1])]                 # tests: a replica that loses one request's new ids
+        return got, {"prompt_tokens": float(sum(len(p) for p in prompts)), "new_tokens": float(sum(new)), "steps": float(max(new, default=0)),
+                     "admissions": float(len(prompts)), "prefill_s": 0.0, "decode_s": 0.0}
+
+    def close(self):
+        pass
+
+
+def serving_queue(n_prompts, make_tokens, seed=2024):
+    """ONE global synthetic queue, the same on every rank: prompt j has 64..512 ids (ids from make_tokens(length, j)) and
+    a budget of 32..224 new ids, so that requests end at different times"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(64, 513, n_prompts)
+    budgets = rng.integers(32, 225, n_prompts).astype(np.int32)
+    return [list(make_tokens(int(n), j)) for j, n in enumerate(lens)], budgets
+
+
+def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist, device, sync):
+    """north_star's multi-GPU split: per-prompt sharding, no collective on the data path.  Rank r serves prompts
+    r, r + world, ... (replicas.shard_prompts) of ONE global queue through its own slots; the only cross-rank traffic is
+    the bookkeeping -- the barrier-bracketed timed region (MAX elapsed over ranks, new ids summed) and one all-reduce of
+    a served-counter per prompt, which must come back as exactly 1 everywhere."""
+    import numpy as np
+    import torch
+    prompts, budgets = serving_queue(n_global, make_tokens)
+    mine = rep.shard_prompts(n_global, rank, world)
+    my_prompts, my_budgets = [prompts[j] for j in mine], budgets[mine]
+    batch.serve(my_prompts[:slots], N_CTX, -1, 16, max_new=4)        # warm-up: graphs, first-use allocations
+    box = {}
+
+    def run():
+        box["got"], box["st"] = batch.serve(my_prompts, N_CTX, -1, 16, max_new_each=my_budgets)
+        return int(box["st"]["new_tokens"])
+
+    elapsed, new_total, per_rank = rep.timed_region(run, sync, dist=dist, device=device, per_rank=True)
+    served = torch.zeros(n_global, dtype=torch.int32, device=device)
+    for j, ids in zip(mine, box["got"]):
+        if len(ids) == len(prompts[j]) + min(int(budgets[j]), N_CTX - len(prompts[j])) and list(ids[:len(prompts[j])]) == list(prompts[j]):
+            served[j] += 1
+    ptoks = torch.tensor([box["st"]["prompt_tokens"], box["st"]["steps"]], dtype=torch.float64, device=device)
+    every = [ptoks]
+    if dist is not None:
+        dist.all_reduce(served)
+        every = [torch.zeros_like(ptoks) for _ in range(world)]
+        dist.all_gather(every, ptoks)
+    served = served.cpu().numpy()
+    prompt_tokens = int(sum(float(t[0].item()) for t in every))
+    steps = [int(t[1].item()) for t in every]
+    return {"slots_per_gpu": slots, "prompts": n_global, "prompts_per_rank": [len(rep.shard_prompts(n_global, r, world)) for r in range(world)],
+            "prompt_tokens": prompt_tokens, "new_tokens": int(new_total), "wall_s": round(elapsed, 3),
+            "new_tok_s": round(new_total / elapsed, 1), "all_tok_s": round((new_total + prompt_tokens) / elapsed, 1),
+            "per_rank": [{"rank": r, "new_tokens": k, "wall_s": round(e, 3), "new_tok_s": round(k / e, 1), "shared_steps": steps[r],
+                          "slot_utilisation": round(k / max(steps[r] * slots, 1), 3)} for r, (e, k) in enumerate(per_rank)],
+            "every_prompt_served_exactly_once": bool((served == 1).all()),
+            "note": "ONE global queue (prompts of 64..512 ids, 32..224 new ids each; %d per GPU: weak scaling) sharded round-robin "
+                    "over the replicas, each rank its shard through its own %d slots (continuous batching, prompts on the library's "
+                    "second stream beside slices of 16 shared steps); new_tok_s = new ids of all ranks / the slowest rank's wall "
+                    "time; no collective on the data path (the served-counter all-reduce and the timing all-gather are bookkeeping)"
+                    % (n_global // world, slots)}
 
 
 def load_replicas():
@@ -437,6 +516,20 @@ def worker(args, rank, local_rank, world, dist):
     # barrier + synchronise on both sides of exactly K steps; MAX elapsed over ranks
     elapsed, total_tokens, per_rank = rep.timed_region(run_steps, sync, dist=dist, device=ddev, per_rank=True)
     last = model.decode_result(n_of(W + K - 1, total)) if fused else step(n_of(W + K - 1, total))
+    # N > 1: one global prompt queue sharded over the replicas (north_star's per-prompt split), every rank its shard
+    # through its own continuous-batching slots -- the aggregate serving rate beside the batch-1 rate of `value`
+    sharded = None
+    if dist is not None and world > 1 and fused and args.serve > 0 and args.wide_streams > 1 and not args.brief:
+        S = args.wide_streams
+        if stub:
+            sbatch = StubBatch()
+            make_tokens = lambda n, j: np.random.default_rng(rep_seed(999, j)).integers(3, 31993, n).astype(np.int32)
+        else:
+            sbatch = host.batch(cfg, S)
+            sbatch.load_synthetic(args.seed)
+            make_tokens = lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j))
+        sharded = sharded_serving(sbatch, S, args.serve * world, make_tokens, rep, rank, world, dist, ddev, sync)
+        sbatch.close()
     # the replicas are done with each other: every rank leaves the process group here (rank 0 goes on alone with the
     # roofline / CPU-baseline legs, the others exit and free their host cores)
     if dist is not None:
@@ -530,6 +623,8 @@ def worker(args, rank, local_rank, world, dist):
         out["efficiency"] = round(tok_s / (world * solo), 4)
         out["efficiency_note"] = ("value / (n_gpus x rank 0's rate over the same K steps while the other GPUs idle at a "
                                   "barrier, same run); value = tokens of all ranks / the slowest rank's time")
+    if sharded is not None:
+        out["sharded_serving"] = sharded
     if args.rehearse_one_gpu and world > 1:
         out["metric"] = "REHEARSAL (all %d replicas share GPU 0): " % world + out["metric"]
     if stub:
@@ -699,10 +794,7 @@ def worker(args, rank, local_rank, world, dist):
         S = args.wide_streams
         batch = host.batch(cfg, S)
         batch.load_synthetic(args.seed)
-        rng = np.random.default_rng(2024)
-        lens = rng.integers(64, 513, args.serve)
-        prompts = [list(host.synthetic_tokens(int(n), seed=rep_seed(999, j))) for j, n in enumerate(lens)]
-        budgets = rng.integers(32, 225, args.serve).astype(np.int32)  # new ids per prompt: 32..224 (mean 128) -- requests end at different times
+        prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
         batch.serve(prompts[:S], N_CTX, -1, 16, max_new=4)           # warm-up: graphs, first-use allocations
         t0 = time.perf_counter()
         got, st = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)

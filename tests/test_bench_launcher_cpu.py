@@ -86,3 +86,45 @@ def test_same_worker_under_torch_distributed_run():
     assert p.returncode == 0, p.stderr[-2000:]
     r = result_line(p)
     assert r["n_gpus"] == 2 and len(r["per_rank"]) == 2 and "launcher" not in r
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_one_global_prompt_queue_is_sharded_over_the_replicas(n):
+    """north_star's multi-GPU split: `--gpus N` ranks take replicas.shard_prompts(n_prompts, rank, N) of ONE global queue
+    through their own slots; the N > 1 line carries the aggregate serving rate beside the batch-1 rate, and every prompt
+    is served exactly once (an all-reduced counter per prompt)"""
+    p = run_bench("--gpus", str(n), "--serve", "24")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = result_line(p)
+    sv = r["sharded_serving"]
+    assert sv["prompts"] == 24 * n and sv["prompts_per_rank"] == [24] * n
+    assert sv["every_prompt_served_exactly_once"] is True
+    assert [x["rank"] for x in sv["per_rank"]] == list(range(n))
+    assert sum(x["new_tokens"] for x in sv["per_rank"]) == sv["new_tokens"] > 0
+    assert abs(sv["new_tok_s"] - sv["new_tokens"] / sv["wall_s"]) / sv["new_tok_s"] < 0.02
+    assert sv["wall_s"] >= max(x["wall_s"] for x in sv["per_rank"]) - 1e-3
+    assert r["value"] > 0 and r["config"]["parallelism"] == f"replicas x{n}"        # the batch-1 rate is still the headline
+
+
+def test_a_lost_request_is_reported():
+    p = run_bench("--gpus", "2", "--serve", "24", env={"GTEN_BENCH_STUB_DROP_RANK": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert result_line(p)["sharded_serving"]["every_prompt_served_exactly_once"] is False
+
+
+def test_brief_runs_skip_the_sharded_queue():
+    p = run_bench("--gpus", "2", "--brief")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "sharded_serving" not in result_line(p)
+
+
+def test_shards_partition_the_queue():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gten_replicas_s", os.path.join(ROOT, "tinyllama.cpp_amd", "replicas.py"))
+    rep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rep)
+    for n_prompts in (0, 1, 7, 256, 1000):
+        for world in (1, 2, 3, 8):
+            shards = [rep.shard_prompts(n_prompts, r, world) for r in range(world)]
+            assert sorted(j for sh in shards for j in sh) == list(range(n_prompts))
+            assert max(len(sh) for sh in shards) - min(len(sh) for sh in shards) <= 1

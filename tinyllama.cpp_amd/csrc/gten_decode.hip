@@ -462,19 +462,19 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
             if (F16W) {
                 // f16 rows: NCH counts 512-element segments, lane takes 8 halves of each
                 const int e = (c * 512 + lane * 8 < d) ? c * 512 + lane * 8 : 0;
-                wq[j][c] = *(const uint4*)((const uint16_t*)qbase + (size_t)lr * d + e);
+                wq[j][c] = ld_w16((const uint16_t*)qbase + (size_t)lr * d + e);
                 wq1[j][c] = make_uint4(0, 0, 0, 0);
                 wd[j][c] = 0;
                 continue;
             }
             if (WT == GTEN_Q4) {
-                wq[j][c] = ((const uint4*)(qbase + (size_t)lr * nb * 16))[b];
+                wq[j][c] = ld_w16((const uint4*)(qbase + (size_t)lr * nb * 16) + b);
             } else {
                 const uint4* q0 = (const uint4*)(qbase + (size_t)lr * nb * 32);
-                wq[j][c] = q0[b];
-                wq1[j][c] = q0[nb + b];
+                wq[j][c] = ld_w16(q0 + b);
+                wq1[j][c] = ld_w16(q0 + nb + b);
             }
-            wd[j][c] = drow[b];
+            wd[j][c] = ld_w2(drow + b);
         }
     }
     __builtin_amdgcn_sched_barrier(0);            // keep every request above ahead of the prologue's arithmetic

@@ -43,6 +43,32 @@ __device__ __forceinline__ uint16_t f2h(float f)
     return h;
 }
 
+// ---- once-read weight stream: nontemporal loads (global_load ... nt) ----
+// A decode step reads every weight byte exactly once and each byte by ONE workgroup; with the default policy the
+// stream displaces what the step DOES re-read from the caches (residual rows, attention partials, K/V).  Measured on
+// the fused q4 step (profiles/README.md, round 3).  Activations, K/V and anything re-read keep the default policy.
+#ifndef GTEN_NT_WEIGHTS
+#define GTEN_NT_WEIGHTS 1
+#endif
+typedef unsigned gt_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_w16(const void* p)
+{
+#if GTEN_NT_WEIGHTS
+    const gt_u4v v = __builtin_nontemporal_load((const gt_u4v*)p);
+#else
+    const gt_u4v v = *(const gt_u4v*)p;
+#endif
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint16_t ld_w2(const uint16_t* p)
+{
+#if GTEN_NT_WEIGHTS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // ---- cross-lane moves on the DPP path (no LDS crossbar round trip) ----
 // CTRL: 0xB1 quad_perm[1,0,3,2] (xor 1) | 0x4E quad_perm[2,3,0,1] (xor 2) |
 //       0x141 row_half_mirror | 0x140 row_mirror | 0x142 row_bcast15 | 0x143 row_bcast31

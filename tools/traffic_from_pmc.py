@@ -42,13 +42,10 @@ def family(name):
 
 
 def csrc_fingerprint():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "tinyllama.cpp_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+    """the same hash bench.py checks (kernel sources + compiler flags): one definition, bench.py's"""
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.csrc_fingerprint()
 
 
 def read_counter(dirname, counter, last_steps=8):
