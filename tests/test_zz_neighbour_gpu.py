@@ -80,9 +80,10 @@ def test_fused_decode_step_beside_a_matrix_core_neighbour(hip, host_api, neighbo
     assert np.array_equal(step(), quiet)
 
 
-@pytest.mark.parametrize("n_seq", [8, 16])
-def test_shared_step_beside_a_matrix_core_neighbour(hip, host_api, neighbour, n_seq):  # noqa: F811
-    cfg = host_api.default_config(4, 3)
+@pytest.mark.parametrize("n_seq,wdtype,adtype", [(8, 4, 3), (16, 4, 3), (64, 4, 3), (32, 1, 1)], ids=["q4-8", "q4-16", "q4-64", "f16-32"])
+def test_shared_step_beside_a_matrix_core_neighbour(hip, host_api, neighbour, n_seq, wdtype, adtype):  # noqa: F811
+    """GEMV kernels (8), k_dec_mmvh + k_dec_attn_mm_g (16, 64), k_dec_mmv_f16 + the f16 grouped attention (f16, 32)"""
+    cfg = host_api.default_config(wdtype, adtype)
     b = host_api.batch(cfg, n_seq)
     b.load_synthetic(1234)
     toks = host_api.synthetic_tokens(400, seed=1000)
@@ -98,17 +99,64 @@ def test_shared_step_beside_a_matrix_core_neighbour(hip, host_api, neighbour, n_
 
     quiet = step()
     assert np.array_equal(step(), quiet)
-    for _ in range(5):
-        got = beside(neighbour, MFMA_F16, step, launches=30)
-        assert np.array_equal(got, quiet), f"{int((got != quiet).any(axis=1).sum())} of {n_seq} sequences changed beside the neighbour"
+    for kind in (MFMA_F16, MFMA_I8):
+        for _ in range(3):
+            got = beside(neighbour, kind, step, launches=30)
+            assert np.array_equal(got, quiet), f"{int((got != quiet).any(axis=1).sum())} of {n_seq} sequences changed beside neighbour kind {kind}"
 
 
-def test_prompt_kernels_beside_a_matrix_core_neighbour(hip, host_api, neighbour):  # noqa: F811
-    cfg = host_api.default_config(4, 3)
+@pytest.mark.parametrize("wdtype,adtype", [(4, 3), (3, 3), (1, 1)], ids=["q4", "q8", "f16"])
+def test_prompt_kernels_beside_a_matrix_core_neighbour(hip, host_api, neighbour, wdtype, adtype):  # noqa: F811
+    cfg = host_api.default_config(wdtype, adtype)
     m = host_api.model(cfg)
     m.load_synthetic(1234)
     toks = host_api.synthetic_tokens(300, seed=7)
     quiet = m.logits(toks[:256], 0)
-    for _ in range(4):
-        got = beside(neighbour, MFMA_F16, lambda: m.logits(toks[:256], 0), launches=40)
-        assert np.array_equal(got, quiet)
+    for kind in (MFMA_F16, MFMA_I8):
+        for _ in range(3):
+            got = beside(neighbour, kind, lambda: m.logits(toks[:256], 0), launches=40)
+            assert np.array_equal(got, quiet), f"prompt beside neighbour kind {kind}"
+
+
+def test_decode_step_beside_the_librarys_own_prompt_kernels(hip, host_api):  # noqa: F811
+    """the real serving case as the neighbour: a 512-id q4 prompt (f16 MFMA W.x, int8 MFMA scores) on the library's second
+    stream while the fused decode step of ANOTHER model object runs on stream 0"""
+    cfg = host_api.default_config(4, 3)
+    dec, pre = host_api.model(cfg), host_api.model(cfg)
+    dec.load_synthetic(1234)
+    pre.load_synthetic(1234)
+    toks = host_api.synthetic_tokens(600, seed=1000)
+    dec.logits(toks[:299], 0, want=False)
+
+    def step():
+        return dec.logits(toks[:300], 299)
+
+    quiet = step()
+    assert np.array_equal(step(), quiet)
+    for _ in range(6):
+        hip.select_stream(1)
+        pre.logits(toks[:512], 0, want=False)           # asynchronous: queued on stream 1
+        hip.select_stream(0)
+        got = step()
+        hip.select_stream(1); hip.sync(); hip.select_stream(0)
+        assert np.array_equal(got, quiet), f"max |d| {np.abs(got - quiet).max():.3g}"
+    dec.close(); pre.close()
+
+
+def test_standalone_reproducer(hip, tmp_path):  # noqa: F811
+    """tools/mfma_neighbour/repro.hip, built and run here: the scalar build of the victim and every packed f16 form the
+    library contains must be clean beside both neighbours.  (The packed-f32 forms with src1's halves swapped fail on the
+    MI355X boxes of rounds 2 and 3 -- reported, not asserted: a later chip or firmware may well fix them.)"""
+    script = os.path.join(NB_DIR, "run_repro.sh")
+    if not os.path.exists(shutil.which("hipcc") or "/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box")
+    r = subprocess.run(["bash", script, "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    scalar = [l for l in lines if l.startswith("victim") and "scalar" in l]
+    assert len(scalar) >= 8 and all(" 0 of " in l for l in scalar), "\n".join(scalar)
+    forms = [l for l in lines if l.strip().startswith("by form")]
+    for l in forms:                                         # [f16 forms 0..3 | f32 forms 4..7]
+        counts = [int(x) for x in l[l.rindex("[") + 1:l.rindex("]")].split()]
+        assert counts[:4] == [0, 0, 0, 0], l
+    print("\n".join(l for l in lines if "differ" in l and " 0 of " not in l))
