@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--wide-streams", type=int, default=64, choices=[0, 16, 32, 48, 64],
+    ap.add_argument("--wide-streams", type=int, default=64, choices=[0, 16, 32, 48, 64, 128, 192, 256],
                     help="also report the aggregate rate of this many sequences on the matrix-core decode path (0: skip)")
     ap.add_argument("--streams", type=int, default=8, choices=[0, 2, 4, 8, 16, 32, 48, 64],
                     help="also measure this many sequences sharing each weight pass on the GPU (0 = skip); "

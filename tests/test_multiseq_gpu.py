@@ -285,3 +285,46 @@ def test_multiseq_argument_errors_are_reported(hip):
     b.decode_step_ragged([1 + (q % 8) for q in range(16)])     # valid: runs
     assert 0 <= b.decode_result(3, 1 + 3) < cfg.n_vocab
     b.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+@pytest.mark.parametrize("n_seq", [128, 256])
+def test_lanes_equal_separate_64_sequence_decoders(hip, name, wd, ad, n_seq):
+    """more than 64 sequences run as LANES of 64 -- parallel branches of one graph, each on its sequences' rows of every
+    buffer: per sequence the logits and ids of a 64-sequence decoder holding the same sequences, bit for bit, eager and
+    replayed, from n = 1 across the attention chunk boundary, and with the sequences at different positions"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 97, i) for i in range(len(cfg.weight_shapes()))]
+    N = 266
+    streams = [host.synthetic_tokens(N + 2, seed=900 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
+    big = host.batch(cfg, n_seq)
+    for i, w in enumerate(weights):
+        big.set_weight(i, w)
+    for q in range(n_seq):
+        big.decode_begin(q, streams[q])
+    for n in range(1, 9):
+        big.decode_step(n, n % 2 == 0)                      # eager and single-step replays
+    big.decode_steps(9, N - 8, True)                        # four steps per replay
+    got_ids = [big.decode_result(q, N) for q in range(n_seq)]
+    got = [big.logits(q).copy() for q in range(n_seq)]
+    # ragged: every sequence one more step at its own position (half of them stay where they are and redo row N - 1)
+    ns = [N + (q % 2) for q in range(n_seq)]
+    big.decode_step_ragged(ns, True)
+    got_r = [big.logits(q).copy() for q in range(n_seq)]
+    big.close()
+    for lane in range(n_seq // 64):
+        small = host.batch(cfg, 64)
+        for i, w in enumerate(weights):
+            small.set_weight(i, w)
+        for q in range(64):
+            small.decode_begin(q, streams[64 * lane + q])
+        small.decode_steps(1, N, True)
+        for q in range(64):
+            assert small.decode_result(q, N) == got_ids[64 * lane + q], (name, lane, q)
+            assert np.array_equal(small.logits(q), got[64 * lane + q]), (name, lane, q)
+        small.decode_step_ragged(ns[64 * lane:64 * lane + 64], True)
+        for q in range(64):
+            assert np.array_equal(small.logits(q), got_r[64 * lane + q]), (name, "ragged", lane, q)
+        small.close()

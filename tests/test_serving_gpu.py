@@ -104,6 +104,29 @@ def test_wide_batch_serves_a_queue(hip):
     b.close()
 
 
+def test_queue_through_128_slots_equals_16_slots(hip):
+    """two lanes of 64 slots in one decoder: a queue longer than the slots gives, prompt by prompt, the ids the 16-slot
+    decoder gives (a sequence's rows do not depend on its neighbours or its slot)"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 2718, i) for i in range(len(cfg.weight_shapes()))]
+    lengths = [3 + (17 * i) % 150 for i in range(300)]
+    prompts = make_prompts(host, cfg, lengths, 91)
+    budgets = np.array([5 + (7 * i) % 60 for i in range(300)], np.int32)
+    outs = []
+    for slots in (128, 16):
+        b = host.batch(cfg, slots)
+        for i, w in enumerate(weights):
+            b.set_weight(i, w)
+        got, st = b.serve(prompts, 300, -1, 16, max_new_each=budgets)
+        assert st["admissions"] == 300
+        outs.append(got)
+        b.close()
+    for j in range(300):
+        assert outs[0][j].tolist() == outs[1][j].tolist(), j
+
+
 def test_slot_api_errors_are_reported(hip):
     pkg = load_package()
     host = pkg.load_host()

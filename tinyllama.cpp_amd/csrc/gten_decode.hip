@@ -33,6 +33,7 @@ using namespace gtd;
 extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
 
 #define DEC_CHUNK 256            // attention positions per workgroup
+#define DEC_MAX_LANES 4           // lanes of up to 64 sequences in one decoder (256 sequences)
 #define DEC_ATT_MAXCH 8          // chunk partials / statistics a consumer requests up front (2048 positions)
 #define GEMVM_F16_LDS_LIMIT 65536  // multi-sequence f16 inputs are staged in LDS up to this many bytes (8 sequences x 2048 x f32; the launchers raise
                                    // the kernel's dynamic LDS limit past the 64 KiB default where needed)
@@ -3293,7 +3294,47 @@ struct gten_hip_decoder {
     hipGraphExec_t exec_k = nullptr;    // the last kernel of a step advances it): one replay per DEC_GRAPH_STEPS tokens
     const float2* rope = nullptr;
     float2* rope_now = nullptr;       // [n_seq][d_head / 2], see Gemv8Args
+    // ---- more than 64 sequences: LANES.  The step of a wide decoder is a chain of ~180 dependent launches that leaves most
+    // of the chip idle between and inside them; a decoder of 128 / 192 / 256 sequences runs 2 / 3 / 4 such chains -- one per
+    // lane of 64 sequences, each on the rows of every buffer that belong to its sequences -- as parallel branches of ONE
+    // graph (fork behind the previous replay, join at the end), so the chains fill each other's gaps.  Per sequence the
+    // kernels, their arguments and therefore the results are those of a 64-sequence decoder.
+    int lanes = 1;
+    hipStream_t lane_stream[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};    // capture / eager side streams of lanes 1..
+    hipEvent_t lane_fork = nullptr, lane_join[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 };
+
+// the rows of every per-sequence buffer that belong to one lane (lane 0 of a single-lane decoder: the buffers themselves)
+struct LaneBufs {
+    int n_seq;
+    DecStep* step; int32_t* tokens; int32_t* result;
+    float *qkv_raw, *proj_raw, *down_raw, *scores, *stats, *att_part;
+    uint8_t *xbuf, *hbuf;
+    float* act_f; int8_t* act_q; float* act_d; int* act_sum;
+    const void** kv_tab;
+    int8_t* stg_q; float* stg_d; int* stg_sum; float* stg_f;
+    float* logits_m; float* gu_raw; float2* rope_now;
+};
+static LaneBufs lane_bufs(const gten_hip_decoder* dc, int lane)
+{
+    const gten_hip_decoder_desc& d = dc->d;
+    const size_t SL = (size_t)(dc->n_seq / dc->lanes), o = (size_t)lane * SL;      // sequences per lane, first sequence of this lane
+    const size_t E = (size_t)d.n_embd, F = (size_t)d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads, V = (size_t)d.n_vocab;
+    const size_t planes = dc->n_seq >= 16 ? 2 : 1, H = (size_t)d.n_heads, C = (size_t)dc->n_chunks;
+    LaneBufs b;
+    b.n_seq = (int)SL;
+    b.step = dc->step + o; b.tokens = dc->tokens + o * (d.max_ctx + 1); b.result = dc->result + o * (d.max_ctx + 2);
+    b.qkv_raw = dc->qkv_raw + o * planes * (E + 2 * KV); b.proj_raw = dc->proj_raw + o * planes * E; b.down_raw = dc->down_raw + o * planes * E;
+    b.scores = dc->scores + o * H * d.max_ctx; b.stats = dc->stats + o * H * C * 2; b.att_part = dc->att_part + o * H * C * dh;
+    b.xbuf = dc->xbuf + o * E * 4; b.hbuf = dc->hbuf + o * E * 4;
+    b.act_f = dc->act_f + o * F; b.act_q = dc->act_q + o * 2 * F; b.act_d = dc->act_d + o * (F / 32); b.act_sum = dc->act_sum + o * (F / 32);
+    b.kv_tab = dc->kv_tab ? dc->kv_tab + o * d.n_layers * 2 : nullptr;
+    b.stg_q = dc->stg_q ? dc->stg_q + o * 2 * E : nullptr; b.stg_d = dc->stg_d ? dc->stg_d + o * (E / 32) : nullptr;
+    b.stg_sum = dc->stg_sum ? dc->stg_sum + o * (E / 32) : nullptr; b.stg_f = dc->stg_f ? dc->stg_f + o * E : nullptr;
+    b.logits_m = dc->logits_m ? dc->logits_m + o * V : nullptr; b.gu_raw = dc->gu_raw ? dc->gu_raw + o * planes * 2 * F : nullptr;
+    b.rope_now = dc->rope_now + o * (dh / 2);
+    return b;
+}
 
 // many sequences, Q8 activations, 64-wide heads, 8 (or 4, 2, 1) query heads per kv head: grouped kernels
 static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
@@ -3918,18 +3959,19 @@ static int launch_mmv(int tag, const MmvArgs& a)
 // block sums in k_dec_mmv's order (eight K slices) instead of the GEMV wave tree, so a sequence's logits are not
 // bit-for-bit those of the single-sequence decoder (tests: model band, graph == eager, run-to-run identical).
 template <int WT>
-static int enqueue_step_wide(gten_hip_decoder* dc)
+static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
 {
+    const LaneBufs b = lane_bufs(dc, lane);
     const gten_hip_decoder_desc& d = dc->d;
-    const int S = dc->n_seq;
+    const int S = b.n_seq;
     const int E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads, V = d.n_vocab;
     const size_t kv_pitch = gten_hip_row_bytes(d.adtype, KV);
-    float* xbuf = (float*)dc->xbuf;
-    float* hbuf = (float*)dc->hbuf;
+    float* xbuf = (float*)b.xbuf;
+    float* hbuf = (float*)b.hbuf;
     int rc;
     bool grouped = false, grouped_known = false;
     Gemv8Args base{};
-    base.step = dc->step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
+    base.step = b.step; base.tok_stride = d.max_ctx + 1; base.part_stride = d.n_heads * dc->n_chunks * dh;
     base.best_stride = dc->n_best;
     const bool folded = WT != GTEN_F16 && mmv_folded();
     base.frag_h16 = folded ? 1 : 0;
@@ -3967,24 +4009,24 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         const gten_hip_layer_ptrs& L = dc->layers[l];
         Gemv8Args st = base;
         st.d_in = E; st.norm_w = (const uint16_t*)L.attn_norm; st.x_out = xbuf;
-        st.act_q = dc->stg_q; st.act_d = dc->stg_d; st.act_sum = dc->stg_sum; st.act_f = dc->stg_f;
+        st.act_q = b.stg_q; st.act_d = b.stg_d; st.act_sum = b.stg_sum; st.act_f = b.stg_f;
         if (l == 0) {
-            st.table = d.embed; st.rope = dc->rope; st.rope_now = dc->rope_now; st.rope_half = dh / 2; st.n_vocab = V; st.tokens = dc->tokens;
+            st.table = d.embed; st.rope = dc->rope; st.rope_now = b.rope_now; st.rope_half = dh / 2; st.n_vocab = V; st.tokens = b.tokens;
             rc = launch_stage_frag<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
         } else {
-            st.res_a = hbuf; st.res_raw = dc->down_raw; st.raw_stride = E; st.raw_plane = ks_of(F) > 1 ? S * E : 0;
+            st.res_a = hbuf; st.res_raw = b.down_raw; st.raw_stride = E; st.raw_plane = ks_of(F) > 1 ? S * E : 0;
             rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
         }
         if (rc) return rc;
         const int QW = E + 2 * KV;
         const int ks_qkv = S <= 32 ? ks_of(E) : 1;             // (measured: 160 x 2 workgroups of 4 row tiles run slower than 160)
-        if ((rc = mmk(KT_DEC_GEMV_QKV, dc->stg_q, dc->stg_d, dc->qkv_raw, QW, E, ks_qkv, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
+        if ((rc = mmk(KT_DEC_GEMV_QKV, b.stg_q, b.stg_d, b.qkv_raw, QW, E, ks_qkv, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
         AttnArgs t{};
-        t.step = dc->step; t.qkv_raw = dc->qkv_raw; t.kv_pitch = kv_pitch; t.scores = dc->scores; t.stats = dc->stats;
-        t.att_part = dc->att_part; t.rope = dc->rope; t.rope_now = dc->rope_now;
+        t.step = b.step; t.qkv_raw = b.qkv_raw; t.kv_pitch = kv_pitch; t.scores = b.scores; t.stats = b.stats;
+        t.att_part = b.att_part; t.rope = dc->rope; t.rope_now = b.rope_now;
         t.adtype = d.adtype; t.n_heads = d.n_heads; t.n_kv = d.n_kv_heads; t.d_head = dh; t.max_ctx = d.max_ctx;
         t.n_chunks = dc->n_chunks; t.n_embd = E;
-        t.kv_tab = (const void* const*)dc->kv_tab; t.layer = l; t.n_layers = d.n_layers;
+        t.kv_tab = (const void* const*)b.kv_tab; t.layer = l; t.n_layers = d.n_layers;
         t.qkv_stride = QW; t.scores_stride = d.n_heads * d.max_ctx; t.stats_stride = d.n_heads * dc->n_chunks * 2;
         t.part_stride = d.n_heads * dc->n_chunks * dh;
         t.qkv_plane = ks_qkv > 1 ? S * QW : 0;
@@ -3993,18 +4035,18 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         if (!grouped_known) { grouped = attention_grouped_ok(t, S); grouped_known = true; }
         if ((rc = grouped ? launch_attention_grouped(t, S) : launch_attention(t, agrid, smem1))) return rc;
         Gemv8Args sa = base;
-        sa.d_in = E; sa.att_part = dc->att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
-        sa.att_stats = dc->stats; sa.stats_stride = d.n_heads * dc->n_chunks * 2;
-        sa.act_q = dc->stg_q; sa.act_d = dc->stg_d; sa.act_sum = dc->stg_sum; sa.act_f = dc->stg_f;
+        sa.d_in = E; sa.att_part = b.att_part; sa.d_head = dh; sa.d_head_shift = __builtin_ctz(dh); sa.n_chunks = dc->n_chunks;
+        sa.att_stats = b.stats; sa.stats_stride = d.n_heads * dc->n_chunks * 2;
+        sa.act_q = b.stg_q; sa.act_d = b.stg_d; sa.act_sum = b.stg_sum; sa.act_f = b.stg_f;
         rc = (grouped ? grouped_one_pass(t, S) : attention_one_pass(dh)) ? launch_stage_frag<WT, PRO_ATTW>(KT_DEC_STAGE, sa, S)
                                                                          : launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S);
         if (rc) return rc;
-        if ((rc = mmk(KT_DEC_GEMV_O, dc->stg_q, dc->stg_d, dc->proj_raw, E, E, ks_of(E), L.wo, E))) return rc;
+        if ((rc = mmk(KT_DEC_GEMV_O, b.stg_q, b.stg_d, b.proj_raw, E, E, ks_of(E), L.wo, E))) return rc;
         Gemv8Args sh = base;
-        sh.d_in = E; sh.res_a = xbuf; sh.res_raw = dc->proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
+        sh.d_in = E; sh.res_a = xbuf; sh.res_raw = b.proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
         sh.raw_plane = ks_of(E) > 1 ? S * E : 0;
         sh.norm_w = (const uint16_t*)L.ffn_norm;
-        sh.act_q = dc->stg_q; sh.act_d = dc->stg_d; sh.act_sum = dc->stg_sum; sh.act_f = dc->stg_f;
+        sh.act_q = b.stg_q; sh.act_d = b.stg_d; sh.act_sum = b.stg_sum; sh.act_f = b.stg_f;
         if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
         // gate|up has 176-352 workgroups already; the split measured +4 % at 16 sequences, +2 % at 64, -2 % at 32
         const char* kge = std::getenv("GTEN_HIP_MMV_KSPLIT_GU");
@@ -4012,48 +4054,49 @@ static int enqueue_step_wide(gten_hip_decoder* dc)
         static const bool no_fuse = [] { const char* e = std::getenv("GTEN_HIP_MMV_NO_SILU_FUSE"); return e && e[0] == '1'; }();
         const bool fuse_ffn = folded && !no_fuse && WT == GTEN_Q4 && E / 32 <= 32 * (MMV_MAXP / 4);      // (a tile's slab: <= 2 pieces per thread)
         if (fuse_ffn) {
-            if ((rc = launch_mmvh_silu<WT>(KT_DEC_GEMV_GATEUP, (const uint16_t*)dc->stg_q, L.wgate, L.wup, F, E, S, (uint16_t*)dc->act_q))) return rc;
+            if ((rc = launch_mmvh_silu<WT>(KT_DEC_GEMV_GATEUP, (const uint16_t*)b.stg_q, L.wgate, L.wup, F, E, S, (uint16_t*)b.act_q))) return rc;
         } else {
-        if ((rc = mmk(KT_DEC_GEMV_GATEUP, dc->stg_q, dc->stg_d, dc->gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
+        if ((rc = mmk(KT_DEC_GEMV_GATEUP, b.stg_q, b.stg_d, b.gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)
-            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows_f16, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F,
-                       ks_gu > 1 ? S * 2 * F : 0, (uint16_t*)dc->act_q);
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows_f16, dim3(F / 256, S), dim3(256), 0, (const float*)b.gu_raw, F,
+                       ks_gu > 1 ? S * 2 * F : 0, (uint16_t*)b.act_q);
         else
-            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)dc->gu_raw, F, (S + 15) / 16,
-                       ks_gu > 1 ? S * 2 * F : 0, dc->act_q, dc->act_d, dc->act_sum, folded ? 1 : 0);
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)b.gu_raw, F, (S + 15) / 16,
+                       ks_gu > 1 ? S * 2 * F : 0, b.act_q, b.act_d, b.act_sum, folded ? 1 : 0);
         }
-        if ((rc = mmk(KT_DEC_GEMV_DOWN, dc->act_q, dc->act_d, dc->down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
+        if ((rc = mmk(KT_DEC_GEMV_DOWN, b.act_q, b.act_d, b.down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
-    sf.d_in = E; sf.res_a = hbuf; sf.res_raw = dc->down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
+    sf.d_in = E; sf.res_a = hbuf; sf.res_raw = b.down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
     sf.raw_plane = ks_of(F) > 1 ? S * E : 0;
-    sf.act_q = dc->stg_q; sf.act_d = dc->stg_d; sf.act_sum = dc->stg_sum; sf.act_f = dc->stg_f;
+    sf.act_q = b.stg_q; sf.act_d = b.stg_d; sf.act_sum = b.stg_sum; sf.act_f = b.stg_f;
     if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
-    if ((rc = mm(KT_DEC_GEMV_HEAD, dc->stg_q, dc->stg_d, dc->stg_sum, dc->logits_m, V, E, d.lm_head, V))) return rc;
-    DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)dc->logits_m, (const int*)nullptr,
-               V, dc->step, dc->result, V, d.max_ctx + 2, dc->tokens, d.max_ctx + 1);
+    if ((rc = mm(KT_DEC_GEMV_HEAD, b.stg_q, b.stg_d, b.stg_sum, b.logits_m, V, E, d.lm_head, V))) return rc;
+    DEC_LAUNCH(KT_DEC_ARGMAX, k_dec_argmax, dim3(S), dim3(1024), 0, (const float*)b.logits_m, (const int*)nullptr,
+               V, b.step, b.result, V, d.max_ctx + 2, b.tokens, d.max_ctx + 1);
     return 0;
 }
 
 template <int WT>
-static int enqueue_multi(gten_hip_decoder* dc)
+static int enqueue_multi(gten_hip_decoder* dc, int lane)
 {
     switch (dc->n_seq) {
     case 2: return enqueue_step_multi<WT, 2>(dc);
     case 4: return enqueue_step_multi<WT, 4>(dc);
     case 8: return enqueue_step_multi<WT, 8>(dc);
     }
-    if (dc->n_seq >= 16) return enqueue_step_wide<WT>(dc);
+    if (dc->n_seq >= 16) return enqueue_step_wide<WT>(dc, lane);
     return fail(-4, "decoder: n_seq %d not supported for this configuration", dc->n_seq);
 }
 
-static int enqueue(gten_hip_decoder* dc)
+// one step of one lane (a decoder of up to 64 sequences has the single lane 0)
+static int enqueue_lane(gten_hip_decoder* dc, int lane)
 {
     if (dc->n_seq > 1) {
         switch (dc->d.wdtype) {
-        case GTEN_F16: return enqueue_multi<GTEN_F16>(dc);
-        case GTEN_Q8: return enqueue_multi<GTEN_Q8>(dc);
-        case GTEN_Q4: return enqueue_multi<GTEN_Q4>(dc);
+        case GTEN_F16: return enqueue_multi<GTEN_F16>(dc, lane);
+        case GTEN_Q8: return enqueue_multi<GTEN_Q8>(dc, lane);
+        case GTEN_Q4: return enqueue_multi<GTEN_Q4>(dc, lane);
         }
     }
     switch (dc->d.wdtype) {
@@ -4062,6 +4105,34 @@ static int enqueue(gten_hip_decoder* dc)
     case GTEN_Q4: return enqueue_step_q8act<GTEN_Q4>(dc);
     }
     return fail(-4, "decoder: bad weight dtype %d", dc->d.wdtype);
+}
+
+// `count` consecutive steps.  Several lanes: lane 0's chain on the current stream, the others on the decoder's side
+// streams, forked behind whatever the current stream holds and joined at the end -- under stream capture these become
+// parallel branches of the graph, eagerly they are real events.  The lanes never touch each other's rows, and a lane's
+// steps follow each other in its own stream: nothing else needs ordering.
+static int enqueue(gten_hip_decoder* dc, int count = 1)
+{
+    if (dc->lanes <= 1) {
+        for (int i = 0; i < count; i++)
+            if (int rc = enqueue_lane(dc, 0)) return rc;
+        return 0;
+    }
+    hipStream_t main_s = stream();
+    GTR_CHECK(hipEventRecord(dc->lane_fork, main_s));
+    for (int g = 1; g < dc->lanes; g++) GTR_CHECK(hipStreamWaitEvent(dc->lane_stream[g], dc->lane_fork, 0));
+    int rc = 0;
+    for (int g = 0; g < dc->lanes && !rc; g++) {
+        if (g) gtr::stream_override(dc->lane_stream[g]);
+        for (int i = 0; i < count && !rc; i++) rc = enqueue_lane(dc, g);
+        gtr::stream_override(nullptr);
+    }
+    // (join even after a failure: a capture must not be left with dangling branches)
+    for (int g = 1; g < dc->lanes; g++) {
+        GTR_CHECK(hipEventRecord(dc->lane_join[g], dc->lane_stream[g]));
+        GTR_CHECK(hipStreamWaitEvent(main_s, dc->lane_join[g], 0));
+    }
+    return rc;
 }
 
 static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, const gten_hip_layer_ptrs* layers,
@@ -4084,8 +4155,9 @@ static int decoder_create_common(const gten_hip_decoder_desc* desc, const gten_h
     GTR_REQUIRE(pair_ok, "decoder_create: unsupported dtype pair (%d,%d) (tinyllama.cpp:258-265)", d.wdtype, d.adtype);
     GTR_REQUIRE(d.embed && d.final_norm && d.lm_head, "decoder_create: null model pointer");
     const bool wide = n_seq >= 16;
-    GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8 || (wide && n_seq <= 64 && n_seq % 16 == 0),
-                "decoder_create: n_seq %d not in {1, 2, 4, 8, 16, 32, 48, 64}", n_seq);
+    GTR_REQUIRE(n_seq == 1 || n_seq == 2 || n_seq == 4 || n_seq == 8 || (wide && n_seq <= 64 && n_seq % 16 == 0) ||
+                (n_seq > 64 && n_seq <= 64 * DEC_MAX_LANES && n_seq % 64 == 0),
+                "decoder_create: n_seq %d not in {1, 2, 4, 8, 16, 32, 48, 64, 128, 192, 256}", n_seq);
     GTR_REQUIRE(!wide || (d.n_ffn % 256 == 0 && d.n_embd % 256 == 0 && (dh * d.n_kv_heads) % 16 == 0),
                 "decoder_create: n_seq >= 16 runs the W.x on the matrix cores: n_embd and n_ffn %% 256 == 0");
     GTR_REQUIRE(n_seq == 1 || (kv && dh == 64), "decoder_create: multi-sequence decode needs the cache table and d_head 64");
@@ -4112,6 +4184,12 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     const bool wide = n_seq >= 16;
     dc->d = d;
     dc->n_seq = n_seq;
+    dc->lanes = (n_seq + 63) / 64;
+    for (int g = 1; g < dc->lanes; g++) {
+        GTR_CHECK(hipStreamCreateWithFlags(&dc->lane_stream[g], hipStreamNonBlocking));
+        GTR_CHECK(hipEventCreateWithFlags(&dc->lane_join[g], hipEventDisableTiming));
+    }
+    if (dc->lanes > 1) GTR_CHECK(hipEventCreateWithFlags(&dc->lane_fork, hipEventDisableTiming));
     dc->layers.assign(layers, layers + d.n_layers);
     dc->n_chunks = (d.max_ctx + DEC_CHUNK - 1) / DEC_CHUNK;
     static_assert(GTEN_ROPE_MAX_POS <= DEC_ATT_MAXCH * DEC_CHUNK, "max_ctx (checked above) bounds the attention chunks the consumers request up front");
@@ -4212,6 +4290,11 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
                     dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now, dc->dummy_kv};
     for (void* b : bufs) if (b) hipFree(b);
+    for (int g = 1; g < DEC_MAX_LANES; g++) {
+        if (dc->lane_stream[g]) { hipStreamSynchronize(dc->lane_stream[g]); hipStreamDestroy(dc->lane_stream[g]); }
+        if (dc->lane_join[g]) hipEventDestroy(dc->lane_join[g]);
+    }
+    if (dc->lane_fork) hipEventDestroy(dc->lane_fork);
     delete dc;
     return 0;
 }
@@ -4246,8 +4329,7 @@ static int run_steps_free(gten_hip_decoder* dc, int count)
     while (count >= DEC_GRAPH_STEPS) {
         if (!dc->exec_k) {
             GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
-            int rc = 0;
-            for (int i = 0; i < DEC_GRAPH_STEPS && !rc; i++) rc = enqueue(dc);
+            const int rc = enqueue(dc, DEC_GRAPH_STEPS);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(stream(), &g);
             if (rc) { if (g) hipGraphDestroy(g); return rc; }

@@ -35,7 +35,9 @@ int fail(int code, const char* fmt, ...)
     return code ? code : -1;
 }
 
-hipStream_t stream() { return g_streams[g_cur]; }
+static hipStream_t g_override = nullptr;
+hipStream_t stream() { return g_override ? g_override : g_streams[g_cur]; }
+void stream_override(hipStream_t s) { g_override = s; }
 bool inited() { return g_inited; }
 
 // RoPE angles use the host libm exactly as the reference does
@@ -83,13 +85,13 @@ void prof_before(int tag)
         g_ev_tag.push_back(tag);
     }
     g_ev_tag[g_ev_used] = tag;
-    hipEventRecord(g_ev[2 * g_ev_used], g_stream);
+    hipEventRecord(g_ev[2 * g_ev_used], stream());
 }
 
 void prof_after(int)
 {
     if (!g_prof_on || g_ev_used >= kMaxPairs) return;
-    hipEventRecord(g_ev[2 * g_ev_used + 1], g_stream);
+    hipEventRecord(g_ev[2 * g_ev_used + 1], stream());
     g_ev_used++;
 }
 
