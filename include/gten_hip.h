@@ -169,6 +169,25 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos);
  * the environment variable GTEN_HIP_NO_BLOCK_ROWS=1 sets the same at start */
 int gten_hip_set_block_rows(int on);
 
+/* SEVERAL prompts as one row matrix (batched prompt processing; round 3).  The rows of a prompt-sized call are
+ * row-independent in every operator except two: the position RoPE rotates by, and the rows attention looks back over.
+ * With row segments set -- starts[0] = 0 < starts[1] < ... < starts[n_segments] = the row count, every segment >= 16 rows --
+ * gten_hip_block_rows (start_pos 0, n = starts[n_segments]) treats rows [starts[k], starts[k + 1]) as prompt k: position =
+ * row - starts[k], attention inside the segment only; everything else runs once over all rows (one W.x per projection for
+ * all prompts).  Per prompt the results do not depend on the other segments: the W.x launches of a segmented call never
+ * share a K loop between workgroups (a K split chosen by the row count would), so a prompt gets the same bits alone
+ * or beside others.  gten_hip_rotary_emb / gten_hip_qkv_attn REFUSE to run while segments are set (they would rotate
+ * and attend across prompts).  n_segments = 0 clears.  The caller copies each prompt's K / V rows from the shared row
+ * matrix into its own caches: gten_hip_copy_ranges. */
+int gten_hip_set_row_segments(const int32_t* starts, int n_segments);
+/* 1 when gten_hip_block_rows computes segmented calls for this configuration (else the modules would run one by one and
+ * the two operators above would refuse): ask before setting segments */
+int gten_hip_row_segments_ok(int n_embd, int n_ffn, int n_heads, int n_kv_heads, int wdtype, int adtype);
+/* up to GTEN_HIP_MAX_COPY_RANGES device-to-device copies (non-overlapping) in ONE launch on the current stream */
+#define GTEN_HIP_MAX_COPY_RANGES 64
+typedef struct { void* dst; const void* src; size_t bytes; } gten_hip_copy_range;
+int gten_hip_copy_ranges(const gten_hip_copy_range* ranges, int n);
+
 /* ---- single-token decode fast path -------------------------------------
  * One call = one decoded token = TinyLlama::logits(tokens, start_pos = n-1)
  * (tinyllama.cpp:45-61) plus the greedy argmax of tinyllama.cpp:416-424, for a

@@ -20,8 +20,11 @@ namespace {
 char g_err[256] = "";
 int g_stream_idx = 0;
 int g_block_rows = 1;
-int32_t g_last_token = 0;        // of the last token_embed: tokens[n - 1] and n
-int g_last_n = 0;
+std::vector<int32_t> g_tokens;   // ids of the last token_embed (rows [0, n))
+std::vector<int32_t> g_stub_seg; // gten_hip_set_row_segments: starts[0 .. n]
+std::vector<int32_t> g_rule_seg; // ... as they were when the rows were embedded (the caller clears them before it asks for logits)
+const char* g_norm_out = nullptr; // output rows of the last rms_norm (the final norm, when the lm_head form follows) and their pitch
+size_t g_norm_pitch = 0;
 
 int fail(const char* fmt, ...)
 {
@@ -103,21 +106,53 @@ int gten_hip_token_embed(const void*, int, int n_vocab, const int32_t* tokens, v
     if (n <= 0 || start_pos < 0 || start_pos >= n) return fail("token_embed: rows");
     for (int i = start_pos; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= n_vocab) return fail("token_embed: id %d", tokens[i]);
-    g_last_token = tokens[n - 1];
-    g_last_n = n;
+    g_tokens.assign(tokens, tokens + n);
+    g_rule_seg = g_stub_seg;
     return 0;
 }
-int gten_hip_matmul_2d(const void*, int, size_t, const void*, int, void* out, int out_dtype, size_t, int n, int, int d_out, int start_pos)
+int gten_hip_matmul_2d(const void* x, int, size_t, const void*, int, void* out, int out_dtype, size_t, int n, int, int d_out, int start_pos)
 {
     if (out_dtype == GTEN_F32 && n - start_pos == 1) {       // the lm_head form: one-hot logits of the rule's next id
         float* lg = (float*)out;
         for (int i = 0; i < d_out; i++) lg[i] = 0.f;
-        lg[next_id(g_last_token, g_last_n, d_out)] = 1.f;
+        // which row of the last embedded row matrix: the caller hands over a pointer to ONE row of the final norm's output
+        // (gten/ops.h, the 1-D form); the last row when that cannot be told.  With row segments set (several prompts in one
+        // matrix) the row's context length counts from its prompt's first row.
+        if (g_tokens.empty()) return fail("matmul_2d (lm_head): nothing embedded");
+        long row = (long)g_tokens.size() - 1;
+        if (g_norm_out && g_norm_pitch && (const char*)x >= g_norm_out) {
+            const long r = (long)(((const char*)x - g_norm_out) / (long)g_norm_pitch);
+            if (r < (long)g_tokens.size()) row = r;
+        }
+        int first = 0;
+        for (size_t k = 0; k + 1 < g_rule_seg.size(); k++)
+            if (g_rule_seg[k] <= row) first = g_rule_seg[k];
+        lg[next_id(g_tokens[(size_t)row], (int)row + 1 - first, d_out)] = 1.f;
     }
     return 0;
 }
 int gten_hip_set_prefill_exact(int) { return 0; }
-int gten_hip_rms_norm(const void*, int, size_t, const void*, void*, size_t, int, int, int) { return 0; }
+int gten_hip_row_segments_ok(int, int, int, int, int, int) { return g_block_rows; }
+int gten_hip_set_row_segments(const int32_t* starts, int n)
+{
+    if (n > 0 && (!starts || starts[0] != 0)) return fail("set_row_segments: starts[0] must be 0");
+    for (int k = 0; k < n; k++)
+        if (starts[k + 1] - starts[k] < 16) return fail("set_row_segments: short segment");
+    g_stub_seg.assign(starts, starts + (n > 0 ? n + 1 : 0));
+    return 0;
+}
+int gten_hip_copy_ranges(const gten_hip_copy_range* r, int n)
+{
+    if (!r || n < 0 || n > GTEN_HIP_MAX_COPY_RANGES) return fail("copy_ranges: bad arguments");
+    for (int i = 0; i < n; i++) std::memmove(r[i].dst, r[i].src, r[i].bytes);
+    return 0;
+}
+int gten_hip_rms_norm(const void*, int, size_t, const void*, void* out, size_t out_pitch, int, int, int)
+{
+    g_norm_out = (const char*)out;
+    g_norm_pitch = out_pitch;
+    return 0;
+}
 int gten_hip_rotary_emb(void*, int, size_t, int, int, int, int) { return 0; }
 int gten_hip_silu(const void*, void*, int, size_t, int, int, int) { return 0; }
 int gten_hip_mul(const void*, const void*, void*, int, size_t, int, int, int) { return 0; }

@@ -3,7 +3,7 @@
 // stand-in for libgten_hip.so whose "model" is a fixed next-id rule) in a binary built with -fsanitize=address,undefined
 // (tests/test_host_sanitize_cpu.py).  What is checked besides the sanitizers: every way of generating -- the reference's
 // loop through logits(), the device sampler, the fixed batch, the queue through the slots under several admission schedules
-// and slice lengths -- returns the same ids.  Exits 0 when every check holds.
+// and slice lengths, one by one or (16 slots) several prompts per row matrix -- returns the same ids.  Exits 0 when every check holds.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -78,11 +78,13 @@ int main()
 
     // ---- the fixed batch and the queue through the slots
     CHECK(gten_host_batch_create(&cfg, 3) == nullptr);
-    for (int n_seq : {2, 8}) {
+    // (16 slots: prompts of >= 16 ids are processed as segments of ONE row matrix -- TinyLlamaBatch::prefill_many, the
+    //  segmented gten_hip_block_rows and the K / V range copies -- mixed with the one-by-one path of the short ones)
+    for (int n_seq : {2, 8, 16}) {
         gten_host_batch* b = gten_host_batch_create(&cfg, n_seq);
         CHECK(b);
         CHECK(gten_host_batch_load_synthetic(b, 1234) == 0);
-        {
+        if (n_seq <= 8) {       // (the fixed batch wants room behind every prompt: the first 8 lengths have it, the 12th fills the context)
             std::vector<int32_t> pr((size_t)n_seq * total, 0), npr((size_t)n_seq), out((size_t)n_seq * total, 0), tot((size_t)n_seq, 0);
             for (int q = 0; q < n_seq; q++) {
                 npr[(size_t)q] = lengths[q];

@@ -109,3 +109,81 @@ def test_long_context_probe_f16_q8(hip, extra, name, wd, ad):
         else:
             assert rms <= 1.35 * own_rms and mx <= 0.5, (n, rms, own_rms, mx)
     m.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_prompts_sharing_a_row_matrix_equal_each_prompt_alone(hip, name, wd, ad):
+    """batched prompt processing (gten_hip_set_row_segments, TinyLlamaBatch::prefill_many): a prompt's logits AND its K / V
+    rows are the bits of processing it alone through the same path -- whatever shares the row matrix with it, in whatever
+    order -- and a decode step of the whole batch afterwards agrees"""
+    from helpers import tiny_config
+    from test_model_gpu import host_cfg
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, ad, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 606, i) for i in range(len(cfg.weight_shapes()))]
+    lens = [16, 17, 300, 64, 33, 255, 256, 31]
+    prompts = [host.synthetic_tokens(n + 1, seed=40 + i, n_vocab=cfg.n_vocab) for i, n in enumerate(lens)]
+
+    def batch():
+        b = host.batch(cfg, 16)
+        for i, w in enumerate(weights):
+            b.set_weight(i, w)
+        return b
+
+    alone, together, shuffled = batch(), batch(), batch()
+    lg_alone = [alone.prefill(q, p[:-1]) for q, p in enumerate(prompts)]                      # one segment each
+    lg_tog = together.prefill_many(list(range(8)), [p[:-1] for p in prompts])                 # eight segments, one matrix
+    order = [5, 2, 7, 0, 3]
+    lg_shuf = shuffled.prefill_many([q + 8 for q in order], [prompts[q][:-1] for q in order])  # other company, other slots
+    for q in range(8):
+        assert np.array_equal(lg_tog[q], lg_alone[q]), (name, q, float(np.abs(lg_tog[q] - lg_alone[q]).max()))
+    for k, q in enumerate(order):
+        assert np.array_equal(lg_shuf[k], lg_alone[q]), (name, "shuffled", q)
+    # the caches: one ragged decode step of every sequence on its own prompt's next id
+    for b, slots in ((alone, range(8)), (together, range(8)), (shuffled, [q + 8 for q in order])):
+        ns = [1] * 16
+        for k, s_ in enumerate(slots):
+            q = order[k] if b is shuffled else k
+            b.decode_begin(s_, prompts[q])
+            ns[s_] = lens[q] + 1
+        for s_ in range(16):
+            if ns[s_] == 1:
+                b.decode_begin(s_, prompts[0])
+        b.decode_step_ragged(ns, True)
+    for q in range(8):
+        assert np.array_equal(together.logits(q), alone.logits(q)), (name, "step", q)
+    for k, q in enumerate(order):
+        assert np.array_equal(shuffled.logits(8 + q), alone.logits(q)), (name, "step shuffled", q)
+    alone.close(); together.close(); shuffled.close()
+
+
+@pytest.mark.parametrize("name,wd,ad", MODES())
+def test_full_size_prompt_in_a_shared_row_matrix_against_reference_golden(hip, extra, name, wd, ad):
+    """the reference's full-size 92-id prompt as the MIDDLE segment of a row matrix shared with two synthetic prompts:
+    held to the same golden bands as the lone prompt (test_full_size_prompt_against_reference_golden)"""
+    g = extra
+    if f"prefill.{name}.avx.tokens" not in g:
+        pytest.skip("prefill goldens not in the fixture")
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host.default_config(wd, ad)
+    cfg.max_ctx = 256
+    b = host.batch(cfg, 16)
+    b.load_synthetic(int(g["seed"][0]))
+    toks = g[f"prefill.{name}.avx.tokens"]
+    P = len(toks) - 4
+    others = [host.synthetic_tokens(200, seed=3), host.synthetic_tokens(57, seed=4)]
+    lg = b.prefill_many([3, 9, 12], [others[0], toks[:P], others[1]])[1]
+    probe = g["probe_ids"]
+    ids = g[f"prefill.{name}.avx.top_ids"][0]
+    ref_vals = np.concatenate([g[f"prefill.{name}.avx.top_logits"][0], g[f"prefill.{name}.avx.probes"][0]])
+    std = float(g[f"prefill.{name}.avx.stats"][0][1])
+    rms, mx = band(name, np.concatenate([lg[ids], lg[probe]]) - ref_vals, std)
+    gap = float(g[f"prefill.{name}.avx.top_logits"][0][0] - g[f"prefill.{name}.avx.top_logits"][0][1])
+    print(f"{name} segmented: rms {rms:.4f} max {mx:.4f}; top-1 {'same' if int(np.argmax(lg)) == int(ids[0]) else 'differs'} (reference gap {gap:.3f})")
+    if name == "f16":
+        assert int(np.argmax(lg)) == int(ids[0]) or gap < 0.03
+    elif gap > 0.5 * max(std / 0.91, 1.0):
+        assert int(np.argmax(lg)) == int(ids[0])
+    b.close()

@@ -869,7 +869,9 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
     // loads it cannot cover: the K loop is then shared by 2 (4 for d_in >= 4096) workgroups.  The factor depends on (rows,
     // d_in, d_out of the matrix) only, so a matrix gets the same sums whether it is launched alone or beside its siblings.
     int ks = 1;
-    if (FAST && out_dtype == GTEN_Q8 && splitk_enabled()) {
+    // (row segments set: never -- the factor depends on the row count, and a prompt must get the same bits whatever
+    //  shares the row matrix with it, gten_hip_set_row_segments)
+    if (FAST && out_dtype == GTEN_Q8 && splitk_enabled() && !row_segments(nullptr)) {
         ks = splitk_factor(rows, d_in, m.d_out[0]);
         for (int k = 1; k < m.n; k++)
             if (splitk_factor(rows, d_in, m.d_out[k]) != ks) ks = 0;              // (mixed: the caller launches them one by one)

@@ -7,11 +7,17 @@
 // Every kernel follows the reference's row discipline: storage dtype -> f32,
 // compute in f32, write the row back in the storage dtype (gten/ops.h:40-96).
 #include "gten_dev.h"
+
+#include <vector>
+#include <algorithm>
 #include "gten_rt.h"
 
 #include <cstdlib>
 
 using namespace gtd;
+
+// gten_hip_set_row_segments (include/gten_hip.h): starts[0 .. n] of the prompts sharing one row matrix; empty = one prompt
+static std::vector<int> g_seg;
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
 
@@ -721,6 +727,11 @@ __global__ __launch_bounds__(256) void k_attn(const uint8_t* __restrict__ q, con
 // ------------------------------------------------------------------ C-ABI
 
 using namespace gtr;
+const int* gtr::row_segments(int* n_segments)
+{
+    if (n_segments) *n_segments = g_seg.empty() ? 0 : (int)g_seg.size() - 1;
+    return g_seg.empty() ? nullptr : g_seg.data();
+}
 
 static bool act_dtype_ok(int dt) { return dt == GTEN_F16 || dt == GTEN_Q8; }
 
@@ -869,6 +880,7 @@ int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f1
 int gten_hip_rotary_emb(void* x, int dtype, size_t pitch, int n, int d, int d_head, int start_pos)
 {
     GTR_NEED_INIT();
+    GTR_REQUIRE(g_seg.empty(), "rotary_emb: row segments are set (gten_hip_set_row_segments): only gten_hip_block_rows rotates per prompt");
     if (int rc = check_rowwise("rotary_emb", x, x, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(d_head > 0 && d_head % 2 == 0 && d % d_head == 0, "rotary_emb: bad d_head %d for width %d", d_head, d);
     GTR_REQUIRE(n <= GTEN_ROPE_MAX_POS, "rotary_emb: position %d beyond the table (%d)", n, GTEN_ROPE_MAX_POS);
@@ -923,6 +935,7 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(q && k && v && out, "qkv_attn: null pointer");
+    GTR_REQUIRE(g_seg.empty(), "qkv_attn: row segments are set (gten_hip_set_row_segments): only gten_hip_block_rows attends per prompt");
     GTR_REQUIRE(act_dtype_ok(dtype), "qkv_attn: bad activation dtype %d", dtype);
     GTR_REQUIRE(n > 0 && start_pos >= 0 && start_pos < n, "qkv_attn: bad rows n=%d start_pos=%d", n, start_pos);
     GTR_REQUIRE(n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "qkv_attn: bad head counts %d/%d", n_heads, n_kv_heads);
@@ -969,6 +982,13 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     const int E = b->n_embd, F = b->n_ffn, rows = n - start_pos;
     const int dh = b->n_heads > 0 ? E / b->n_heads : 0, KV = dh * b->n_kv_heads;
     const bool off = !g_block_rows;
+    if (!g_seg.empty())
+        GTR_REQUIRE(start_pos == 0 && n == g_seg.back(), "block_rows: row segments cover %d rows, the call has rows [%d, %d)", g_seg.back(), start_pos, n);
+    // the prompts of this call: (first row, rows) -- one, unless row segments are set
+    std::vector<std::pair<int, int>> segs;
+    if (g_seg.empty()) segs.push_back({start_pos, rows});
+    else for (size_t k = 0; k + 1 < g_seg.size(); k++) segs.push_back({g_seg[k], g_seg[k + 1] - g_seg[k]});
+    const bool seg = !g_seg.empty();
     static const bool no_mfma = [] { const char* e = std::getenv("GTEN_HIP_NO_MFMA"); return e && e[0] == '1'; }();
     static const bool no_tiled = [] { const char* e = std::getenv("GTEN_HIP_NO_TILED_ATTN"); return e && e[0] == '1'; }();
     // what this path computes; everything else stays with the operators (the caller falls back on GTEN_HIP_NOT_HANDLED)
@@ -997,9 +1017,18 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
         {
             const float2* table = nullptr;
             if ((rc = rope_table(dh, &table))) return rc;
-            GTR_LAUNCH(KT_ROPE, k_rope2, dim3(rows, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q, hE, E, (uint8_t*)b->k, hKV, KV, GTEN_F16, dh, start_pos, table);
+            // (row segments: every prompt from position 0 -- base pointers moved to its first row, start_pos 0)
+            for (const auto& sg : segs) {
+                const size_t r0 = seg ? (size_t)sg.first : 0;
+                GTR_LAUNCH(KT_ROPE, k_rope2, dim3(sg.second, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q + r0 * hE, hE, E, (uint8_t*)b->k + r0 * hKV, hKV, KV,
+                           GTEN_F16, dh, seg ? 0 : start_pos, table);
+            }
         }
-        if ((rc = gten_launch_attn_tiled_f16(b->q, b->k, b->v, b->attn_out, hE, hKV, hE, n, b->n_heads, b->n_kv_heads, start_pos))) return rc;
+        for (const auto& sg : segs) {
+            const size_t r0 = seg ? (size_t)sg.first : 0;
+            if ((rc = gten_launch_attn_tiled_f16((const uint8_t*)b->q + r0 * hE, (const uint8_t*)b->k + r0 * hKV, (const uint8_t*)b->v + r0 * hKV,
+                                                 (uint8_t*)b->attn_out + r0 * hE, hE, hKV, hE, seg ? sg.second : n, b->n_heads, b->n_kv_heads, seg ? 0 : start_pos))) return rc;
+        }
         {
             MfmaMats m;
             m.n = 1; m.w[0] = b->wo; m.out[0] = b->o; m.out_pitch[0] = hE; m.d_out[0] = E;
@@ -1059,12 +1088,24 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     {
         const float2* table = nullptr;
         if ((rc = rope_table(dh, &table))) return rc;
-        if (rope_q8w_ok(b->q, pE, GTEN_Q8, E, dh) && rope_q8w_ok(b->k, pKV, GTEN_Q8, KV, dh))
-            GTR_LAUNCH(KT_ROPE, k_rope2_q8w, dim3(rows, 2), dim3(64), 0, (uint8_t*)b->q, pE, E / 32, (uint8_t*)b->k, pKV, KV / 32, start_pos, table);
-        else
-            GTR_LAUNCH(KT_ROPE, k_rope2, dim3(rows, 2), dim3(256), (size_t)E * 4, (uint8_t*)b->q, pE, E, (uint8_t*)b->k, pKV, KV, GTEN_Q8, dh, start_pos, table);
+        const bool wave_rows = rope_q8w_ok(b->q, pE, GTEN_Q8, E, dh) && rope_q8w_ok(b->k, pKV, GTEN_Q8, KV, dh);
+        // (row segments: every prompt from position 0 -- base pointers moved to its first row, start_pos 0)
+        for (const auto& sg : segs) {
+            const size_t r0 = seg ? (size_t)sg.first : 0;
+            uint8_t* qs = (uint8_t*)b->q + r0 * pE;
+            uint8_t* ks = (uint8_t*)b->k + r0 * pKV;
+            if (wave_rows)
+                GTR_LAUNCH(KT_ROPE, k_rope2_q8w, dim3(sg.second, 2), dim3(64), 0, qs, pE, E / 32, ks, pKV, KV / 32, seg ? 0 : start_pos, table);
+            else
+                GTR_LAUNCH(KT_ROPE, k_rope2, dim3(sg.second, 2), dim3(256), (size_t)E * 4, qs, pE, E, ks, pKV, KV, GTEN_Q8, dh, seg ? 0 : start_pos, table);
+        }
     }
-    if ((rc = gten_launch_attn_tiled(b->q, b->k, b->v, b->attn_out, pE, pKV, pE, n, b->n_heads, b->n_kv_heads, start_pos, fold ? a16 : nullptr))) return rc;
+    for (const auto& sg : segs) {
+        const size_t r0 = seg ? (size_t)sg.first : 0;
+        if ((rc = gten_launch_attn_tiled((const uint8_t*)b->q + r0 * pE, (const uint8_t*)b->k + r0 * pKV, (const uint8_t*)b->v + r0 * pKV,
+                                         (uint8_t*)b->attn_out + r0 * pE, pE, pKV, pE, seg ? sg.second : n, b->n_heads, b->n_kv_heads, seg ? 0 : start_pos,
+                                         fold ? (void*)(a16 + r0 * (size_t)E) : nullptr))) return rc;
+    }
     {
         MfmaMats m;
         m.n = 1; m.w[0] = b->wo; m.out[0] = b->o; m.out_pitch[0] = pE; m.d_out[0] = E;
@@ -1094,6 +1135,59 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
         m.resid = b->h; m.sum_out = b->out; m.resid_pitch = pE;
         if ((rc = gten_launch_matmul_mfma_multi(b->gate, pF, b->wdtype, m, GTEN_Q8, n, F, start_pos, fold))) return rc;
     }
+    return 0;
+}
+
+int gten_hip_row_segments_ok(int n_embd, int n_ffn, int n_heads, int n_kv_heads, int wdtype, int adtype)
+{
+    if (!g_block_rows || n_heads <= 0 || n_kv_heads <= 0) return 0;
+    static const bool off = [] {
+        const char* a = std::getenv("GTEN_HIP_NO_MFMA");
+        const char* b = std::getenv("GTEN_HIP_NO_TILED_ATTN");
+        return (a && a[0] == '1') || (b && b[0] == '1');
+    }();
+    const int dh = n_embd / n_heads, KV = dh * n_kv_heads;
+    const bool q8cfg = adtype == GTEN_Q8 && (wdtype == GTEN_Q8 || wdtype == GTEN_Q4), f16cfg = adtype == GTEN_F16 && wdtype == GTEN_F16;
+    return !off && (q8cfg || f16cfg) && dh == 64 && n_embd % 128 == 0 && n_ffn % 128 == 0 && KV % 32 == 0 && (n_ffn / 32) % 2 == 0 && n_heads % n_kv_heads == 0;
+}
+
+int gten_hip_set_row_segments(const int32_t* starts, int n_segments)
+{
+    GTR_NEED_INIT();
+    if (n_segments <= 0) { g_seg.clear(); return 0; }
+    GTR_REQUIRE(starts && starts[0] == 0, "set_row_segments: starts[0] must be 0");
+    for (int k = 0; k < n_segments; k++)
+        GTR_REQUIRE(starts[k + 1] - starts[k] >= GTEN_MFMA_MIN_ROWS, "set_row_segments: segment %d has %d rows (at least %d)", k, starts[k + 1] - starts[k], GTEN_MFMA_MIN_ROWS);
+    GTR_REQUIRE(starts[n_segments] <= GTEN_ROPE_MAX_POS, "set_row_segments: %d rows in all (at most %d)", starts[n_segments], GTEN_ROPE_MAX_POS);
+    g_seg.assign(starts, starts + n_segments + 1);
+    return 0;
+}
+
+// n ranges by value in the kernel arguments: no table to upload, nothing for the host to keep alive
+struct CopyRanges { gten_hip_copy_range r[GTEN_HIP_MAX_COPY_RANGES]; };
+__global__ __launch_bounds__(256) void k_copy_ranges(const CopyRanges t)
+{
+    const gten_hip_copy_range r = t.r[blockIdx.y];
+    const uintptr_t al = (uintptr_t)r.dst | (uintptr_t)r.src | r.bytes;      // (uniform per range)
+    const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    if ((al & 15) == 0) for (size_t i = t0; i < (r.bytes >> 4); i += step) ((uint4*)r.dst)[i] = ((const uint4*)r.src)[i];
+    else if ((al & 3) == 0) for (size_t i = t0; i < (r.bytes >> 2); i += step) ((unsigned*)r.dst)[i] = ((const unsigned*)r.src)[i];
+    else for (size_t i = t0; i < r.bytes; i += step) ((uint8_t*)r.dst)[i] = ((const uint8_t*)r.src)[i];
+}
+int gten_hip_copy_ranges(const gten_hip_copy_range* ranges, int n)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(ranges && n >= 0 && n <= GTEN_HIP_MAX_COPY_RANGES, "copy_ranges: %d ranges (at most %d)", n, GTEN_HIP_MAX_COPY_RANGES);
+    if (n == 0) return 0;
+    CopyRanges t{};
+    size_t longest = 0;
+    for (int i = 0; i < n; i++) {
+        GTR_REQUIRE(ranges[i].dst && ranges[i].src, "copy_ranges: range %d is null", i);
+        t.r[i] = ranges[i];
+        longest = std::max(longest, ranges[i].bytes);
+    }
+    const int gx = (int)std::min<size_t>(32, std::max<size_t>(1, (longest / 16 + 255) / 256));
+    GTR_LAUNCH(KT_ELEMWISE, k_copy_ranges, dim3(gx, n), dim3(256), 0, t);
     return 0;
 }
 

@@ -91,6 +91,7 @@ int gten_launch_attn_tiled_f16(const void* q, const void* k, const void* v, void
                                size_t out_pitch, int n, int n_heads, int n_kv_heads, int start_pos);
 
 namespace gtr {
+const int* row_segments(int* n_segments);   // gten_hip_set_row_segments: starts[0 .. n] or null
 bool prefill_exact();          // gten_hip_set_prefill_exact: the exact forms of the prompt-sized kernels (gten_mfma.hip, gten_attn_tiled.hip)
 bool prof_on();
 void prof_before(int tag);

@@ -220,9 +220,29 @@ int gten_host_batch_set_weight(gten_host_batch* b, int idx, const void* bytes, s
 int gten_host_batch_prefill(gten_host_batch* b, int seq, const int32_t* tokens, int n, float* logits_out)
 {
     if (seq < 0 || seq >= b->batch->n_seq() || !tokens || n <= 0) return -1;
-    Tensor tk(tokens, {n}, kInt32);
-    const Tensor lg = b->batch->seq(seq).logits(tk, 0);          // operator path on this sequence's own caches
-    if (logits_out) std::memcpy(logits_out, lg.data_ptr<float>(), (size_t)lg.numel() * sizeof(float));
+    const std::vector<int32_t> prompt(tokens, tokens + n);
+    b->batch->prefill(seq, prompt, logits_out);                  // (wide batches: the segmented prompt path, TinyLlamaBatch::prefill)
+    return 0;
+}
+
+int gten_host_batch_prefill_many(gten_host_batch* b, const int32_t* seqs, const int32_t* tokens, const int32_t* starts, int n_prompts, float* logits_out)
+{
+    if (!b || !seqs || !tokens || !starts || n_prompts < 1 || n_prompts > TinyLlamaBatch::kPreMax || starts[0] != 0) return -1;
+    if (!b->batch->batched_prompts()) return -2;
+    std::vector<std::vector<int32_t>> prompts((size_t)n_prompts);
+    std::vector<const std::vector<int32_t>*> ps;
+    std::vector<int> slots;
+    std::vector<float*> lo;
+    for (int k = 0; k < n_prompts; k++) {
+        const int len = starts[k + 1] - starts[k];
+        if (seqs[k] < 0 || seqs[k] >= b->batch->n_seq() || len < 16 || len > b->cfg.max_ctx || starts[k + 1] > TinyLlamaBatch::kPreRows) return -1;
+        prompts[(size_t)k].assign(tokens + starts[k], tokens + starts[k + 1]);
+        ps.push_back(&prompts[(size_t)k]);
+        slots.push_back(seqs[k]);
+        lo.push_back(logits_out ? logits_out + (size_t)k * b->cfg.n_vocab : nullptr);
+    }
+    std::vector<int> first;
+    b->batch->prefill_many(slots, ps, &first, &lo);
     return 0;
 }
 
@@ -270,13 +290,7 @@ int gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const i
         if (P <= 0 || P > max_prompt || P >= max_tokens || P >= b->cfg.max_ctx) return -1;
         int32_t* row = out + (size_t)q * max_tokens;
         std::memcpy(row, prompts + (size_t)q * max_prompt, (size_t)P * sizeof(int32_t));
-        Tensor tk(row, {P}, kInt32);
-        const Tensor lg = b->batch->seq(q).logits(tk, 0);
-        const float* p = lg.data_ptr<float>();
-        int best_i = 0;
-        float best = -std::numeric_limits<float>::infinity();
-        for (int j = 0; j < lg.numel(); j++)
-            if (p[j] > best) { best = p[j]; best_i = j; }
+        const int best_i = b->batch->prefill(q, std::vector<int32_t>(row, row + P));
         row[P] = best_i;                                          // (an eos here ends the sequence below)
         n_first[q] = P + 1;
         b->batch->decode_set_tokens(q, row, 0, P + 1);

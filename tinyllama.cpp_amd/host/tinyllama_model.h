@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <limits>
@@ -81,6 +82,34 @@ public:
         x = norm_.forward(x, start_pos);
         return lm_head_.forward(x);
     }
+
+    // ---- several prompts as ONE row matrix (TinyLlamaBatch::prefill_many; include/gten_hip.h, gten_hip_set_row_segments):
+    // rows [starts[k], starts[k + 1]) of `tokens` are prompt k.  Returns the final-norm rows; logits_of_row gives the
+    // logits of one of them.  This object's K / V tensors then hold every prompt's rows, at the prompt's rows.
+    Tensor hidden_rows(const Tensor& tokens, const std::vector<int32_t>& starts)
+    {
+        GTEN_ASSERTM(tokens.numel() <= n_ctx_ && (int)starts.size() >= 2 && starts.back() == tokens.numel(), "hidden_rows: %d rows, context %d",
+                     tokens.numel(), n_ctx_);
+        struct OpsOnly {
+            bool was = detail::fused_rows_enabled();
+            OpsOnly() { detail::fused_rows_enabled() = false; }
+            ~OpsOnly() { detail::fused_rows_enabled() = was; }
+        } ops_only;
+        struct Segments {
+            explicit Segments(const std::vector<int32_t>& s) { GTEN_HIP_OK(gten_hip_set_row_segments(s.data(), (int)s.size() - 1)); }
+            ~Segments() { gten_hip_set_row_segments(nullptr, 0); }
+        } segments(starts);
+        Tensor x = tok_emb_.forward(tokens, 0);
+        for (auto& block : blocks_) x = block.forward(x, 0);
+        return norm_.forward(x, 0);
+    }
+    Tensor logits_of_row(const Tensor& hidden, int row)
+    {
+        Tensor v = hidden;                                    // (a shallow handle: the same storage, its own shape)
+        v.resize({row + 1, params.n_embd});
+        return lm_head_.forward(v);                           // EmbeddingLinear computes the last row of what it is given
+    }
+    AttentionBlock& block(int i) { return blocks_[(size_t)i]; }
 
     // ---- single-token decode fast path (include/gten_hip.h, "decode fast path")
     void set_fast_decode(bool on) { fast_decode_ = on; }
@@ -314,7 +343,7 @@ public:
 // streams every weight once per step.
 class TinyLlamaBatch {
 public:
-    TinyLlamaBatch(int n_seq, int n_ctx, ModuleDtype dtype, TinyLLamaParams p = TinyLLamaParams{}) : n_ctx_{n_ctx}
+    TinyLlamaBatch(int n_seq, int n_ctx, ModuleDtype dtype, TinyLLamaParams p = TinyLLamaParams{}) : n_ctx_{n_ctx}, dtype_{dtype}, params_{p}
     {
         GTEN_ASSERTM(n_seq == 2 || n_seq == 4 || n_seq == 8 || (n_seq >= 16 && n_seq <= 64 && n_seq % 16 == 0) || (n_seq > 64 && n_seq <= 256 && n_seq % 64 == 0),
                      "TinyLlamaBatch: n_seq %d not in {2, 4, 8, 16, 32, 48, 64, 128, 192, 256}", n_seq);
@@ -343,6 +372,86 @@ public:
     {
         seqs_[0]->load_synthetic(seed);
         share_weights();
+    }
+
+    // ---- prompt processing.  Wide batches (>= 16 sequences) process prompts of >= 16 ids as segments of ONE row matrix
+    // (a scratch model `pre_` on the shared weights; gten_hip_set_row_segments): every projection is one W.x launch for all
+    // the prompts of a call, RoPE and attention run per prompt, and each prompt's K / V rows are then copied from the
+    // matrix into its slot's caches.  A prompt's bits do not depend on what shares the matrix with it (no K loop is shared
+    // between workgroups in segmented calls), so serve(), generate() and prefill() agree whatever they batch together.
+    // Up to 8 sequences keep the per-sequence operator path: there the ids are those of a lone TinyLlama, bit for bit.
+    static constexpr int kPreRows = 2048;      // rows of the shared matrix (the RoPE table's positions, GTEN_ROPE_MAX_POS)
+    static constexpr int kPreMax = 16;         // prompts per call (two copy ranges per prompt and layer: GTEN_HIP_MAX_COPY_RANGES)
+    bool batched_prompts() const
+    {
+        return n_seq() >= 16 && gten_hip_row_segments_ok(params_.n_embd, params_.n_ffn, params_.n_heads, params_.n_query_groups,
+                                                         dtype_code(dtype_.wdtype), dtype_code(dtype_.adtype)) == 1;
+    }
+    // prompts[k] (>= 16 ids each, kPreRows in all, at most kPreMax) onto the caches of sequence slots[k]; first[k] = argmax of
+    // prompt k's logits (strict >, first maximum: tinyllama.cpp:416-424); logits_out[k], when given, receives them
+    void prefill_many(const std::vector<int>& slots, const std::vector<const std::vector<int32_t>*>& prompts, std::vector<int>* first,
+                      std::vector<float*>* logits_out = nullptr)
+    {
+        const int K = (int)slots.size();
+        GTEN_ASSERTM(K >= 1 && K <= kPreMax && prompts.size() == slots.size(), "prefill_many: %d prompts", K);
+        if (!pre_) {
+            pre_.reset(new TinyLlama(kPreRows, dtype_, params_));
+            pre_->set_fast_decode(false);
+            for (int w = 0; w < seqs_[0]->n_weights(); w++) pre_->weight(w) = seqs_[0]->weight(w);
+        }
+        std::vector<int32_t> ids, starts{0};
+        for (const auto* p : prompts) {
+            GTEN_ASSERTM((int)p->size() >= 16 && (int)p->size() <= n_ctx_, "prefill_many: a prompt of %zu ids", p->size());
+            ids.insert(ids.end(), p->begin(), p->end());
+            starts.push_back((int32_t)ids.size());
+        }
+        GTEN_ASSERTM((int)ids.size() <= kPreRows, "prefill_many: %zu rows (at most %d)", ids.size(), kPreRows);
+        Tensor tk(ids.data(), {(int)ids.size()}, kInt32);
+        const Tensor hidden = pre_->hidden_rows(tk, starts);
+        // every prompt's K / V rows into its own caches: one launch per layer
+        std::vector<gten_hip_copy_range> ranges;
+        for (int l = 0; l < params_.n_layers; l++) {
+            ranges.clear();
+            AttentionBlock& src = pre_->block(l);
+            const size_t pitch = (size_t)src.attn.key.acv.bstride(0);
+            for (int k = 0; k < K; k++) {
+                AttentionBlock& dst = seq(slots[(size_t)k]).block(l);
+                const size_t off = (size_t)starts[(size_t)k] * pitch, bytes = prompts[(size_t)k]->size() * pitch;
+                ranges.push_back({dst.attn.key.acv.device_ptr_mut(), (const uint8_t*)src.attn.key.acv.device_ptr() + off, bytes});
+                ranges.push_back({dst.attn.value.acv.device_ptr_mut(), (const uint8_t*)src.attn.value.acv.device_ptr() + off, bytes});
+            }
+            GTEN_HIP_OK(gten_hip_copy_ranges(ranges.data(), (int)ranges.size()));
+        }
+        first->assign((size_t)K, 0);
+        for (int k = 0; k < K; k++) {
+            const Tensor lg = pre_->logits_of_row(hidden, starts[(size_t)k + 1] - 1);
+            const float* p = lg.data_ptr<float>();                   // (waits for the current stream)
+            int best_i = 0;
+            float best = -std::numeric_limits<float>::infinity();
+            for (int j = 0; j < lg.numel(); j++)
+                if (p[j] > best) { best = p[j]; best_i = j; }
+            (*first)[(size_t)k] = best_i;
+            if (logits_out && (*logits_out)[(size_t)k]) std::memcpy((*logits_out)[(size_t)k], p, (size_t)lg.numel() * sizeof(float));
+        }
+    }
+    // one prompt onto sequence seq_i's caches; returns the argmax of its logits (logits_out may be null)
+    int prefill(int seq_i, const std::vector<int32_t>& prompt, float* logits_out = nullptr)
+    {
+        if (batched_prompts() && (int)prompt.size() >= 16 && (int)prompt.size() <= kPreRows) {
+            std::vector<int> first;
+            std::vector<float*> lo{logits_out};
+            prefill_many({seq_i}, {&prompt}, &first, &lo);
+            return first[0];
+        }
+        Tensor tk(prompt.data(), {(int)prompt.size()}, kInt32);
+        const Tensor lg = seq(seq_i).logits(tk, 0);                  // operator path on this sequence's own caches
+        const float* p = lg.data_ptr<float>();
+        int best_i = 0;
+        float best = -std::numeric_limits<float>::infinity();
+        for (int j = 0; j < lg.numel(); j++)
+            if (p[j] > best) { best = p[j]; best_i = j; }
+        if (logits_out) std::memcpy(logits_out, p, (size_t)lg.numel() * sizeof(float));
+        return best_i;
     }
 
     void decode_set_tokens(int seq_i, const int32_t* ids, int first, int count)
@@ -441,13 +550,7 @@ public:
                 const int limit = std::min(std::min(max_tokens, n_ctx_), mn > 0 ? P + mn : n_ctx_);   // ids in all
                 if (P >= limit) continue;                                  // no room to generate: returned as is
                 const auto t0 = clock::now();
-                Tensor tk(row.data(), {P}, kInt32);
-                const Tensor lg = seq(q).logits(tk, 0);                    // this slot's caches now hold rows [0, P)
-                const float* p = lg.data_ptr<float>();                     // (waits for stream 1 only)
-                int best_i = 0;
-                float best = -std::numeric_limits<float>::infinity();
-                for (int k = 0; k < lg.numel(); k++)
-                    if (p[k] > best) { best = p[k]; best_i = k; }
+                const int best_i = prefill(q, row);                        // this slot's caches now hold rows [0, P) (waits for stream 1 only)
                 st.prefill_s += std::chrono::duration<double>(clock::now() - t0).count();
                 st.admissions++;
                 if (best_i == eos) continue;                               // ended at once: the slot takes the next prompt
@@ -459,6 +562,57 @@ public:
                 return true;
             }
             return false;
+        };
+        // Wide batches: the next prompts of the queue -- as many as there are free slots, kPreMax at most, kPreRows rows in
+        // all, `cap` when the schedule is fixed -- as ONE row matrix (prefill_many) on stream 1.  Prompts under 16 ids (and
+        // configurations the segmented call does not compute) go one by one through prepare().
+        const bool batched = batched_prompts();
+        auto prepare_many = [&](int cap) -> bool {
+            std::vector<int> fq;
+            for (int q = 0; q < S; q++)
+                if (job[(size_t)q] < 0) fq.push_back(q);
+            if (fq.empty()) return next < prompts.size();
+            const size_t room = std::min<size_t>({fq.size(), (size_t)kPreMax, cap > 0 ? (size_t)cap : (size_t)kPreMax});
+            std::vector<int> js, limits;
+            int rows = 0;
+            while (next < prompts.size() && js.size() < room) {
+                const int j = (int)next;
+                const int P = (int)prompts[(size_t)j].size();
+                GTEN_ASSERTM(P >= 1 && P <= n_ctx_, "serve: prompt %d has %d ids (context %d)", j, P, n_ctx_);
+                if (!batched || P < 16) break;                               // (short prompt: one by one below)
+                if (rows + P > kPreRows) break;
+                next++;
+                (*out)[(size_t)j] = prompts[(size_t)j];
+                st.prompt_tokens += P;
+                const int mn = max_new_each ? max_new_each[j] : max_new;
+                const int limit = std::min(std::min(max_tokens, n_ctx_), mn > 0 ? P + mn : n_ctx_);
+                if (P >= limit) continue;                                    // no room to generate: returned as is
+                js.push_back(j); limits.push_back(limit); rows += P;
+            }
+            if (js.empty()) {
+                if (next >= prompts.size()) return false;
+                const int P = (int)prompts[next].size();
+                if (batched && P >= 16 && P <= kPreRows) return true;        // (only prompts without room were taken: look again)
+                return prepare(fq[0]);
+            }
+            const auto t0 = clock::now();
+            std::vector<int> slots(fq.begin(), fq.begin() + (long)js.size()), first;
+            std::vector<const std::vector<int32_t>*> ps;
+            for (int j : js) ps.push_back(&prompts[(size_t)j]);
+            prefill_many(slots, ps, &first);
+            st.prefill_s += std::chrono::duration<double>(clock::now() - t0).count();
+            for (size_t k = 0; k < js.size(); k++) {
+                std::vector<int32_t>& row = (*out)[(size_t)js[k]];
+                st.admissions++;
+                if (first[k] == eos) continue;                               // ended at once: the slot stays free
+                row.push_back(first[k]);
+                st.new_tokens++;
+                if ((int)row.size() >= limits[k]) continue;
+                const int q = slots[k];
+                job[(size_t)q] = js[k]; cur[(size_t)q] = (int)row.size(); last[(size_t)q] = limits[k] - 1;
+                n_ready++;
+            }
+            return true;
         };
         int cnt = 0;                                                       // steps of the slice in flight (0: none)
         auto t_slice = clock::now();
@@ -516,11 +670,12 @@ public:
                 if (!idle && queue_left)
                     for (int q = 0; q < S && free_q < 0; q++)
                         if (job[(size_t)q] < 0) free_q = q;
-                if (free_q >= 0) {                                          // slice still running: one more prompt beside it
+                if (free_q >= 0) {                                          // slice still running: more prompts beside it
                     GTEN_HIP_OK(gten_hip_select_stream(1));
-                    queue_left = prepare(free_q);
+                    const int before = (int)st.admissions;
+                    queue_left = batched ? prepare_many(serve_schedule_ > 0 ? serve_schedule_ - prepared_this_slice : 0) : prepare(free_q);
                     GTEN_HIP_OK(gten_hip_select_stream(0));
-                    prepared_this_slice++;
+                    prepared_this_slice += batched ? std::max(1, (int)st.admissions - before) : 1;
                     continue;
                 }
                 harvest();                                                  // (waits when nothing is left to prepare)
@@ -532,7 +687,7 @@ public:
                     if (job[(size_t)q] < 0) free_q = q;
                 if (free_q < 0) break;                                      // queue empty, nothing in flight
                 GTEN_HIP_OK(gten_hip_select_stream(1));
-                queue_left = prepare(free_q);
+                queue_left = batched ? prepare_many(serve_schedule_) : prepare(free_q);
                 GTEN_HIP_OK(gten_hip_select_stream(0));
                 if (n_ready == 0) { if (!queue_left) break; continue; }
             }
@@ -547,8 +702,11 @@ public:
 
 private:
     std::vector<std::unique_ptr<TinyLlama>> seqs_;
+    std::unique_ptr<TinyLlama> pre_;         // the shared row matrix of batched prompt processing (prefill_many), made on first use
     gten_hip_decoder* dec_ = nullptr;
     int n_ctx_;
+    ModuleDtype dtype_;
+    TinyLLamaParams params_;
     int serve_schedule_ = 0;
 
     void ensure_decoder()

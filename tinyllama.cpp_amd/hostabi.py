@@ -39,7 +39,7 @@ class GtenHost:
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step", "gten_host_model_decode_steps", "gten_host_batch_decode_steps",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
-        "gten_host_batch_prefill", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_set_serve_schedule", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
+        "gten_host_batch_prefill", "gten_host_batch_prefill_many", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_set_serve_schedule", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
         "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
     ]
 
@@ -78,6 +78,7 @@ class GtenHost:
         self._bloads = _sig(L, "gten_host_batch_load_synthetic", ci, [vp, C.c_uint64])
         self._bsetw = _sig(L, "gten_host_batch_set_weight", ci, [vp, ci, vp, sz])
         self._bprefill = _sig(L, "gten_host_batch_prefill", ci, [vp, ci, vp, ci, vp])
+        self._bprefill_many = _sig(L, "gten_host_batch_prefill_many", ci, [vp, vp, vp, vp, ci, vp])
         self._bbegin = _sig(L, "gten_host_batch_decode_begin", ci, [vp, ci, vp, ci])
         self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
         self._bstepr = _sig(L, "gten_host_batch_decode_step_ragged", ci, [vp, vp, ci])
@@ -284,6 +285,18 @@ class HostBatch:
         out = np.zeros(self.cfg.n_vocab, np.float32) if want else None
         self._ck(self.host._bprefill(self.h, seq, tokens.ctypes.data_as(C.c_void_p), len(tokens),
                                      out.ctypes.data_as(C.c_void_p) if want else None), "batch_prefill")
+        return out
+
+    def prefill_many(self, seqs, prompts, want=True):
+        """several prompts (>= 16 ids each) as segments of one row matrix, prompt k onto the caches of sequence seqs[k];
+        returns [n_prompts][n_vocab] logits (wide batches only: raises otherwise)"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.int32)
+        starts = np.zeros(len(prompts) + 1, np.int32)
+        starts[1:] = np.cumsum([len(p) for p in prompts])
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(p, np.int32) for p in prompts]), dtype=np.int32)
+        out = np.zeros((len(prompts), self.cfg.n_vocab), np.float32) if want else None
+        self._ck(self.host._bprefill_many(self.h, seqs.ctypes.data_as(C.c_void_p), toks.ctypes.data_as(C.c_void_p), starts.ctypes.data_as(C.c_void_p),
+                                          len(prompts), out.ctypes.data_as(C.c_void_p) if want else None), "batch_prefill_many")
         return out
 
     def decode_begin(self, seq, tokens):
