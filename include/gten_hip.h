@@ -121,6 +121,13 @@ int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch,
  * reference's exact integer block dot, rescaled and added in the scalar build's order (gten/ops.h:296-312), bit for
  * bit.  Process-wide; f16 weights are not affected. */
 int gten_hip_set_prefill_exact(int on);
+/* The same choice for the decode step of decoders created AFTERWARDS (a decoder's graphs are captured once): exact
+ * (on != 0) -- attention probabilities rounded against the statistics of the whole row (two launches per block, the
+ * reference's rounding point gten/ops.h:972-997), p.V as separately rounded multiplies and adds, the W.x of 16+ sequences
+ * as exact integer block sums (k_dec_mmv) -- or fast (default; DESIGN.md 3.5 lists the deviations: chunk-local rounding
+ * of the probabilities, fp16 operand rounding in the wide W.x and p.V).  Up to 8 sequences and contexts <= 256 both forms
+ * are the same bytes. */
+int gten_hip_set_decode_exact(int on);
 
 /* ops::rms_norm, gten/ops.h:762-814.  w: f16[d]. */
 int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f16,
@@ -165,8 +172,7 @@ typedef struct {
     void* out;                  /* h + down: the block's output rows */
 } gten_hip_block_desc;
 int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos);
-/* 0: gten_hip_block_rows answers GTEN_HIP_NOT_HANDLED for everything (the modules run one by one; tests compare the two);
- * the environment variable GTEN_HIP_NO_BLOCK_ROWS=1 sets the same at start */
+/* 0: gten_hip_block_rows answers GTEN_HIP_NOT_HANDLED for everything (the modules run one by one; tests compare the two) */
 int gten_hip_set_block_rows(int on);
 
 /* SEVERAL prompts as one row matrix (batched prompt processing; round 3).  The rows of a prompt-sized call are

@@ -132,6 +132,7 @@ int gten_hip_matmul_2d(const void* x, int, size_t, const void*, int, void* out, 
     return 0;
 }
 int gten_hip_set_prefill_exact(int) { return 0; }
+int gten_hip_set_decode_exact(int) { return 0; }
 int gten_hip_row_segments_ok(int, int, int, int, int, int) { return g_block_rows; }
 int gten_hip_set_row_segments(const int32_t* starts, int n)
 {

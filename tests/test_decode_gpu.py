@@ -170,9 +170,9 @@ def test_decode_at_the_last_position(hip, oracle):
 
 
 @pytest.mark.parametrize("name,wd,ad", MODES())
-def test_one_pass_attention_against_the_two_launch_form(hip, oracle, name, wd, ad, monkeypatch):
+def test_one_pass_attention_against_the_two_launch_form(hip, oracle, name, wd, ad):
     """default: scores, chunk-local softmax and p.V in ONE launch per block (k_dec_attn_one64), the chunks joined with
-    their weights in the o projection's prologue.  GTEN_HIP_ATTN_TWO_PASS=1: two launches, probabilities rounded
+    their weights in the o projection's prologue.  gten_hip_set_decode_exact(1): two launches, probabilities rounded
     against the statistics of the whole row (the reference's rounding point, gten/ops.h:972-997).  While the context
     fits one chunk (n <= 256) both are the same bytes; beyond, the logits stay inside the model band (a probability
     block is rounded against its chunk's scale: fp16 rounding of the block delta) and BOTH sit inside the band
@@ -186,8 +186,8 @@ def test_one_pass_attention_against_the_two_launch_form(hip, oracle, name, wd, a
     weights = [host.synth_weight(cfg, 77, i) for i in range(len(cfg.weight_shapes()))]
     watch = (1, 2, 100, 255, 256, 257, 290, N)
     outs = []
-    for two in ("0", "1"):
-        monkeypatch.setenv("GTEN_HIP_ATTN_TWO_PASS", two)
+    for two in (False, True):
+        hip.set_decode_exact(two)                   # (read when the decoder is created)
         gm = host.model(cfg)
         for i, w in enumerate(weights):
             gm.set_weight(i, w)
@@ -199,6 +199,7 @@ def test_one_pass_attention_against_the_two_launch_form(hip, oracle, name, wd, a
                 got[n] = (gm.decode_result(n), gm.logits(toks[:n], n - 1).copy())
         outs.append(got)
         gm.close()
+    hip.set_decode_exact(False)
     om = oracle.model(ocfg)
     for i, w in enumerate(weights):
         om.set_weight(i, w)

@@ -146,70 +146,44 @@ def test_batch_generation_on_device_equals_single_sequence_generation(hip, name,
         assert got[q].tolist() == want[q].tolist(), (name, q, len(got[q]), len(want[q]))
 
 
-def test_wide_batch_k_split_planes_agree_with_single_plane(hip, monkeypatch):
-    """k_dec_mmv splits K over two workgroups per feature tile and the consumers add the two planes of partial sums
-    (default); GTEN_HIP_MMV_KSPLIT=1 keeps one workgroup and one plane.  Same block sums, one more f32 association:
-    the logits of both runs agree inside the model band and the greedy ids are equal where the margin is clear."""
-    from helpers import Q4, Q8
-    pkg = load_package()
-    host = pkg.load_host()
-    cfg = host_cfg(tiny_config(Q4, Q8, n_embd=512, n_ffn=1024, n_heads=8, n_kv_heads=2, max_ctx=64, n_layers=2))
-    n_seq, N = 16, 24
-    streams = [host.synthetic_tokens(N, seed=900 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
-    runs = []
-    for ks in ("1", "2"):
-        monkeypatch.setenv("GTEN_HIP_MMV_KSPLIT", ks)
-        monkeypatch.setenv("GTEN_HIP_MMV_KSPLIT_GU", ks)
-        batch = host.batch(cfg, n_seq)
-        for i in range(len(cfg.weight_shapes())):
-            batch.set_weight(i, host.synth_weight(cfg, 31, i))
-        for q in range(n_seq):
-            batch.decode_begin(q, streams[q])
-        for n in range(1, N + 1):
-            batch.decode_step(n, True)
-        runs.append([(batch.decode_result(q, N), batch.logits(q).copy()) for q in range(n_seq)])
-        batch.close()
-    from test_model_gpu import check_logits
-    for (ra, la), (rb, lb) in zip(*runs):
-        # one more f32 association in every W.x: a rounding flip of a Q8 activation moves logits by percents of their spread;
-        # the yardstick is the model band, as everywhere on the wide path
-        check_logits("q4", la, lb, float(lb.std()))
-        top2 = np.sort(la)[-2:]
-        if top2[1] - top2[0] > 0.05 * float(la.std()):
-            assert ra == rb
-
-
 @pytest.mark.parametrize("heads,kv", [(8, 1), (4, 2), (4, 4)])
-def test_grouped_attention_is_bit_identical_to_per_head_kernels(hip, monkeypatch, heads, kv):
-    """wide decode serves all query heads of a kv group from one workgroup (k_dec_attn_score_g / _pv_g): the same
-    bytes as the per-head kernels (GTEN_HIP_ATTN_PER_HEAD=1) -- argmax ids and logits of every sequence, across the
-    attention chunk boundary -- for 8, 2 and 1 query heads per kv head"""
+def test_wide_exact_forms_track_the_fast_forms(hip, heads, kv):
+    """gten_hip_set_decode_exact(1): the wide step with row-global rounding points of the probabilities (the grouped VALU
+    pair k_dec_attn_score_g / _pv_g with exact p.V terms) and exact integer block sums in the W.x (k_dec_mmv), for 8, 2 and 1
+    query heads per kv head, across the attention chunk boundary.  Both forms inside the model band of each other, equal
+    greedy ids wherever the margin is clear; each form is repeatable bit for bit."""
     from helpers import Q4, Q8
+    from test_model_gpu import check_logits
     pkg = load_package()
     host = pkg.load_host()
     cfg = host_cfg(tiny_config(Q4, Q8, n_embd=64 * heads, n_ffn=512, n_heads=heads, n_kv_heads=kv, max_ctx=320, n_layers=2))
     n_seq, N = 16, 270
     streams = [host.synthetic_tokens(N, seed=40 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
     runs = []
-    monkeypatch.setenv("GTEN_HIP_ATTN_EXACT", "1")     # 16 sequences and up fuse the p.V multiply-add by default
-    monkeypatch.setenv("GTEN_HIP_ATTN_TWO_PASS", "1")  # the per-head kernels in their two-launch form (row-global statistics, as the grouped pair)
-    for per_head in ("1", "0"):
-        monkeypatch.setenv("GTEN_HIP_ATTN_PER_HEAD", per_head)
-        batch = host.batch(cfg, n_seq)
-        for i in range(len(cfg.weight_shapes())):
-            batch.set_weight(i, host.synth_weight(cfg, 12, i))
-        for q in range(n_seq):
-            batch.decode_begin(q, streams[q])
-        snaps = []
-        for n in range(1, N + 1):
-            batch.decode_step(n, n % 3 != 0)
-            if n in (1, 5, 255, 256, 257, N):
-                snaps.append([(batch.decode_result(q, n), batch.logits(q).copy()) for q in range(n_seq)])
-        runs.append(snaps)
-        batch.close()
-    for sa, sb in zip(*runs):
-        for (ra, la), (rb, lb) in zip(sa, sb):
-            assert ra == rb and np.array_equal(la, lb)
+    try:
+        for exact in (True, True, False):
+            hip.set_decode_exact(exact)                 # (read when the decoder is created)
+            batch = host.batch(cfg, n_seq)
+            for i in range(len(cfg.weight_shapes())):
+                batch.set_weight(i, host.synth_weight(cfg, 12, i))
+            for q in range(n_seq):
+                batch.decode_begin(q, streams[q])
+            snaps = []
+            for n in range(1, N + 1):
+                batch.decode_step(n, n % 3 != 0)
+                if n in (1, 5, 255, 256, 257, N):
+                    snaps.append([(batch.decode_result(q, n), batch.logits(q).copy()) for q in range(n_seq)])
+            runs.append(snaps)
+            batch.close()
+    finally:
+        hip.set_decode_exact(False)
+    for sa, sb, sc in zip(*runs):
+        for (ra, la), (rb, lb), (rc, lc) in zip(sa, sb, sc):
+            assert ra == rb and np.array_equal(la, lb)              # exact form: repeatable
+            check_logits("q4", lc, la, float(la.std()))
+            top2 = np.sort(la)[-2:]
+            if top2[1] - top2[0] > 0.05 * float(la.std()):
+                assert ra == rc
 
 
 @pytest.mark.parametrize("n_seq", [4, 16])

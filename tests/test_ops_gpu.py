@@ -307,10 +307,14 @@ def test_qkv_attn_tiled_prefill_equals_row_kernel(hip, oracle, monkeypatch, n, s
     outs = []
     hip.set_prefill_exact(True)
     try:
-        for off in ("1", "0"):
-            monkeypatch.setenv("GTEN_HIP_NO_TILED_ATTN", off)
+        for pieces in (True, False):
+            # the row kernel k_attn (calls of fewer than 16 new rows: the same rows in 15-row pieces), then the tiled kernel
             out = hip.upload(np.full((n, row_bytes(Q8, H * dh)), 0xCD, np.uint8))
-            hip.qkv_attn(qd, kd, vd, out, Q8, n, H, G, dh, sp)
+            if pieces:
+                for r0 in range(sp, n, 15):
+                    hip.qkv_attn(qd, kd, vd, out, Q8, min(r0 + 15, n), H, G, dh, r0)
+            else:
+                hip.qkv_attn(qd, kd, vd, out, Q8, n, H, G, dh, sp)
             outs.append(out.download(shape=(n, row_bytes(Q8, H * dh))))
     finally:
         hip.set_prefill_exact(False)

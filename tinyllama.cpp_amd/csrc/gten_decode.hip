@@ -3299,6 +3299,7 @@ struct gten_hip_decoder {
     // lane of 64 sequences, each on the rows of every buffer that belong to its sequences -- as parallel branches of ONE
     // graph (fork behind the previous replay, join at the end), so the chains fill each other's gaps.  Per sequence the
     // kernels, their arguments and therefore the results are those of a 64-sequence decoder.
+    bool exact = false;               // gten_hip_set_decode_exact at creation
     int lanes = 1;
     hipStream_t lane_stream[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};    // capture / eager side streams of lanes 1..
     hipEvent_t lane_fork = nullptr, lane_join[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -3336,12 +3337,23 @@ static LaneBufs lane_bufs(const gten_hip_decoder* dc, int lane)
     return b;
 }
 
+// gten_hip_set_decode_exact (include/gten_hip.h): the exact forms of the decode step -- row-global rounding points of the
+// attention probabilities (two launches), exact p.V terms, integer block sums in the wide W.x (k_dec_mmv) -- instead of
+// the fast ones.  A decoder keeps the choice it was created with (its graphs are captured once); g_exact_now is that
+// choice while one of its steps is being enqueued.
+static bool g_decode_exact = false;
+static bool g_exact_now = false;
+extern "C" int gten_hip_set_decode_exact(int on)
+{
+    g_decode_exact = on != 0;
+    return 0;
+}
+
 // many sequences, Q8 activations, 64-wide heads, 8 (or 4, 2, 1) query heads per kv head: grouped kernels
 static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
 {
     const int grp = t.n_heads / t.n_kv;
-    const char* e = std::getenv("GTEN_HIP_ATTN_PER_HEAD");      // =1: the per-head kernels (comparison / tests)
-    const bool off = e && e[0] == '1';
+    const bool off = false;
     const int min_seq = 8;                                       // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
     if (t.adtype == GTEN_F16 && n_seq < 16) return false;        // f16 below 16 sequences: the per-head kernels (one launch, k_dec_attn_one64)
     return !off && n_seq >= min_seq && (t.adtype == GTEN_Q8 || t.adtype == GTEN_F16) && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
@@ -3358,13 +3370,11 @@ static bool attention_one_pass(int d_head);
 // which grouped launches run in the one-pass form (k_dec_attn_one_g; the consumer then joins with PRO_ATTW): every
 // Q8 configuration; f16 only below 16 sequences is per-head anyway, from 16 up its scores stay on the matrix cores
 // (k_dec_attn_score_gm_f16) in the two-launch form
-// 16-64 sequences with Q8 activations: k_dec_attn_mm_g (one launch, matrix cores).  GTEN_HIP_ATTN_EXACT=1 or
-// GTEN_HIP_ATTN_TWO_PASS=1 keep the VALU pair (exact p.V terms / row-global rounding points; tests compare).
+// 16-64 sequences with Q8 activations: k_dec_attn_mm_g (one launch, matrix cores).  The exact forms
+// (gten_hip_set_decode_exact) keep the VALU pair: exact p.V terms, row-global rounding points; tests compare.
 static bool grouped_mm(const AttnArgs& t, int n_seq)
 {
-    const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
-    const char* tp = std::getenv("GTEN_HIP_ATTN_TWO_PASS");
-    return n_seq >= 16 && t.adtype == GTEN_Q8 && t.d_head == 64 && !(ex && ex[0] == '1') && !(tp && tp[0] == '1');
+    return n_seq >= 16 && t.adtype == GTEN_Q8 && t.d_head == 64 && !g_exact_now;
 }
 
 static bool grouped_one_pass(const AttnArgs& t, int n_seq)
@@ -3398,9 +3408,8 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     const size_t smem1 = (size_t)(8 * GRP + 4 * GRP + 8 + 64) * 4 + (size_t)4 * (GRP + 2) * 2 + (size_t)(GRP + 2) * 64 + 64 +
                          (ADT == GTEN_Q8 ? 0 : (size_t)(GRP + 1) * 64 * 4 + 16);
     const size_t smem2 = (size_t)((GRP + 1) / 2 * 2) * DEC_CHUNK * 4 + (size_t)DEC_CHUNK * NW * 4 + (size_t)(16 + 8 * GRP) * 4;
-    // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (GTEN_HIP_ATTN_EXACT=1)
-    const char* ex = std::getenv("GTEN_HIP_ATTN_EXACT");
-    const bool exact = n_seq <= 8 || (ex && ex[0] == '1');
+    // exact p.V terms up to 8 sequences (bit-identical to single-sequence decode) or on request (gten_hip_set_decode_exact)
+    const bool exact = n_seq <= 8 || g_exact_now;
     if (smem2 > 64 * 1024) {
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, true, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, false, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
@@ -3445,13 +3454,12 @@ static int launch_attention_grouped(const AttnArgs& t, int n_seq)
 }
 
 // One launch with chunk-local statistics (k_dec_attn_one64) wherever the per-head 64-wide kernels run; the consumer
-// must then join the chunks with PRO_ATTW.  GTEN_HIP_ATTN_TWO_PASS=1 keeps the two launches, whose probabilities are
-// rounded against the statistics of the whole row exactly as the reference stores them (a numerics switch: the
-// contexts beyond one chunk then match the operator path's rounding points; tests compare both).
+// must then join the chunks with PRO_ATTW.  The exact forms (gten_hip_set_decode_exact) keep the two launches, whose
+// probabilities are rounded against the statistics of the whole row exactly as the reference stores them (the contexts
+// beyond one chunk then match the operator path's rounding points; tests compare both).
 static bool attention_one_pass(int d_head)
 {
-    const char* e = std::getenv("GTEN_HIP_ATTN_TWO_PASS");
-    return d_head == 64 && !(e && e[0] == '1');
+    return d_head == 64 && !g_exact_now;
 }
 
 static int launch_attention(const AttnArgs& t0, dim3 agrid, size_t smem1)
@@ -3897,11 +3905,10 @@ static int mmvh_prepare()
 #undef MMVH_ATTR
     return 0;
 }
-// the wide path's W.x form: f16 fragments with folded deltas (k_dec_mmvh) unless GTEN_HIP_MMV_EXACT=1
+// the wide path's W.x form: f16 fragments with folded deltas (k_dec_mmvh) unless the exact forms are selected
 static bool mmv_folded()
 {
-    static const bool on = [] { const char* e = std::getenv("GTEN_HIP_MMV_EXACT"); return !(e && e[0] == '1'); }();
-    return on;
+    return !g_exact_now;
 }
 
 // (before the first launch, outside any stream capture: the slab may need more than 64 KB of LDS)
@@ -3992,9 +3999,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         return launch_mmv<WT>(tag, a);
     };
     // K split of the launches with few feature tiles (q|k|v, o, down): two workgroups per tile, two output planes that
-    // the consumers add (staging launches: raw_plane; grouped score kernel: qkv_plane).  GTEN_HIP_MMV_KSPLIT=1: off.
-    const char* kse = std::getenv("GTEN_HIP_MMV_KSPLIT");
-    const int ksplit = (kse && atoi(kse) == 1) ? 1 : 2;
+    // the consumers add (staging launches: raw_plane; grouped score kernel: qkv_plane)
+    const int ksplit = 2;
     auto mmk = [&](int tag, const int8_t* aq, const float* ad, float* out, int out_cols, int d_in, int ks, const void* w, int d_out,
                    const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0) -> int {
         if (folded) return mmh(tag, aq, out, out_cols, d_in, ks, w, d_out, w1, d1, w2, d2);
@@ -4049,10 +4055,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         sh.act_q = b.stg_q; sh.act_d = b.stg_d; sh.act_sum = b.stg_sum; sh.act_f = b.stg_f;
         if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
         // gate|up has 176-352 workgroups already; the split measured +4 % at 16 sequences, +2 % at 64, -2 % at 32
-        const char* kge = std::getenv("GTEN_HIP_MMV_KSPLIT_GU");
-        const int ks_gu = (kge ? atoi(kge) == 2 : (S + 15) / 16 != 2) ? ks_of(E) : 1;
-        static const bool no_fuse = [] { const char* e = std::getenv("GTEN_HIP_MMV_NO_SILU_FUSE"); return e && e[0] == '1'; }();
-        const bool fuse_ffn = folded && !no_fuse && WT == GTEN_Q4 && E / 32 <= 32 * (MMV_MAXP / 4);      // (a tile's slab: <= 2 pieces per thread)
+        const int ks_gu = ((S + 15) / 16 != 2) ? ks_of(E) : 1;
+        const bool fuse_ffn = folded && WT == GTEN_Q4 && E / 32 <= 32 * (MMV_MAXP / 4);      // (a tile's slab: <= 2 pieces per thread)
         if (fuse_ffn) {
             if ((rc = launch_mmvh_silu<WT>(KT_DEC_GEMV_GATEUP, (const uint16_t*)b.stg_q, L.wgate, L.wup, F, E, S, (uint16_t*)b.act_q))) return rc;
         } else {
@@ -4092,6 +4096,7 @@ static int enqueue_multi(gten_hip_decoder* dc, int lane)
 // one step of one lane (a decoder of up to 64 sequences has the single lane 0)
 static int enqueue_lane(gten_hip_decoder* dc, int lane)
 {
+    g_exact_now = dc->exact;
     if (dc->n_seq > 1) {
         switch (dc->d.wdtype) {
         case GTEN_F16: return enqueue_multi<GTEN_F16>(dc, lane);
@@ -4184,6 +4189,7 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     const bool wide = n_seq >= 16;
     dc->d = d;
     dc->n_seq = n_seq;
+    dc->exact = g_decode_exact;
     dc->lanes = (n_seq + 63) / 64;
     for (int g = 1; g < dc->lanes; g++) {
         GTR_CHECK(hipStreamCreateWithFlags(&dc->lane_stream[g], hipStreamNonBlocking));

@@ -759,13 +759,20 @@ __global__ __launch_bounds__(64) void k_splitk_finish_norm(const MatArgs ms, int
     }
 }
 
-// f16 copy of the new Q8 activation rows, owned by the library and reused call after call (one stream)
+// f16 copy of the new Q8 activation rows, owned by the library and reused call after call: ONE SET PER STREAM of the
+// library (prompts are processed on stream 1 beside the decode slices of stream 0, and nothing stops a caller from running
+// prompt-sized calls on both: two streams must never share a scratch whose contents live from one launch to the next)
 static int act_scratch(size_t a_bytes, size_t d_bytes, uint8_t** a16, float** da)
 {
     using namespace gtr;
-    static uint8_t* buf_a = nullptr;
-    static float* buf_d = nullptr;
-    static size_t cap_a = 0, cap_d = 0;
+    static uint8_t* bufs_a[2] = {nullptr, nullptr};
+    static float* bufs_d[2] = {nullptr, nullptr};
+    static size_t caps_a[2] = {0, 0}, caps_d[2] = {0, 0};
+    const int si = stream_index();
+    uint8_t*& buf_a = bufs_a[si];
+    float*& buf_d = bufs_d[si];
+    size_t& cap_a = caps_a[si];
+    size_t& cap_d = caps_d[si];
     if (a_bytes > cap_a) {
         if (buf_a) { GTR_CHECK(hipStreamSynchronize(stream())); GTR_CHECK(hipFree(buf_a)); }
         buf_a = nullptr; cap_a = 0;
@@ -785,8 +792,10 @@ static int act_scratch(size_t a_bytes, size_t d_bytes, uint8_t** a16, float** da
 static int partial_scratch(size_t bytes, float** out)
 {
     using namespace gtr;
-    static float* buf = nullptr;
-    static size_t cap = 0;
+    static float* bufs[2] = {nullptr, nullptr};      // (one per stream, as act_scratch)
+    static size_t caps[2] = {0, 0};
+    float*& buf = bufs[stream_index()];
+    size_t& cap = caps[stream_index()];
     if (bytes > cap) {
         if (buf) { GTR_CHECK(hipStreamSynchronize(stream())); GTR_CHECK(hipFree(buf)); }
         buf = nullptr; cap = 0;
@@ -795,12 +804,6 @@ static int partial_scratch(size_t bytes, float** out)
     }
     *out = buf;
     return 0;
-}
-
-static bool splitk_enabled()
-{
-    static const bool on = [] { const char* e = std::getenv("GTEN_HIP_MFMA_SPLITK"); return !(e && e[0] == '0'); }();
-    return on;
 }
 
 // measured, whole prompts of 16 / 64 / 256 / 512 ids (q4): 3.09 / 3.67 / 4.26 / 5.21 ms without sharing, 2.22 / 2.55 / 3.59 /
@@ -871,7 +874,7 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
     int ks = 1;
     // (row segments set: never -- the factor depends on the row count, and a prompt must get the same bits whatever
     //  shares the row matrix with it, gten_hip_set_row_segments)
-    if (FAST && out_dtype == GTEN_Q8 && splitk_enabled() && !row_segments(nullptr)) {
+    if (FAST && out_dtype == GTEN_Q8 && !row_segments(nullptr)) {
         ks = splitk_factor(rows, d_in, m.d_out[0]);
         for (int k = 1; k < m.n; k++)
             if (splitk_factor(rows, d_in, m.d_out[k]) != ks) ks = 0;              // (mixed: the caller launches them one by one)

@@ -11,6 +11,7 @@ namespace gtr {
 
 int fail(int code, const char* fmt, ...);
 hipStream_t stream();
+int stream_index();                    // 0 or 1: which of the library's two streams is selected (gten_hip_select_stream)
 void stream_override(hipStream_t s);   // launches go to `s` until it is reset with nullptr (a decoder's lanes, gten_decode.hip)
 bool inited();
 int rope_table(int d_head, const float2** out);

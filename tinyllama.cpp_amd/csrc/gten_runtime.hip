@@ -38,6 +38,7 @@ int fail(int code, const char* fmt, ...)
 static hipStream_t g_override = nullptr;
 hipStream_t stream() { return g_override ? g_override : g_streams[g_cur]; }
 void stream_override(hipStream_t s) { g_override = s; }
+int stream_index() { return g_cur; }
 bool inited() { return g_inited; }
 
 // RoPE angles use the host libm exactly as the reference does

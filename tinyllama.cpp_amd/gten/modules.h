@@ -125,6 +125,19 @@ inline void record(PendingRow& p, const void* new_tail, std::function<void()> re
 inline bool run_fused_row(PendingRow& p, EmbeddingLinear* head);     // defined below the module classes
 inline void forget_decoder(const EmbeddingLinear* head);
 
+// A module that is part of the recorded row goes away (a model destroyed between Embedding::forward and lm_head): the
+// recording holds its address and closures that call it.  The recorded calls are run NOW, while the module is still
+// alive -- nothing is skipped, nothing dangles.  (Copies of modules -- a vector of AttentionBlocks being filled -- are
+// never part of a recording: a recording only ever holds the addresses forward() was called on.)
+inline void module_gone(const void* m)
+{
+    PendingRow& p = pending_row();
+    if (!p.active) return;
+    bool mine = (const void*)p.emb == m || (const void*)p.norm == m;
+    for (const AttentionBlock* b : p.blocks) mine = mine || (const void*)b == m;
+    if (mine) settle_row();
+}
+
 } // namespace detail
 
 /// Embedding table lookup, tokens (n_ctx,) -> (n_ctx, d_embed).  gten/modules.cpp:11-26
@@ -135,6 +148,9 @@ public:
         : weight{Tensor({n_vocab, d_embed}, dtype.wdtype)}, emb_acv{Tensor({max_ctx, d_embed}, dtype.adtype)}
     {
     }
+    Embedding(const Embedding&) = default;
+    Embedding& operator=(const Embedding&) = default;
+    ~Embedding() { detail::module_gone(this); }
     Tensor forward(const Tensor& tokens, const int start_pos = 0)
     {
         detail::settle_pending();
@@ -185,6 +201,9 @@ public:
         : weight{Tensor({d_in}, kFloat16)}, acv{Tensor({max_ctx, d_in}, dtype.adtype)}
     {
     }
+    RMSNorm(const RMSNorm&) = default;
+    RMSNorm& operator=(const RMSNorm&) = default;
+    ~RMSNorm() { detail::module_gone(this); }
     Tensor forward(const Tensor& inp, const int start_pos = 0)
     {
         detail::PendingRow& p = detail::pending_row();
@@ -441,6 +460,9 @@ public:
           ffn_silu{SiLU(max_ctx, n_mlp, dtype.adtype, /*inplace=*/true)}
     {
     }
+    AttentionBlock(const AttentionBlock&) = default;
+    AttentionBlock& operator=(const AttentionBlock&) = default;
+    ~AttentionBlock() { detail::module_gone(this); }
 
     // down( silu(gate(x)) * up(x) ), SiLU and the product in place on the gate buffer
     Tensor ffn_forward(const Tensor& inp, const int start_pos = 0)
@@ -629,7 +651,12 @@ inline bool run_fused_row(PendingRow& p, EmbeddingLinear* head)
     gten_hip_decoder_desc d;
     std::vector<gten_hip_layer_ptrs> L;
     if (!describe_row(p, head, &d, &L)) return give_up();
-    const bool same = rd.dec && std::memcmp(&d, &rd.desc, sizeof(d)) == 0 && L.size() == rd.layers.size() &&
+    // (field by field: the descriptor has padding between its ints and its pointers; the layer records are pointers only)
+    const gten_hip_decoder_desc& o = rd.desc;
+    const bool same_desc = d.n_vocab == o.n_vocab && d.max_ctx == o.max_ctx && d.n_embd == o.n_embd && d.n_ffn == o.n_ffn && d.n_layers == o.n_layers &&
+                           d.n_heads == o.n_heads && d.n_kv_heads == o.n_kv_heads && d.wdtype == o.wdtype && d.adtype == o.adtype &&
+                           d.embed == o.embed && d.final_norm == o.final_norm && d.lm_head == o.lm_head && d.logits == o.logits;
+    const bool same = rd.dec && same_desc && L.size() == rd.layers.size() &&
                       std::memcmp(L.data(), rd.layers.data(), L.size() * sizeof(gten_hip_layer_ptrs)) == 0;
     if (!same) {
         if (rd.dec) gten_hip_decoder_destroy(rd.dec);
@@ -644,6 +671,11 @@ inline bool run_fused_row(PendingRow& p, EmbeddingLinear* head)
     }
     GTEN_HIP_OK(gten_hip_decoder_set_tokens(rd.dec, &p.token, p.n - 1, 1));
     GTEN_HIP_OK(gten_hip_decoder_step(rd.dec, p.n, /*use_graph=*/1));
+    // the step appended row n - 1 to the caches: their tensors say so, as after the modules' own forward (gten/modules.cpp:196-201)
+    for (AttentionBlock* b : p.blocks) {
+        b->attn.key.acv.resize({p.n, b->attn.key.acv.dimsize(1)});
+        b->attn.value.acv.resize({p.n, b->attn.value.acv.dimsize(1)});
+    }
     p.blocks.clear();
     p.norm = nullptr;
     return true;

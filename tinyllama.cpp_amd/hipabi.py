@@ -85,7 +85,7 @@ class GtenHip:
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
         "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_block_rows", "gten_hip_set_block_rows", "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
-        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact", "gten_hip_set_row_segments", "gten_hip_row_segments_ok", "gten_hip_copy_ranges",
+        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact", "gten_hip_set_decode_exact", "gten_hip_set_row_segments", "gten_hip_row_segments_ok", "gten_hip_copy_ranges",
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
         # the export check covers the whole header
         "gten_hip_decoder_create", "gten_hip_decoder_destroy", "gten_hip_decoder_set_tokens",
@@ -130,6 +130,7 @@ class GtenHip:
         self._prefill_exact = _sig(L, "gten_hip_set_prefill_exact", ci, [ci])
         self._block_rows = _sig(L, "gten_hip_block_rows", ci, [C.POINTER(BlockDesc), ci, ci])
         self._set_block_rows = _sig(L, "gten_hip_set_block_rows", ci, [ci])
+        self._decode_exact = _sig(L, "gten_hip_set_decode_exact", ci, [ci])
         self._set_row_segments = _sig(L, "gten_hip_set_row_segments", ci, [C.c_void_p, ci])
         self._copy_ranges = _sig(L, "gten_hip_copy_ranges", ci, [C.c_void_p, ci])
         self.initialised = False
@@ -176,6 +177,10 @@ class GtenHip:
             _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("bytes", C.c_size_t)]
         arr = (R * len(ranges))(*[R(int(d), int(s), int(b)) for d, s, b in ranges])
         self._check(self._copy_ranges(C.cast(arr, C.c_void_p), len(ranges)))
+
+    def set_decode_exact(self, on):
+        """exact forms of the decode step for decoders created from now on (include/gten_hip.h)"""
+        self._check(self._decode_exact(1 if on else 0))
 
     def set_prefill_exact(self, on):
         """prompt-sized W.x with quantized weights: exact form (scalar-build order, bit for bit) instead of the fast one"""
