@@ -85,6 +85,7 @@ def parse_args(argv=None):
                          "(default) or one prompt-processing call -- the latter keeps a rocprofv3 kernel trace to "
                          "thousands instead of hundreds of thousands of launches")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the 256-sequence (four lanes) leg")
     ap.add_argument("--brief", action="store_true", help="only the metric line: no secondary legs, no CPU baseline")
     ap.add_argument("--curve", action="store_true",
                     help="with --gpus N > 1 under this file's own launcher: first run 1, 2, 4, ... < N replicas (brief) and "
@@ -705,47 +706,6 @@ def worker(args, rank, local_rank, world, dist):
         batch.close()
         return res
 
-    # secondary: TWO groups of S sequences, each group its own decoder (own weights pass per step), on the library's two
-    # streams: the step of a group is a chain of ~180 dependent launches that leaves the chip idle between them, so the two
-    # chains interleave (the same effect as two replicas per GPU, inside one process)
-    def two_groups(S):
-        groups = []
-        for gi in range(2):
-            b = host.batch(cfg, S)
-            b.load_synthetic(args.seed)
-            seqs = [host.synthetic_tokens(N_CTX, seed=rep_seed(4242 + gi, 1000 + q)) for q in range(S)]
-            for q in range(S):
-                b.prefill(q, seqs[q][:first - 1], want=False)
-            for q in range(S):
-                b.decode_begin(q, seqs[q])
-            groups.append(b)
-        try:
-            for gi, b in enumerate(groups):                 # untimed: each group's four-step graph, captured on its stream
-                hip.select_stream(gi)
-                b.decode_steps(n_of(0, total), 4, True)
-                for i in range(4, W):
-                    b.decode_step(n_of(i, total), True)
-                hip.sync()
-            hip.select_stream(0)
-            t0 = time.perf_counter()
-            for gi, b in enumerate(groups):
-                hip.select_stream(gi)
-                b.decode_steps(n_of(W, total), K, True)
-            for gi in (0, 1):
-                hip.select_stream(gi)
-                hip.sync()
-            dt = time.perf_counter() - t0
-            hip.select_stream(0)
-            last = [int(groups[gi].decode_result(0, n_of(W + K - 1, total))) for gi in (0, 1)]
-        finally:
-            hip.select_stream(0)
-            for b in groups:
-                b.close()
-        return {"groups": 2, "streams_per_group": S, "tok_s": round(2 * S * K / dt, 1), "ms_per_pair_of_steps": round(dt / K * 1e3, 4),
-                "last_tokens": last,
-                "note": "two decoders of %d sequences each on the library's two streams (each streams the weights once per step); "
-                        "the two dependent launch chains fill each other's gaps" % S}
-
     if secondary and fused and (args.streams > 1 or args.wide_streams > 1):
         model.close()
         if args.streams > 1:
@@ -758,11 +718,15 @@ def worker(args, rank, local_rank, world, dist):
                                                      "W.x of the step as int8 MFMA GEMV (k_dec_mmv, rows = sequences), GQA-grouped attention; ") +
                                                     "per sequence inside the model band around single-sequence decode, "
                                                     "graph == eager bit for bit (tests/test_multiseq_gpu.py)")
-        if args.wide_streams == 64 and use_graph and total <= N_CTX - 1 and args.mode != "f16":
+        if args.wide_streams == 64 and use_graph and total <= N_CTX - 1 and not args.no_lanes:
+            # round 3: 256 sequences in ONE decoder -- four lanes of 64, each lane's launch chain a parallel branch of the
+            # step's graph (round 2 measured the effect with two separate decoders on two streams: multi_stream_wide_x2)
             try:
-                out["multi_stream_wide_x2"] = two_groups(args.wide_streams)
+                out["multi_stream_lanes"] = multi_stream(256, "one decoder, four lanes of 64 sequences: the lanes' launch chains are parallel "
+                                                              "branches of one graph and fill each other's gaps; per sequence the kernels and the bits "
+                                                              "of a 64-sequence decoder (tests/test_multiseq_gpu.py)")
             except Exception as e:
-                out["multi_stream_wide_x2"] = {"tok_s": None, "note": "two-group leg unavailable: %r" % (e,)}
+                out["multi_stream_lanes"] = {"tok_s": None, "note": "lanes leg unavailable: %r" % (e,)}
         model = host.model(cfg)
         model.load_synthetic(args.seed)
     # secondary: real greedy generation of a whole batch (sampler on the device, every sequence its own prompt)
