@@ -33,3 +33,4 @@ for p in ("p1", "p2", "p3", "p4"):
             print(f"{k:64s} dispatches {n:5d} " + " ".join(f"{c}={v / n:.0f}" for c, v in sorted(agg[k].items())))
 PY
 cat $R/gpurun_out/pmc_prefill_$TAG.txt
+rm -rf $OUT        # (raw counter files: far beyond what gpurun copies back)
