@@ -325,6 +325,22 @@ def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist,
                     % (n_global // world, slots)}
 
 
+class Leg:
+    """a secondary leg of the line: an exception inside it is recorded under the leg's name instead of costing the line"""
+
+    def __init__(self, out, name):
+        self.out, self.name = out, name
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and issubclass(et, Exception):
+            self.out[self.name] = {"error": "%s: %s" % (et.__name__, ev)}
+            return True
+        return False
+
+
 def load_replicas():
     """tinyllama.cpp_amd/replicas.py by path: the launcher parent must not import anything that could touch the GPU"""
     import importlib.util
@@ -637,28 +653,30 @@ def worker(args, rank, local_rank, world, dist):
     # secondary (median and mean per step): the same K steps again with a synchronise after each one,
     # i.e. the latency a caller that waits for every token sees (`value` above queues the K steps back to back)
     if secondary and fused:
-        per = []
-        for i in range(K):
-            n = n_of(W + i, total)
-            hip.sync()
-            t0 = time.perf_counter()
-            model.decode_step(n, use_graph)
-            hip.sync()
-            per.append(time.perf_counter() - t0)
-        med = float(np.median(per))
-        out["per_step_synced"] = {"steps": K, "median_ms": round(med * 1e3, 4), "mean_ms": round(float(np.mean(per)) * 1e3, 4),
-                                  "tok_s_from_median": round(1.0 / med, 1)}
+      with Leg(out, "per_step_synced"):
+            per = []
+            for i in range(K):
+                n = n_of(W + i, total)
+                hip.sync()
+                t0 = time.perf_counter()
+                model.decode_step(n, use_graph)
+                hip.sync()
+                per.append(time.perf_counter() - t0)
+            med = float(np.median(per))
+            out["per_step_synced"] = {"steps": K, "median_ms": round(med * 1e3, 4), "mean_ms": round(float(np.mean(per)) * 1e3, 4),
+                                      "tok_s_from_median": round(1.0 / med, 1)}
     # secondary: the short-context window n in [16, 80) of the same single-sequence decode path
     if secondary and fused:
-        for n in range(1, 80):
-            model.decode_step(n, use_graph)
-        hip.sync()
-        t0 = time.perf_counter()
-        for n in range(16, 80):
-            model.decode_step(n, use_graph)
-        hip.sync()
-        dts = time.perf_counter() - t0
-        out["short_ctx"] = {"window": "n in [16, 80)", "steps": 64, "ms_per_step": round(dts / 64 * 1e3, 4), "tok_s": round(64 / dts, 1)}
+      with Leg(out, "short_ctx"):
+            for n in range(1, 80):
+                model.decode_step(n, use_graph)
+            hip.sync()
+            t0 = time.perf_counter()
+            for n in range(16, 80):
+                model.decode_step(n, use_graph)
+            hip.sync()
+            dts = time.perf_counter() - t0
+            out["short_ctx"] = {"window": "n in [16, 80)", "steps": 64, "ms_per_step": round(dts / 64 * 1e3, 4), "tok_s": round(64 / dts, 1)}
     # secondary: several sequences on this GPU sharing every weight pass (not part of `value`)
     def multi_stream(S, note):
         batch = host.batch(cfg, S)
@@ -709,9 +727,11 @@ def worker(args, rank, local_rank, world, dist):
     if secondary and fused and (args.streams > 1 or args.wide_streams > 1):
         model.close()
         if args.streams > 1:
+          with Leg(out, "multi_stream"):
             out["multi_stream"] = multi_stream(args.streams, "GEMV kernels: per sequence bit-identical to the single-sequence decoder "
                                                "(tests/test_multiseq_gpu.py)" if args.streams <= 8 else "W.x on the matrix cores (k_dec_mmv)")
         if args.wide_streams > 1:
+          with Leg(out, "multi_stream_wide"):
             out["multi_stream_wide"] = multi_stream(args.wide_streams,
                                                     ("W.x of the step on v_mfma_f32_16x16x32_f16 (k_dec_mmv_f16, rows = sequences), per-head attention; "
                                                      if args.mode == "f16" else
@@ -731,97 +751,101 @@ def worker(args, rank, local_rank, world, dist):
         model.load_synthetic(args.seed)
     # secondary: real greedy generation of a whole batch (sampler on the device, every sequence its own prompt)
     if secondary and fused and args.generate > 0 and args.wide_streams > 1:
-        S = args.wide_streams
-        G = min(args.generate, N_CTX - 16)
-        P0 = N_CTX - G
-        batch = host.batch(cfg, S)
-        batch.load_synthetic(args.seed)
-        prompts = [host.synthetic_tokens(P0, seed=rep_seed(777, q)) for q in range(S)]
-        batch.prefill(0, prompts[0]); hip.sync()      # warm-up (one-time attribute / scratch set-up)
-        t_pre = 1e9
-        for q in (1, 2):
-            t0 = time.perf_counter(); batch.prefill(q % S, prompts[q % S]); hip.sync()
-            t_pre = min(t_pre, time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        ids = batch.generate(prompts, N_CTX)
-        dt = time.perf_counter() - t0
-        new = sum(len(x) - P0 for x in ids)
-        out["batch_generation"] = {"streams": S, "prompt_tokens_each": P0, "new_tokens": int(new), "wall_s": round(dt, 3),
-                                   "prefill_s_estimate": round(S * t_pre, 3),
-                                   "tok_s": round(new / max(dt - S * t_pre, 1e-9), 1),
-                                   "note": "greedy ids generated up to n = %d for every sequence; tok/s = new ids / (wall time - "
-                                           "n_seq x one prompt's processing time)" % N_CTX}
-        batch.close()
+      with Leg(out, "batch_generation"):
+            S = args.wide_streams
+            G = min(args.generate, N_CTX - 16)
+            P0 = N_CTX - G
+            batch = host.batch(cfg, S)
+            batch.load_synthetic(args.seed)
+            prompts = [host.synthetic_tokens(P0, seed=rep_seed(777, q)) for q in range(S)]
+            batch.prefill(0, prompts[0]); hip.sync()      # warm-up (one-time attribute / scratch set-up)
+            t_pre = 1e9
+            for q in (1, 2):
+                t0 = time.perf_counter(); batch.prefill(q % S, prompts[q % S]); hip.sync()
+                t_pre = min(t_pre, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            ids = batch.generate(prompts, N_CTX)
+            dt = time.perf_counter() - t0
+            new = sum(len(x) - P0 for x in ids)
+            out["batch_generation"] = {"streams": S, "prompt_tokens_each": P0, "new_tokens": int(new), "wall_s": round(dt, 3),
+                                       "prefill_s_estimate": round(S * t_pre, 3),
+                                       "tok_s": round(new / max(dt - S * t_pre, 1e-9), 1),
+                                       "note": "greedy ids generated up to n = %d for every sequence; tok/s = new ids / (wall time - "
+                                               "n_seq x one prompt's processing time)" % N_CTX}
+            batch.close()
     # secondary: continuous batching -- a queue of 256 synthetic prompts (64..512 ids each, up to 128 new ids per prompt)
     # through 64 slots sharing every weight pass; a slot that ends takes the next prompt while the others go on
     if secondary and fused and args.serve > 0 and args.wide_streams > 1:
-        S = args.wide_streams
-        batch = host.batch(cfg, S)
-        batch.load_synthetic(args.seed)
-        prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
-        batch.serve(prompts[:S], N_CTX, -1, 16, max_new=4)           # warm-up: graphs, first-use allocations
-        t0 = time.perf_counter()
-        got, st = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
-        dt = time.perf_counter() - t0
-        out["serving"] = {"slots": S, "prompts": int(args.serve), "prompt_tokens": int(st["prompt_tokens"]), "new_tokens": int(st["new_tokens"]),
-                          "wall_s": round(dt, 3), "new_tok_s": round(st["new_tokens"] / dt, 1),
-                          "all_tok_s": round((st["new_tokens"] + st["prompt_tokens"]) / dt, 1),
-                          "shared_steps": int(st["steps"]), "prefill_s": round(st["prefill_s"], 3), "decode_s": round(st["decode_s"], 3),
-                          "slot_utilisation": round(st["new_tokens"] / max(st["steps"] * S, 1), 3),
-                          "note": "sustained rates over the whole queue (256 prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
-                                  "the library's second stream BESIDE the slices of 16 shared steps (prefill_s = host time spent in it, "
-                                  "overlapped); slot_utilisation = new ids / (shared steps x slots)"}
-        try:
-            # the same queue once more, untimed: the ids must not depend on which prompt overlapped which slice
-            got2, _ = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
-            out["serving"]["same_ids_second_run"] = bool(len(got2) == len(got) and all(np.array_equal(a, b) for a, b in zip(got, got2)))
-        except Exception as e:                                       # a reporting extra: never costs the line
-            out["serving"]["same_ids_second_run"] = "not checked: %s" % type(e).__name__
-        batch.close()
+      with Leg(out, "serving"):
+            S = args.wide_streams
+            batch = host.batch(cfg, S)
+            batch.load_synthetic(args.seed)
+            prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
+            batch.serve(prompts[:S], N_CTX, -1, 16, max_new=4)           # warm-up: graphs, first-use allocations
+            t0 = time.perf_counter()
+            got, st = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
+            dt = time.perf_counter() - t0
+            out["serving"] = {"slots": S, "prompts": int(args.serve), "prompt_tokens": int(st["prompt_tokens"]), "new_tokens": int(st["new_tokens"]),
+                              "wall_s": round(dt, 3), "new_tok_s": round(st["new_tokens"] / dt, 1),
+                              "all_tok_s": round((st["new_tokens"] + st["prompt_tokens"]) / dt, 1),
+                              "shared_steps": int(st["steps"]), "prefill_s": round(st["prefill_s"], 3), "decode_s": round(st["decode_s"], 3),
+                              "slot_utilisation": round(st["new_tokens"] / max(st["steps"] * S, 1), 3),
+                              "note": "sustained rates over the whole queue (256 prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
+                                      "the library's second stream BESIDE the slices of 16 shared steps (prefill_s = host time spent in it, "
+                                      "overlapped); slot_utilisation = new ids / (shared steps x slots)"}
+            try:
+                # the same queue once more, untimed: the ids must not depend on which prompt overlapped which slice
+                got2, _ = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
+                out["serving"]["same_ids_second_run"] = bool(len(got2) == len(got) and all(np.array_equal(a, b) for a, b in zip(got, got2)))
+            except Exception as e:                                       # a reporting extra: never costs the line
+                out["serving"]["same_ids_second_run"] = "not checked: %s" % type(e).__name__
+            batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if secondary and args.prefill > 0:
-        P = min(args.prefill, N_CTX)
-        model.set_fast_decode(False)
-        model.logits(toks[:P], 0, want=False)
-        hip.sync()
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
+      with Leg(out, "prefill"):
+            P = min(args.prefill, N_CTX)
+            model.set_fast_decode(False)
             model.logits(toks[:P], 0, want=False)
-        hip.sync()
-        dt = (time.perf_counter() - t0) / reps
-        flops = 2.0 * 1_034_426_368 * P
-        # where the time goes: one more pass with an event pair around every launch (adds ~2 us per launch)
-        hip.prof_enable(True)
-        model.logits(toks[:P], 0, want=False)
-        fams = {k: round(v[1], 3) for k, v in hip.prof_read().items()}
-        hip.prof_enable(False)
-        wx_ms = fams.get("matmul_2d_mfma", 0.0)
-        out["prefill"] = {"prompt_tokens": P, "ms": round(dt * 1e3, 3), "tok_s": round(P / dt, 1),
-                          "linear_tflops": round(flops / dt / 1e12, 2),
-                          "family_ms": fams,
-                          "wx_tflops": round((flops - 2.0 * 32003 * 2048 * (P - 1)) / (wx_ms * 1e-3) / 1e12, 1) if wx_ms > 0 else None,
-                          "note": "W.x on v_mfma_f32_16x16x32_f16 (gten_mfma.hip, fast form: block deltas folded into the f16 operands, K accumulated in the matrix core), "
-                                  "attention on gten_attn_tiled.hip (int8 / f16 MFMA scores), element-wise ops on the "
-                                  "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time; wx_tflops = the same FLOPs (lm_head: last row only) / "
-                                  "the event-bracketed time of the W.x launches alone (activation expansion included)"}
+            hip.sync()
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model.logits(toks[:P], 0, want=False)
+            hip.sync()
+            dt = (time.perf_counter() - t0) / reps
+            flops = 2.0 * 1_034_426_368 * P
+            # where the time goes: one more pass with an event pair around every launch (adds ~2 us per launch)
+            hip.prof_enable(True)
+            model.logits(toks[:P], 0, want=False)
+            fams = {k: round(v[1], 3) for k, v in hip.prof_read().items()}
+            hip.prof_enable(False)
+            wx_ms = fams.get("matmul_2d_mfma", 0.0)
+            out["prefill"] = {"prompt_tokens": P, "ms": round(dt * 1e3, 3), "tok_s": round(P / dt, 1),
+                              "linear_tflops": round(flops / dt / 1e12, 2),
+                              "family_ms": fams,
+                              "wx_tflops": round((flops - 2.0 * 32003 * 2048 * (P - 1)) / (wx_ms * 1e-3) / 1e12, 1) if wx_ms > 0 else None,
+                              "note": "W.x on v_mfma_f32_16x16x32_f16 (gten_mfma.hip, fast form: block deltas folded into the f16 operands, K accumulated in the matrix core), "
+                                      "attention on gten_attn_tiled.hip (int8 / f16 MFMA scores), element-wise ops on the "
+                                      "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time; wx_tflops = the same FLOPs (lm_head: last row only) / "
+                                      "the event-bracketed time of the W.x launches alone (activation expansion included)"}
     # secondary: real greedy generation (every token is the argmax of the previous step), the reference-style loop
     # (logits to the host, host argmax, one call per token) against the sampler on the device
     if secondary and fused and args.generate > 0:
-        G = min(args.generate, N_CTX - 16)
-        P0 = N_CTX - G
-        prompt = toks[:P0]
-        model.set_fast_decode(True)                  # (the prefill leg above switches the fused single-row path off)
-        t0 = time.perf_counter(); model.logits(prompt, 0, want=True); t_pre = time.perf_counter() - t0
-        res = {}
-        for name, fn in (("host_loop", model.greedy), ("device_sampler", model.generate)):
-            t0 = time.perf_counter()
-            ids = fn(prompt, N_CTX)
-            dt = time.perf_counter() - t0
-            res[name] = {"new_tokens": int(len(ids) - P0), "tok_s": round((len(ids) - P0) / max(dt - t_pre, 1e-9), 1), "last": int(ids[-1])}
-        out["greedy_generation"] = {"prompt_tokens": P0, "prefill_ms": round(t_pre * 1e3, 2), **res,
-                                    "same_ids": res["host_loop"]["last"] == res["device_sampler"]["last"],
-                                    "note": "ids generated up to n = %d; tok/s = new ids / (wall time - prompt processing time)" % N_CTX}
+      with Leg(out, "greedy_generation"):
+            G = min(args.generate, N_CTX - 16)
+            P0 = N_CTX - G
+            prompt = toks[:P0]
+            model.set_fast_decode(True)                  # (the prefill leg above switches the fused single-row path off)
+            t0 = time.perf_counter(); model.logits(prompt, 0, want=True); t_pre = time.perf_counter() - t0
+            res = {}
+            for name, fn in (("host_loop", model.greedy), ("device_sampler", model.generate)):
+                t0 = time.perf_counter()
+                ids = fn(prompt, N_CTX)
+                dt = time.perf_counter() - t0
+                res[name] = {"new_tokens": int(len(ids) - P0), "tok_s": round((len(ids) - P0) / max(dt - t_pre, 1e-9), 1), "last": int(ids[-1])}
+            out["greedy_generation"] = {"prompt_tokens": P0, "prefill_ms": round(t_pre * 1e3, 2), **res,
+                                        "same_ids": res["host_loop"]["last"] == res["device_sampler"]["last"],
+                                        "note": "ids generated up to n = %d; tok/s = new ids / (wall time - prompt processing time)" % N_CTX}
     # secondary: the reference's OWN caller on this path -- its unmodified tinyllama.cpp (TinyLlama::logits per token,
     # logits read on the host, host argmax: tinyllama.cpp:395-440) compiled against this repository's gten headers
     # (oracle/Makefile `dropin`, built where /root/reference exists; the .so travels).  gten/modules.h records the

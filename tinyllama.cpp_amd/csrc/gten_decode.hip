@@ -1156,6 +1156,8 @@ __global__ __launch_bounds__(512) void k_dec_mmvh(const uint16_t* __restrict__ a
             if (32 * k < ppr) {
                 const int lp = min(c0 + 32 * k, ppr - 1);
                 const int gp = (WT == GTEN_Q4) ? b_lo + lp : (lp < nbs ? b_lo + lp : nb + b_lo + (lp - nbs));
+                // (default cache policy on purpose: nontemporal requests here measured 36.5 k = 36.5 k tok/s at 64 sequences and
+                //  57.0 -> 56.0 k at 256 -- a lane's neighbours find the slab in the memory-side cache)
                 wp[f][k] = *(const uint4*)(srow + (size_t)gp * 16);
             }
         const unsigned* drow = (const unsigned*)(pm.ds + frow * nb + b_lo);

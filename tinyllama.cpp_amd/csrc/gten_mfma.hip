@@ -39,6 +39,8 @@
 #include "gten_dev.h"
 #include "gten_rt.h"
 
+#include <algorithm>
+
 using namespace gtd;
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
