@@ -367,6 +367,7 @@ public:
     {
         for (size_t i = 1; i < seqs_.size(); i++)
             for (int w = 0; w < seqs_[0]->n_weights(); w++) seqs_[i]->weight(w) = seqs_[0]->weight(w);
+        pre_.reset();                                        // (the shared prompt matrix aliases the weights too: rebuilt on next use)
     }
     void load_synthetic(uint64_t seed)
     {
