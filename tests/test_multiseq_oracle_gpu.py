@@ -73,8 +73,8 @@ def full_golden():
     return np.load(path)
 
 
-@pytest.mark.parametrize("name,wd,ad", MODES())
-def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name, wd, ad):
+@pytest.mark.parametrize("name,wd,ad,S", [m + (64,) for m in MODES()] + [m + (128,) for m in MODES() if m[0] == "q4"])
+def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name, wd, ad, S):
     """TinyLlama-1.1B, 64 sequences sharing the weight passes: every slot carries the reference's golden token stream
     (15-id prompt through the slot's operator path, then 23 teacher-forced steps of the whole batch on the matrix-core
     decode kernels) and EVERY slot is held to the reference's logits at every step"""
@@ -83,8 +83,7 @@ def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name,
     host = pkg.load_host()
     cfg = host.default_config(wd, ad)
     cfg.max_ctx = 256
-    S = 64
-    batch = host.batch(cfg, S)
+    batch = host.batch(cfg, S)                  # (128: two lanes of 64 in one decoder)
     batch.load_synthetic(int(g["seed"][0]))
     toks = g[f"{name}.avx.tokens"]
     probe = g["probe_ids"]
@@ -119,7 +118,7 @@ def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name,
             worst = [max(worst[0], rms), max(worst[1], mx)]
             assert batch.decode_result(q, n) == int(np.argmax(batch.logits(q)))
     batch.close()
-    print(f"{name} S=64 full size: worst rms {worst[0]:.4f} max {worst[1]:.4f} over 64 slots x {steps - 1} steps")
+    print(f"{name} S={S} full size: worst rms {worst[0]:.4f} max {worst[1]:.4f} over {S} slots x {steps - 1} steps")
 
 
 def test_wide_path_long_context_probe_q4(hip, full_golden):

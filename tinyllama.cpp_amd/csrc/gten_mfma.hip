@@ -930,6 +930,9 @@ static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int 
         // 11.6 for <2,4> on four-block stages and 12.5 for <4,4> on four-block stages (one workgroup per CU)
         // (the 2048-wide projections give exactly 256 of these tiles, one workgroup per CU; 64 x 128 tiles -- 512 workgroups --
         //  measured the same: 13.0 against 13.2 ms for a 2048-id prompt)
+        // (round 3, measured and not kept: 128 x 128 tiles for EVERY projection from 128 rows up, their K loops shared by 2-8
+        //  workgroups until 200 / 400 / 800 workgroups are in flight: 128 rows 1.79 -> 2.25 / 2.37 / 2.36 ms of W.x, 256: 2.27 -> 2.71 /
+        //  2.84 / 3.17, 512: 3.26 -> 3.22 / 3.63 / 3.85, 1024: 4.42 -> 4.63 / 4.73 / 6.03 -- the 64 x 64 tiles with their factors stay)
         if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
     }
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
