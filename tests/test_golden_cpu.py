@@ -123,6 +123,25 @@ def test_full_model_golden_q4_first_steps(oracle):
     m.close()
 
 
+def test_round_half_away_by_one_addition():
+    """The HIP quantizer rounds x * scale half away from zero (gten/quants.h:62: roundf) as
+    trunc(x + copysign(0x1.fffffep-2, x)) (csrc/gten_dev.h: round_half_away_i).  Exhaustive over every
+    binary32 value from 2^-30 up to 2^22 (a Q8 quant never leaves +-127.0001); below 2^-30 both give 0."""
+    c = np.float32(float.fromhex("0x1.fffffep-2"))
+    assert c < np.float32(0.5) and np.nextafter(c, np.float32(1)) == np.float32(0.5)
+    for e in range(-30, 22):
+        base = np.float32(2.0 ** e).view(np.uint32)
+        for lo in range(0, 1 << 23, 1 << 22):
+            x = (base + np.arange(lo, lo + (1 << 22), dtype=np.uint32)).astype(np.uint32).view(np.float32)
+            got = np.trunc(x + c)                                   # one f32 addition (RN), then truncation
+            want = np.floor(x.astype(np.float64) + 0.5)             # half away from zero, exact in binary64
+            assert np.array_equal(got.astype(np.float64), want), e
+            if lo == 0:
+                assert np.array_equal(np.trunc(-x + np.copysign(c, -x)).astype(np.float64), -want)
+    tiny = np.float32(2.0 ** -31)
+    assert np.trunc(tiny + c) == 0
+
+
 def test_div127_markstein():
     """The HIP Q8 quantizer divides the block absmax by 127 with a 3-instruction Markstein sequence
     (csrc/gten_dev.h: div127) instead of the IEEE division expansion.  It must be the correctly rounded

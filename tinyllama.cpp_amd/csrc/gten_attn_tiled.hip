@@ -40,12 +40,18 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(2))) U2 { uint32_t v[2]; };
 struct __attribute__((packed, aligned(2))) U4 { uint32_t v[4]; };
 
+// maximum over each row of 16 lanes, any sign (all lanes active): four v_max_f32 with a DPP operand.  Written out because
+// the compiler spells a step as v_mov 0 + v_mov_dpp + a canonicalising v_max + v_max -- 16 instructions where 4 do, in a
+// kernel bound by VALU issue; the two wait states a DPP read needs behind the VALU write of its source are in the text
+// (the hazard recogniser does not look inside it).
 __device__ __forceinline__ float row16_max(float v)
 {
-    v = fmaxf(v, dpp_mov<0xB1>(v));
-    v = fmaxf(v, dpp_mov<0x4E>(v));
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    return fmaxf(v, dpp_mov<0x140>(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
 }
 // the first four steps of wave_sum(): every lane of a 16-lane row ends with the row's sum
 __device__ __forceinline__ float row16_sum(float v)
@@ -65,7 +71,7 @@ __device__ __forceinline__ long as_long(const U2& u)
 
 struct QFrag {
     long a[2][2];          // [row group][quant block]: MFMA A operand, row = lane % 16, k = 8 * (lane / 16) ..
-    float d[2][2][4];      // deltas of the 4 output rows of this lane: [row group][block][i]
+    float d[2][2][4];      // deltas of the 4 output rows of this lane, times 1 / sqrt(64): [row group][block][i]
 };
 
 // scores of 2 x 16 query rows against the 16 positions of one column group
@@ -81,12 +87,11 @@ __device__ __forceinline__ void tile_scores(const QFrag& q, const uint8_t* __res
         const v4i i0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(q.a[rg][0], kb0, z, 0, 0, 0);
         const v4i i1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(q.a[rg][1], kb1, z, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float acc = 0.f;
-            acc += (float)i0[i] * (q.d[rg][0][i] * kd0);       // gten/ops.h:224-316: block sums scaled by both deltas
-            acc += (float)i1[i] * (q.d[rg][1][i] * kd1);
-            s[rg][i] = acc * 0.125f;                          // 1 / sqrt(64)
-        }
+        for (int i = 0; i < 4; i++)
+            // gten/ops.h:224-316: block sums scaled by both deltas, their sum by 1 / sqrt(64) -- q.d carries that factor: a power
+            // of two commutes with every rounding on the way (no term is near the subnormal range), the same bits in 7
+            // instructions per score instead of 9
+            s[rg][i] = (float)i0[i] * (q.d[rg][0][i] * kd0) + (float)i1[i] * (q.d[rg][1][i] * kd1);
     }
 }
 
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint8_t* qr = q + (size_t)min(r0 + 16 * rg + 4 * lq + i, n - 1) * q_pitch + (size_t)h * 68;
-            qf.d[rg][0][i] = h2f(*(const uint16_t*)qr);
-            qf.d[rg][1][i] = h2f(*(const uint16_t*)(qr + 34));
+            qf.d[rg][0][i] = h2f(*(const uint16_t*)qr) * 0.125f;          // (1 / sqrt(64): tile_scores)
+            qf.d[rg][1][i] = h2f(*(const uint16_t*)(qr + 34)) * 0.125f;
         }
     }
     const int row_base = r0 + 4 * lq;                      // this lane's rows: row_base + 16 rg + i
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int bp = 0; bp < 2; bp++) {
-                    const float amax = row16_max(fmaxf(fabsf(p[rg][2 * bp][i]), fabsf(p[rg][2 * bp + 1][i])));
+                    const float amax = row16_absmax(fmaxf(fabsf(p[rg][2 * bp][i]), fabsf(p[rg][2 * bp + 1][i])));
                     const Q8Scale sc = q8_scale_from_absmax(amax);
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int j = 0; j < 4; j++) o += acc[rr][j];
         }
-        const float amax = row16_max(fmaxf(fabsf(o.x), fabsf(o.y)));
+        const float amax = row16_absmax(fmaxf(fabsf(o.x), fabsf(o.y)));
         const Q8Scale sc = q8_scale_from_absmax(amax);
         const int row = r0 + 4 * rq + rr;
         if (row < n) {

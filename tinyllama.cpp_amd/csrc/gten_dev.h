@@ -115,6 +115,11 @@ __device__ __forceinline__ float nn_max8(float v)              // aligned groups
     i = nn_max_step<0x141>(i);
     return __int_as_float(i);
 }
+__device__ __forceinline__ float row16_absmax(float v)         // each row of 16 lanes
+{
+    int i = __float_as_int(nn_max8(v));
+    return __int_as_float(nn_max_step<0x140>(i));
+}
 __device__ __forceinline__ float nn_max32(float v)             // the two 32-lane halves of the wave
 {
     int i = __float_as_int(nn_max8(v));
@@ -343,16 +348,19 @@ __device__ __forceinline__ Q8Scale q8_scale_from_absmax(float amax)
     s.scale = (delta != 0.0f) ? recip_rn(delta) : 0.0f;
     return s;
 }
-// roundf (half away from zero), exactly: x - trunc(x) is exact for |x| < 2^23
-__device__ __forceinline__ float round_half_away(float x)
+// (int)roundf(x) (half away from zero), exactly, for |x| < 2^22: add the largest float below one half with x's sign (one
+// f32 addition, round to nearest even) and truncate (the conversion does).  A fraction below .5 leaves the sum at most
+// one ulp short of the next integer, a fraction of .5 or more carries it there.  Checked against floor(|x| + .5) over
+// every binary32 value from 2^-30 to 2^22 (tests/test_golden_cpu.py::test_round_half_away_by_one_addition); the build
+// never contracts the product in front of it into this addition (-ffp-contract=off, tests/test_no_packed_f32_cpu.py).
+__device__ __forceinline__ int round_half_away_i(float x)
 {
-    const float r = truncf(x);
-    const float f = x - r;
-    return (fabsf(f) >= 0.5f) ? r + copysignf(1.0f, x) : r;
+    return (int)(x + copysignf(0x1.fffffep-2f, x));
 }
+// a Q8 quant: |x * scale| <= 127 by the scale's construction
 __device__ __forceinline__ int q8_round(float x, float scale)
 {
-    return (int)(int8_t)(int)round_half_away(x * scale);
+    return round_half_away_i(x * scale);
 }
 
 // a lane's Q8 block (32 quants as 8 dwords + its stored delta) into a row of 34-byte blocks, lane L = block L: the

@@ -113,13 +113,6 @@ __device__ __forceinline__ half8 weight_frag(const uint2 bytes, int nibble_shift
     return out;
 }
 
-__device__ __forceinline__ float row16_absmax(float v)
-{
-    v = fmaxf(v, dpp_mov<0xB1>(v));
-    v = fmaxf(v, dpp_mov<0x4E>(v));
-    v = fmaxf(v, dpp_mov<0x141>(v));
-    return fmaxf(v, dpp_mov<0x140>(v));
-}
 
 template <int WT, int WM, int WN, int KB_ = 4>
 struct MfmaCfg {
@@ -241,6 +234,149 @@ struct MatArgs {
     int part_pitch;
     int part_col0[3];
 };
+
+// A wave tile that lies wholly inside a Q8 output (every tile of a prompt GEMM but those on the last rows / features): the same
+// arithmetic as mfma_epilogue below, per output two multiplies, one addition and the conversions, no bounds predicate and no
+// address arithmetic in the vector unit: the row and block of a store are a scalar offset (SALU) on a buffer descriptor, the
+// lane's share (its row group and byte) one VGPR for the whole tile.  The generic form spent 60 VALU instructions per output
+// on predicates and 64-bit addresses, three fifths of all VALU work of a kernel that is bound by VALU issue.
+template <int WM, int WN, bool RESID>
+__device__ __forceinline__ void mfma_epilogue_q8_full(floatx4 (&acc)[WM][WN], const MatArgs& ms, uint8_t* __restrict__ out, const int out_pitch,
+                                                      const int row_base, const int col0, const int g, const int l16, const int start_pos)
+{
+    const size_t boff = (size_t)(col0 >> 5) * GTEN_Q8_BYTES;
+    const int span = (16 * WM - 1) * out_pitch + (WN / 2) * GTEN_Q8_BYTES;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)(start_pos + row_base) * out_pitch + boff), 0, span, 0x00020000);
+    // a block's delta leaves from the first lane of its row: the other lanes' offset lies beyond the descriptor's range, where a
+    // buffer store is dropped -- no exec-mask branch between the blocks, so the scheduler may interleave them
+    constexpr int DROP = 0x40000000;
+    const int vd = 4 * g * out_pitch, vq = vd + 2 + l16, vdp = l16 == 0 ? vd : DROP;
+    const int rpitch = (int)ms.resid_pitch;
+    const int rspan = (16 * WM - 1) * rpitch + (WN / 2) * GTEN_Q8_BYTES;
+    const size_t roff = (size_t)(start_pos + row_base) * ms.resid_pitch + boff;
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(ms.resid + (RESID ? roff : 0)), 0, RESID ? rspan : 0, 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(ms.sum_out + (RESID ? roff : 0)), 0, RESID ? rspan : 0, 0x00020000);
+    const int rd = 4 * g * rpitch, rq = rd + 2 + l16, rdp = l16 == 0 ? rd : DROP;
+#pragma unroll
+    for (int t = 0; t < WM; t++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < WN; j += 2) {
+                const int so = (16 * t + i) * out_pitch + (j >> 1) * GTEN_Q8_BYTES;
+                const float v0 = acc[t][j][i], v1 = acc[t][j + 1][i];
+                const Q8Scale sc = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(v0), fabsf(v1))));
+                const int q0 = q8_round(v0, sc.scale), q1 = q8_round(v1, sc.scale);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q0, rs_o, vq, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q1, rs_o, vq, so + 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(sc.d16, rs_o, vdp, so, 0);
+                if (RESID) {
+                    // ops::add on the block just stored (gten/ops.h:816-860): both operands from their stored bytes
+                    const int ro = (16 * t + i) * rpitch + (j >> 1) * GTEN_Q8_BYTES;
+                    const float dr = h2f(__builtin_amdgcn_raw_buffer_load_b16(rs_r, rd, ro, 0)), dq = sc.ddeq;
+                    const float r0 = (float)(int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rs_r, rq, ro, 0);
+                    const float r1 = (float)(int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rs_r, rq, ro + 16, 0);
+                    const float s0 = r0 * dr + (float)q0 * dq, s1 = r1 * dr + (float)q1 * dq;
+                    const Q8Scale ss = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(s0), fabsf(s1))));
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q8_round(s0, ss.scale), rs_s, rq, ro, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)q8_round(s1, ss.scale), rs_s, rq, ro + 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(ss.d16, rs_s, rdp, ro, 0);
+                }
+            }
+        }
+    }
+}
+
+// Results leave straight from the accumulators (shared by the prompt GEMM kernels): either this workgroup's f32 sums into its
+// plane of a shared K loop, or the rows written in the output dtype (gten/ops.h:73-96), a Q8 output block = two adjacent
+// 16-wide tiles of the wave, with the residual sum behind a single Q8 / f16 projection.  row_base: first row of this wave
+// (relative to start_pos), col0: its first feature.
+template <int WM, int WN>
+__device__ __forceinline__ void mfma_epilogue(floatx4 (&acc)[WM][WN], const MatArgs& ms, const int mi, uint8_t* __restrict__ out, const size_t out_pitch,
+                                              const int d_out, const int out_dtype, const int rows, const int row_base, const int col0, const int g,
+                                              const int l16, const int start_pos)
+{
+    if (ms.partial) {
+        // K shared with other workgroups: this one's f32 sums into its plane
+        float* plane = ms.partial + (size_t)blockIdx.z * rows * ms.part_pitch + ms.part_col0[mi];
+#pragma unroll
+        for (int t = 0; t < WM; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = row_base + 16 * t + 4 * g + i;
+                if (r >= rows) continue;
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int c = col0 + 16 * j + l16;
+                    if (c < d_out) plane[(size_t)r * ms.part_pitch + c] = acc[t][j][i];
+                }
+            }
+        return;
+    }
+    // ---- rows written in the output dtype straight from the accumulators (gten/ops.h:73-96)
+    {
+        const int rb = __builtin_amdgcn_readfirstlane(row_base), cb = __builtin_amdgcn_readfirstlane(col0);
+        if (out_dtype == GTEN_Q8 && rb + 16 * WM <= rows && cb + 16 * WN <= d_out && out_pitch < (size_t)(1 << 24)
+            && (!ms.resid || ms.resid_pitch < (size_t)(1 << 24))) {
+            if (ms.resid) mfma_epilogue_q8_full<WM, WN, true>(acc, ms, out, (int)out_pitch, rb, cb, g, l16, start_pos);
+            else mfma_epilogue_q8_full<WM, WN, false>(acc, ms, out, (int)out_pitch, rb, cb, g, l16, start_pos);
+            return;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < WM; t++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = row_base + 16 * t + 4 * g + i;
+            const bool rok = r < rows;
+            uint8_t* orow = out + (size_t)(start_pos + (rok ? r : rows - 1)) * out_pitch;
+#pragma unroll
+            for (int j = 0; j < WN; j += 2) {
+                const int c0 = col0 + 16 * j + l16, c1 = c0 + 16;
+                const bool ok0 = rok && c0 < d_out, ok1 = rok && c1 < d_out;
+                const float v0 = ok0 ? acc[t][j][i] : 0.f, v1 = ok1 ? acc[t][j + 1][i] : 0.f;
+                if (out_dtype == GTEN_Q8) {
+                    // one 32-wide output block = tiles j, j + 1 of this wave
+                    const Q8Scale sc = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(v0), fabsf(v1))));
+                    uint8_t* blk = orow + (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
+                    const int q0 = q8_round(v0, sc.scale), q1 = q8_round(v1, sc.scale);
+                    if (ok0) blk[2 + l16] = (uint8_t)(int8_t)q0;
+                    if (ok1) blk[18 + l16] = (uint8_t)(int8_t)q1;
+                    if (ok0 && l16 == 0) *(uint16_t*)blk = sc.d16;
+                    if (ms.resid) {
+                        // ops::add on the block just stored (gten/ops.h:816-860 via k_elementwise's arithmetic): both operands
+                        // dequantized from their stored bytes, f32 sum, rounded to a Q8 block again
+                        const size_t boff = (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
+                        const uint8_t* rb = ms.resid + (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch + boff;
+                        const float dr = h2f(*(const uint16_t*)rb), dq = sc.ddeq;
+                        const float s0 = ok0 ? (float)(int)(int8_t)rb[2 + l16] * dr + (float)q0 * dq : 0.f;
+                        const float s1 = ok1 ? (float)(int)(int8_t)rb[18 + l16] * dr + (float)q1 * dq : 0.f;
+                        const Q8Scale ss = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(s0), fabsf(s1))));
+                        uint8_t* sb = ms.sum_out + (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch + boff;
+                        if (ok0) sb[2 + l16] = (uint8_t)(int8_t)q8_round(s0, ss.scale);
+                        if (ok1) sb[18 + l16] = (uint8_t)(int8_t)q8_round(s1, ss.scale);
+                        if (ok0 && l16 == 0) *(uint16_t*)sb = ss.d16;
+                    }
+                } else if (out_dtype == GTEN_F16) {
+                    const uint16_t h0 = f2h(v0), h1 = f2h(v1);
+                    if (ok0) ((uint16_t*)orow)[c0] = h0;
+                    if (ok1) ((uint16_t*)orow)[c1] = h1;
+                    if (ms.resid) {
+                        // ops::add on the f16 values just stored: both operands from their stored halves, f32 sum, one rounding
+                        const size_t ro = (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch;
+                        const uint16_t* rr16 = (const uint16_t*)(ms.resid + ro);
+                        uint16_t* so16 = (uint16_t*)(ms.sum_out + ro);
+                        if (ok0) so16[c0] = f2h(h2f(rr16[c0]) + h2f(h0));
+                        if (ok1) so16[c1] = f2h(h2f(rr16[c1]) + h2f(h1));
+                    }
+                } else {
+                    if (ok0) ((float*)orow)[c0] = v0;
+                    if (ok1) ((float*)orow)[c1] = v1;
+                }
+            }
+        }
+    }
+}
 
 // (2 waves per SIMD = a 256-VGPR budget: the block sums then come back in VGPRs instead of AGPRs, which
 //  would cost four v_accvgpr_read per MFMA in a loop that is bound by VALU issue)
@@ -546,77 +682,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             if (s + u < nstage) stage_body(s + u, raw[u], raw[(u + 1) % NS]);
     }
 
-    if (ms.partial) {
-        // K shared with other workgroups: this one's f32 sums into its plane
-        float* plane = ms.partial + (size_t)blockIdx.z * rows * ms.part_pitch + ms.part_col0[mi];
-#pragma unroll
-        for (int t = 0; t < WM; t++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int r = row0 + wr * 16 * WM + 16 * t + 4 * g + i;
-                if (r >= rows) continue;
-#pragma unroll
-                for (int j = 0; j < WN; j++) {
-                    const int c = col0 + 16 * j + l16;
-                    if (c < d_out) plane[(size_t)r * ms.part_pitch + c] = acc[t][j][i];
-                }
-            }
-        return;
-    }
-    // ---- rows written in the output dtype straight from the accumulators (gten/ops.h:73-96)
-#pragma unroll
-    for (int t = 0; t < WM; t++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = row0 + wr * 16 * WM + 16 * t + 4 * g + i;
-            const bool rok = r < rows;
-            uint8_t* orow = out + (size_t)(start_pos + (rok ? r : rows - 1)) * out_pitch;
-#pragma unroll
-            for (int j = 0; j < WN; j += 2) {
-                const int c0 = col0 + 16 * j + l16, c1 = c0 + 16;
-                const bool ok0 = rok && c0 < d_out, ok1 = rok && c1 < d_out;
-                const float v0 = ok0 ? acc[t][j][i] : 0.f, v1 = ok1 ? acc[t][j + 1][i] : 0.f;
-                if (out_dtype == GTEN_Q8) {
-                    // one 32-wide output block = tiles j, j + 1 of this wave
-                    const Q8Scale sc = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(v0), fabsf(v1))));
-                    uint8_t* blk = orow + (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
-                    const int q0 = q8_round(v0, sc.scale), q1 = q8_round(v1, sc.scale);
-                    if (ok0) blk[2 + l16] = (uint8_t)(int8_t)q0;
-                    if (ok1) blk[18 + l16] = (uint8_t)(int8_t)q1;
-                    if (ok0 && l16 == 0) *(uint16_t*)blk = sc.d16;
-                    if (ms.resid) {
-                        // ops::add on the block just stored (gten/ops.h:816-860 via k_elementwise's arithmetic): both operands
-                        // dequantized from their stored bytes, f32 sum, rounded to a Q8 block again
-                        const size_t boff = (size_t)((col0 + 16 * j) >> 5) * GTEN_Q8_BYTES;
-                        const uint8_t* rb = ms.resid + (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch + boff;
-                        const float dr = h2f(*(const uint16_t*)rb), dq = sc.ddeq;
-                        const float s0 = ok0 ? (float)(int)(int8_t)rb[2 + l16] * dr + (float)q0 * dq : 0.f;
-                        const float s1 = ok1 ? (float)(int)(int8_t)rb[18 + l16] * dr + (float)q1 * dq : 0.f;
-                        const Q8Scale ss = q8_scale_from_absmax(row16_absmax(fmaxf(fabsf(s0), fabsf(s1))));
-                        uint8_t* sb = ms.sum_out + (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch + boff;
-                        if (ok0) sb[2 + l16] = (uint8_t)(int8_t)q8_round(s0, ss.scale);
-                        if (ok1) sb[18 + l16] = (uint8_t)(int8_t)q8_round(s1, ss.scale);
-                        if (ok0 && l16 == 0) *(uint16_t*)sb = ss.d16;
-                    }
-                } else if (out_dtype == GTEN_F16) {
-                    const uint16_t h0 = f2h(v0), h1 = f2h(v1);
-                    if (ok0) ((uint16_t*)orow)[c0] = h0;
-                    if (ok1) ((uint16_t*)orow)[c1] = h1;
-                    if (ms.resid) {
-                        // ops::add on the f16 values just stored: both operands from their stored halves, f32 sum, one rounding
-                        const size_t ro = (size_t)(start_pos + (rok ? r : rows - 1)) * ms.resid_pitch;
-                        const uint16_t* rr16 = (const uint16_t*)(ms.resid + ro);
-                        uint16_t* so16 = (uint16_t*)(ms.sum_out + ro);
-                        if (ok0) so16[c0] = f2h(h2f(rr16[c0]) + h2f(h0));
-                        if (ok1) so16[c1] = f2h(h2f(rr16[c1]) + h2f(h1));
-                    }
-                } else {
-                    if (ok0) ((float*)orow)[c0] = v0;
-                    if (ok1) ((float*)orow)[c1] = v1;
-                }
-            }
-        }
-    }
+    mfma_epilogue<WM, WN>(acc, ms, mi, out, out_pitch, d_out, out_dtype, rows, row0 + wr * 16 * WM, col0, g, l16, start_pos);
 }
 
 // The planes of a shared K loop -> rows: per element the planes are added in order (((p0 + p1) + p2) + p3), then the row
@@ -812,6 +878,7 @@ static int partial_scratch(size_t bytes, float** out)
 // 5.09 ms with these factors (twice the factors: 3.79 ms at 256 ids; sharing the wide gate | up loops too: no gain)
 static int splitk_factor(int rows, int d_in, int d_out)
 {
+    // (2048 rows, round 3: factors 2 / 2, 2 / 4, 1 / 2, 1 / 4 for K = 2048 / 5632 -- 6.92 / 7.08 / 6.55 / 6.68 ms of W.x against 6.67)
     if (rows > 512 || d_out > 2560 || d_out % 32 != 0) return 1;
     return (d_in >= 4096 ? 4 : 2) * (rows <= 128 ? 2 : 1);
 }
@@ -843,14 +910,17 @@ static int converted_rows(int rows, int d_in, uint8_t** buf_out, float** da_out)
     return act_scratch((size_t)rows * d_in * 2, (size_t)rows * (d_in / 32) * 4, buf_out, da_out);
 }
 
+// the launch of one tile configuration
 template <int WT, int WM, int WN, bool FAST, int KB_ = 4>
 static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int out_dtype, int n, int d_in, int start_pos, bool converted)
 {
     using namespace gtr;
     using C = MfmaCfg<WT, WM, WN, KB_>;
+    constexpr int TBM = C::BM, TBN = C::BN, TNT = 256;
+    const size_t smem = (FAST || !C::QUANT) ? C::smem_fast() : C::smem();
     static bool attr_set = false;
     if (!attr_set) {
-        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((FAST || !C::QUANT) ? C::smem_fast() : C::smem())));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_matmul_mfma<WT, WM, WN, KB_, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int rows = n - start_pos;
@@ -866,7 +936,7 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
     int tiles = 0;
     for (int k = 0; k < m.n; k++) {
         ms.w[k] = m.w[k]; ms.out[k] = (uint8_t*)m.out[k]; ms.out_pitch[k] = m.out_pitch[k]; ms.d_out[k] = m.d_out[k]; ms.tile0[k] = tiles;
-        tiles += (m.d_out[k] + C::BN - 1) / C::BN;
+        tiles += (m.d_out[k] + TBN - 1) / TBN;
     }
     ms.n_mats = m.n;
     ms.resid = (const uint8_t*)m.resid; ms.sum_out = (uint8_t*)m.sum_out; ms.resid_pitch = m.resid_pitch;
@@ -883,14 +953,14 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
         GTR_REQUIRE(ks != 0, "matmul: matrices of one launch disagree about sharing the K loop");
         if ((d_in / 32 / C::KB) < 2 * ks) ks = 1;
     }
-    const dim3 grid(tiles, (rows + C::BM - 1) / C::BM, ks), block(256);
+    const dim3 grid(tiles, (rows + TBM - 1) / TBM, ks), block(TNT);
     if (ks > 1) {
         int cols = 0;
         for (int k = 0; k < m.n; k++) { ms.part_col0[k] = cols; cols += (m.d_out[k] + 31) & ~31; }
         float* planes = nullptr;
         if (int rc = partial_scratch((size_t)ks * rows * cols * 4, &planes)) return rc;
         ms.partial = planes; ms.part_pitch = cols;
-        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, (FAST || !C::QUANT) ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+        GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, smem, a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
         const auto al4 = [](const void* q, size_t pitch) { return ((uintptr_t)q & 3) == 0 && pitch % 4 == 0; };
         if (m.norm_w && m.n == 1 && m.resid && m.d_out[0] == 2048 && al4(m.out[0], m.out_pitch[0]) && al4(m.resid, m.resid_pitch) &&
             al4(m.sum_out, m.resid_pitch) && al4(m.norm_out, m.norm_out_pitch) && ((uintptr_t)m.norm_w & 15) == 0) {
@@ -903,7 +973,7 @@ static int launch_cfg(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int
         GTR_LAUNCH(KT_MATMUL_MFMA, k_splitk_finish, dim3((blocks + 7) / 8), dim3(256), 0, ms, ks, rows, start_pos);
         return 0;
     }
-    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, (FAST || !C::QUANT) ? C::smem_fast() : C::smem(), a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
+    GTR_LAUNCH(KT_MATMUL_MFMA, (k_matmul_mfma<WT, WM, WN, KB_, FAST>), grid, block, smem, a16, a_pitch, (const float*)da, ms, out_dtype, n, d_in, start_pos);
     return 0;
 }
 
@@ -933,6 +1003,14 @@ static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int 
         // (round 3, measured and not kept: 128 x 128 tiles for EVERY projection from 128 rows up, their K loops shared by 2-8
         //  workgroups until 200 / 400 / 800 workgroups are in flight: 128 rows 1.79 -> 2.25 / 2.37 / 2.36 ms of W.x, 256: 2.27 -> 2.71 /
         //  2.84 / 3.17, 512: 3.26 -> 3.22 / 3.63 / 3.85, 1024: 4.42 -> 4.63 / 4.73 / 6.03 -- the 64 x 64 tiles with their factors stay)
+        // (round 3, measured and not kept: a kernel with EVERY global byte moved by LDS-DMA (`buffer_load ... lds` as inline
+        //  assembly with hand-counted s_waitcnt vmcnt, three-slot rings for the activation tile and the packed weights, the
+        //  weight tile expanded LDS -> registers -> LDS, one barrier per stage), 256 x 128 outputs on eight waves: the same
+        //  bits, gate | up 138.6 us against 140.4 at 2048 rows, but the 2048-wide projections 98 us against 75 (128 tiles on
+        //  256 CUs), W.x 8.6 ms against 7.6 -- and still 7.4 against 6.6 once both had the lean epilogue.  With parts of its
+        //  loop knocked out (W.x ms, base 8.60): no MFMA 8.42, no fragment reads 7.71, no weight expansion 7.04, no DMA 7.03,
+        //  no barrier 8.08, no epilogue 5.9 -- the matrix pipe is the smallest term; what the kernels wait for adds up from
+        //  VALU issue (the epilogue), the LDS store path and exposed latencies at 2 waves per SIMD: DESIGN.md 3.3.)
         if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
     }
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
