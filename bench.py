@@ -78,7 +78,11 @@ def parse_args(argv=None):
                          "reported separately, `value` stays the single-sequence rate")
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--generate", type=int, default=256, help="also time real greedy generation of this many ids ending at the context limit (0 = skip)")
-    ap.add_argument("--serve", type=int, default=256, help="also serve a queue of this many synthetic prompts through the wide batch's slots (0 = skip)")
+    ap.add_argument("--serve", type=int, default=1024, help="also serve a queue of this many synthetic prompts through the serving slots (0 = skip)")
+    ap.add_argument("--serve-slots", type=int, default=128, choices=[0, 16, 32, 48, 64, 128, 192, 256],
+                    help="slots of the serving leg (0: --wide-streams); measured, 1024 prompts: 64 slots 25.6k new ids/s, 128 30.0k, 256 22.5k "
+                         "(four lanes leave the prompt stream too little of the chip)")
+    ap.add_argument("--serve-slice", type=int, default=8, help="shared steps per slice of the serving leg")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
                     help="how the (untimed) context below the timed window is produced: single-token decode steps "
@@ -281,7 +285,7 @@ def serving_queue(n_prompts, make_tokens, seed=2024):
     return [list(make_tokens(int(n), j)) for j, n in enumerate(lens)], budgets
 
 
-def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist, device, sync):
+def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist, device, sync, slice_steps=8):
     """north_star's multi-GPU split: per-prompt sharding, no collective on the data path.  Rank r serves prompts
     r, r + world, ... (replicas.shard_prompts) of ONE global queue through its own slots; the only cross-rank traffic is
     the bookkeeping -- the barrier-bracketed timed region (MAX elapsed over ranks, new ids summed) and one all-reduce of
@@ -291,11 +295,11 @@ def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist,
     prompts, budgets = serving_queue(n_global, make_tokens)
     mine = rep.shard_prompts(n_global, rank, world)
     my_prompts, my_budgets = [prompts[j] for j in mine], budgets[mine]
-    batch.serve(my_prompts[:slots], N_CTX, -1, 16, max_new=4)        # warm-up: graphs, first-use allocations
+    batch.serve(my_prompts[:slots], N_CTX, -1, slice_steps, max_new=4)        # warm-up: graphs, first-use allocations
     box = {}
 
     def run():
-        box["got"], box["st"] = batch.serve(my_prompts, N_CTX, -1, 16, max_new_each=my_budgets)
+        box["got"], box["st"] = batch.serve(my_prompts, N_CTX, -1, slice_steps, max_new_each=my_budgets)
         return int(box["st"]["new_tokens"])
 
     elapsed, new_total, per_rank = rep.timed_region(run, sync, dist=dist, device=device, per_rank=True)
@@ -320,9 +324,9 @@ def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist,
             "every_prompt_served_exactly_once": bool((served == 1).all()),
             "note": "ONE global queue (prompts of 64..512 ids, 32..224 new ids each; %d per GPU: weak scaling) sharded round-robin "
                     "over the replicas, each rank its shard through its own %d slots (continuous batching, prompts on the library's "
-                    "second stream beside slices of 16 shared steps); new_tok_s = new ids of all ranks / the slowest rank's wall "
+                    "second stream beside slices of %d shared steps); new_tok_s = new ids of all ranks / the slowest rank's wall "
                     "time; no collective on the data path (the served-counter all-reduce and the timing all-gather are bookkeeping)"
-                    % (n_global // world, slots)}
+                    % (n_global // world, slots, slice_steps)}
 
 
 class Leg:
@@ -536,8 +540,8 @@ def worker(args, rank, local_rank, world, dist):
     # N > 1: one global prompt queue sharded over the replicas (north_star's per-prompt split), every rank its shard
     # through its own continuous-batching slots -- the aggregate serving rate beside the batch-1 rate of `value`
     sharded = None
-    if dist is not None and world > 1 and fused and args.serve > 0 and args.wide_streams > 1 and not args.brief:
-        S = args.wide_streams
+    if dist is not None and world > 1 and fused and args.serve > 0 and (args.serve_slots or args.wide_streams) > 1 and not args.brief:
+        S = args.serve_slots or args.wide_streams
         if stub:
             sbatch = StubBatch()
             make_tokens = lambda n, j: np.random.default_rng(rep_seed(999, j)).integers(3, 31993, n).astype(np.int32)
@@ -545,7 +549,7 @@ def worker(args, rank, local_rank, world, dist):
             sbatch = host.batch(cfg, S)
             sbatch.load_synthetic(args.seed)
             make_tokens = lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j))
-        sharded = sharded_serving(sbatch, S, args.serve * world, make_tokens, rep, rank, world, dist, ddev, sync)
+        sharded = sharded_serving(sbatch, S, args.serve * world, make_tokens, rep, rank, world, dist, ddev, sync, args.serve_slice)
         sbatch.close()
     # the replicas are done with each other: every rank leaves the process group here (rank 0 goes on alone with the
     # roofline / CPU-baseline legs, the others exit and free their host cores)
@@ -773,29 +777,31 @@ def worker(args, rank, local_rank, world, dist):
                                        "note": "greedy ids generated up to n = %d for every sequence; tok/s = new ids / (wall time - "
                                                "n_seq x one prompt's processing time)" % N_CTX}
             batch.close()
-    # secondary: continuous batching -- a queue of 256 synthetic prompts (64..512 ids each, up to 128 new ids per prompt)
-    # through 64 slots sharing every weight pass; a slot that ends takes the next prompt while the others go on
-    if secondary and fused and args.serve > 0 and args.wide_streams > 1:
+    # secondary: continuous batching -- a queue of synthetic prompts (64..512 ids each, 32..224 new ids per prompt)
+    # through the serving slots sharing every weight pass; a slot that ends takes the next prompt while the others go on
+    if secondary and fused and args.serve > 0 and (args.serve_slots or args.wide_streams) > 1:
       with Leg(out, "serving"):
-            S = args.wide_streams
+            S = args.serve_slots or args.wide_streams
             batch = host.batch(cfg, S)
             batch.load_synthetic(args.seed)
             prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
-            batch.serve(prompts[:S], N_CTX, -1, 16, max_new=4)           # warm-up: graphs, first-use allocations
+            batch.serve(prompts[:S], N_CTX, -1, args.serve_slice, max_new=4)           # warm-up: graphs, first-use allocations
             t0 = time.perf_counter()
-            got, st = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
+            got, st = batch.serve(prompts, N_CTX, -1, args.serve_slice, max_new_each=budgets)
             dt = time.perf_counter() - t0
             out["serving"] = {"slots": S, "prompts": int(args.serve), "prompt_tokens": int(st["prompt_tokens"]), "new_tokens": int(st["new_tokens"]),
                               "wall_s": round(dt, 3), "new_tok_s": round(st["new_tokens"] / dt, 1),
                               "all_tok_s": round((st["new_tokens"] + st["prompt_tokens"]) / dt, 1),
                               "shared_steps": int(st["steps"]), "prefill_s": round(st["prefill_s"], 3), "decode_s": round(st["decode_s"], 3),
                               "slot_utilisation": round(st["new_tokens"] / max(st["steps"] * S, 1), 3),
-                              "note": "sustained rates over the whole queue (256 prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
-                                      "the library's second stream BESIDE the slices of 16 shared steps (prefill_s = host time spent in it, "
-                                      "overlapped); slot_utilisation = new ids / (shared steps x slots)"}
+                              "slice_steps": args.serve_slice,
+                              "note": "sustained rates over the whole queue (prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
+                                      "the library's second stream BESIDE the slices of shared steps (prefill_s = host time spent in it, "
+                                      "overlapped); a slot whose run ends inside a slice repeats its last step until the slice is over; "
+                                      "slot_utilisation = new ids / (shared steps x slots)"}
             try:
                 # the same queue once more, untimed: the ids must not depend on which prompt overlapped which slice
-                got2, _ = batch.serve(prompts, N_CTX, -1, 16, max_new_each=budgets)
+                got2, _ = batch.serve(prompts, N_CTX, -1, args.serve_slice, max_new_each=budgets)
                 out["serving"]["same_ids_second_run"] = bool(len(got2) == len(got) and all(np.array_equal(a, b) for a, b in zip(got, got2)))
             except Exception as e:                                       # a reporting extra: never costs the line
                 out["serving"]["same_ids_second_run"] = "not checked: %s" % type(e).__name__

@@ -264,13 +264,17 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, c
  *   slot_start: sequence `seq` generates from step n_first on -- its ids [0, n_first) must be set
  *               (gten_hip_decoder_set_tokens_seq) and its caches hold rows [0, n_first - 1) (operator-path prefill);
  *               each step's argmax becomes its next input token on the device;
+ *   slot_start_until: ... and the slot's LAST step is n_last (0: no bound, as slot_start): once it has run, further
+ *               shared steps repeat it (the same row, the same bytes into the same places) instead of moving on, so a run
+ *               of `steps` need not be cut to the shortest remaining sequence -- the caller reads the ids up to n_last;
  *   slot_park:  the slot stops advancing (its row is still computed by the shared launches; the results are ignored);
- *   run:        `steps` back-to-back graph replays of the whole batch, asynchronous; no live slot may pass max_ctx
- *               (returns an error instead of launching);
+ *   run:        `steps` back-to-back graph replays of the whole batch, asynchronous; no live slot without a last step
+ *               may pass max_ctx (returns an error instead of launching);
  *   slot_ids:   waits for the stream and copies the argmax ids of steps [n_from, n_from + count) of `seq`.
  * The scheduler that drives these (prompt queue, eos, admission) is host code: TinyLlamaBatch::serve,
  * tinyllama.cpp_amd/host/tinyllama_model.h. */
 int gten_hip_decoder_slot_start(gten_hip_decoder* dec, int seq, int n_first);
+int gten_hip_decoder_slot_start_until(gten_hip_decoder* dec, int seq, int n_first, int n_last);
 int gten_hip_decoder_slot_park(gten_hip_decoder* dec, int seq);
 int gten_hip_decoder_run(gten_hip_decoder* dec, int steps);
 int gten_hip_decoder_slot_ids(gten_hip_decoder* dec, int seq, int n_from, int count, int32_t* ids_host);

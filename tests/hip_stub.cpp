@@ -37,7 +37,7 @@ int fail(const char* fmt, ...)
 
 int next_id(int32_t tok, int n, int n_vocab) { return (int)(((long long)tok * 7 + (long long)n * 13 + 1) % n_vocab); }
 
-struct Slot { int n = 1; int advance = 0; };
+struct Slot { int n = 1; int advance = 0; int stop = 0; };
 
 }  // namespace
 
@@ -288,14 +288,21 @@ int gten_hip_decoder_slot_start(gten_hip_decoder* dc, int seq, int n_first)
     if (!dc || seq < 0 || seq >= dc->n_seq) return fail("slot_start: sequence %d", seq);
     if (n_first < 1 || n_first > dc->d.max_ctx) return fail("slot_start: n_first=%d", n_first);
     slots_view(dc);
-    dc->slots[(size_t)seq] = Slot{n_first, 3};
+    dc->slots[(size_t)seq] = Slot{n_first, 3, 0};
+    return 0;
+}
+int gten_hip_decoder_slot_start_until(gten_hip_decoder* dc, int seq, int n_first, int n_last)
+{
+    if (int rc = gten_hip_decoder_slot_start(dc, seq, n_first)) return rc;
+    if (n_last != 0 && (n_last < n_first || n_last > dc->d.max_ctx)) return fail("slot_start_until: n_last=%d", n_last);
+    dc->slots[(size_t)seq].stop = n_last;
     return 0;
 }
 int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
 {
     if (!dc || seq < 0 || seq >= dc->n_seq) return fail("slot_park: sequence %d", seq);
     slots_view(dc);
-    dc->slots[(size_t)seq] = Slot{1, 0};
+    dc->slots[(size_t)seq] = Slot{1, 0, 0};
     return 0;
 }
 int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
@@ -303,11 +310,14 @@ int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
     if (!dc || steps < 0) return fail("decoder_run: arguments");
     slots_view(dc);
     for (const Slot& s : dc->slots)
-        if ((s.advance & 1) && s.n + steps - 1 > dc->d.max_ctx) return fail("decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n, dc->d.max_ctx);
+        if ((s.advance & 1) && s.stop <= 0 && s.n + steps - 1 > dc->d.max_ctx) return fail("decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n, dc->d.max_ctx);
     for (int q = 0; q < dc->n_seq; q++) {
         Slot& s = dc->slots[(size_t)q];
         if (!(s.advance & 1)) continue;
-        for (int i = 0; i < steps; i++) one_step(dc, q, s.n++);
+        for (int i = 0; i < steps; i++) {
+            one_step(dc, q, s.n);
+            if (s.stop <= 0 || s.n < s.stop) s.n++;               // (the last step is repeated, not passed)
+        }
     }
     return 0;
 }

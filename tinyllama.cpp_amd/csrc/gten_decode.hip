@@ -53,6 +53,8 @@ struct DecStep {
     int n;                        // context length of this step; the new row is n-1
     int advance;                  // bit 0: the argmax kernel bumps n afterwards (free-running replay);
                                   // bit 1: ... and stores its argmax as the NEXT input token (greedy generation without the host)
+    int stop;                     // > 0: n is not bumped past it -- a slot whose run ends inside a slice of shared steps repeats
+                                  // its last step (the same row, the same bytes) instead of cutting the slice short for everybody
 };
 
 // ---------------------------------------------------------------- LDS stage
@@ -3249,7 +3251,8 @@ __global__ __launch_bounds__(1024) void k_dec_argmax(const float* __restrict__ v
         result[n] = idx;                       // argmax of the step that computed row n-1
         const int adv = step->advance;
         if (adv & 2) tokens0[(size_t)blockIdx.x * tok_stride + n] = idx;   // greedy generation: the next step embeds it (tinyllama.cpp:426)
-        if (adv & 1) step->n = n + 1;          // free-running replay: the next launch decodes row n
+        const int stop = step->stop;
+        if ((adv & 1) && (stop <= 0 || n < stop)) step->n = n + 1;          // free-running replay: the next launch decodes row n
     }
 }
 
@@ -4567,12 +4570,18 @@ static int slots_leave(gten_hip_decoder* dc)
 
 int gten_hip_decoder_slot_start(gten_hip_decoder* dc, int seq, int n_first)
 {
+    return gten_hip_decoder_slot_start_until(dc, seq, n_first, 0);
+}
+
+int gten_hip_decoder_slot_start_until(gten_hip_decoder* dc, int seq, int n_first, int n_last)
+{
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && seq >= 0 && seq < dc->n_seq, "decoder_slot_start: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
     GTR_REQUIRE(n_first >= 1 && n_first <= dc->d.max_ctx, "decoder_slot_start: n_first=%d outside [1, %d]", n_first, dc->d.max_ctx);
+    GTR_REQUIRE(n_last == 0 || (n_last >= n_first && n_last <= dc->d.max_ctx), "decoder_slot_start: n_last=%d outside [%d, %d]", n_last, n_first, dc->d.max_ctx);
     if (int rc = slots_view(dc)) return rc;
     if (int rc = slot_caches(dc, seq, false)) return rc;
-    dc->slots[(size_t)seq] = DecStep{n_first, 3};
+    dc->slots[(size_t)seq] = DecStep{n_first, 3, n_last};
     GTR_CHECK(hipMemcpyAsync(dc->step + seq, &dc->slots[(size_t)seq], sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     return 0;
@@ -4587,6 +4596,7 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
     DecStep& s = dc->slots[(size_t)seq];
     s.n = 1;
     s.advance = 0;
+    s.stop = 0;
     GTR_CHECK(hipMemcpyAsync(dc->step + seq, &s, sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     return 0;
@@ -4599,10 +4609,11 @@ int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
     GTR_REQUIRE(!prof_on(), "decoder_run: switch the per-launch profiler off first");
     if (int rc = slots_view(dc)) return rc;
     for (const DecStep& s : dc->slots)
-        GTR_REQUIRE(!(s.advance & 1) || s.n + steps - 1 <= dc->d.max_ctx, "decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n, dc->d.max_ctx);
+        GTR_REQUIRE(!(s.advance & 1) || s.stop > 0 || s.n + steps - 1 <= dc->d.max_ctx, "decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n,
+                    dc->d.max_ctx);
     if (int rc = run_steps_free(dc, steps)) return rc;
     for (DecStep& s : dc->slots)
-        if (s.advance & 1) s.n += steps;          // (a slot that reaches max_ctx + 1 has to be parked or restarted before the next run)
+        if (s.advance & 1) s.n = s.stop > 0 ? std::min(s.n + steps, s.stop) : s.n + steps;   // (a slot that reaches max_ctx + 1 has to be parked or restarted before the next run)
     return 0;
 }
 

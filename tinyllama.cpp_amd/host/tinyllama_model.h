@@ -518,7 +518,9 @@ public:
     //     they hide each other.
     // Between two prompts the slice is polled (gten_hip_stream_idle): once done its ids are read (eos / length -> the slot is
     // parked and becomes free) and the next slice starts at once with the slots whose prompts became ready meanwhile.  Nobody
-    // runs past its last step (the slice is cut to the shortest remaining run).  Per sequence the ids are those of
+    // runs past its last step: a slot that ends inside a slice repeats that step until the slice is over
+    // (gten_hip_decoder_slot_start_until; cutting the slice to the shortest remaining run instead left 128 slots with
+    // slices of one to three steps and prompt batches of two).  Per sequence the ids are those of
     // generating it alone (bit for bit up to 8 slots; tests/test_serving_gpu.py).
     struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0; double prefill_s = 0.0, decode_s = 0.0; };
     // (max_new_each, when given, bounds the new ids of prompt j by max_new_each[j] instead of max_new)
@@ -626,13 +628,16 @@ public:
                 if (job[(size_t)q] >= 0 && !live[(size_t)q]) {
                     const std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
                     GTEN_HIP_OK(gten_hip_decoder_set_tokens_seq(dec_, q, row.data(), 0, (int)row.size()));
-                    GTEN_HIP_OK(gten_hip_decoder_slot_start(dec_, q, cur[(size_t)q]));
+                    GTEN_HIP_OK(gten_hip_decoder_slot_start_until(dec_, q, cur[(size_t)q], last[(size_t)q]));
                     live[(size_t)q] = 1; n_live++; n_ready--;
                 }
             if (n_live == 0) return;
-            cnt = std::max(slice, 1);
+            // (a slot whose run ends inside the slice repeats its last step until the slice is over, slot_start_until: the slice
+            //  is cut only when EVERY live slot ends earlier)
+            int longest = 0;
             for (int q = 0; q < S; q++)
-                if (live[(size_t)q]) cnt = std::min(cnt, last[(size_t)q] - cur[(size_t)q] + 1);   // nobody runs past its last step
+                if (live[(size_t)q]) longest = std::max(longest, last[(size_t)q] - cur[(size_t)q] + 1);
+            cnt = std::min(std::max(slice, 1), longest);
             t_slice = clock::now();
             GTEN_HIP_OK(gten_hip_decoder_run(dec_, cnt));
             st.steps += cnt;
@@ -641,14 +646,15 @@ public:
         auto harvest = [&]() {
             for (int q = 0; q < S; q++) {
                 if (!live[(size_t)q]) continue;
-                GTEN_HIP_OK(gten_hip_decoder_slot_ids(dec_, q, cur[(size_t)q], cnt, ids.data()));   // (waits for stream 0)
+                const int got = std::min(cnt, last[(size_t)q] - cur[(size_t)q] + 1);                  // (its steps of this slice)
+                GTEN_HIP_OK(gten_hip_decoder_slot_ids(dec_, q, cur[(size_t)q], got, ids.data()));   // (waits for stream 0)
                 std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
                 bool stop = false;
-                for (int i = 0; i < cnt && !stop; i++) {
+                for (int i = 0; i < got && !stop; i++) {
                     if (ids[(size_t)i] == eos) stop = true;
                     else { row.push_back(ids[(size_t)i]); st.new_tokens++; }
                 }
-                cur[(size_t)q] += cnt;
+                cur[(size_t)q] += got;
                 if (stop || cur[(size_t)q] > last[(size_t)q]) {
                     GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
                     job[(size_t)q] = -1; live[(size_t)q] = 0; n_live--;
