@@ -805,6 +805,17 @@ def worker(args, rank, local_rank, world, dist):
                 out["serving"]["same_ids_second_run"] = bool(len(got2) == len(got) and all(np.array_equal(a, b) for a, b in zip(got, got2)))
             except Exception as e:                                       # a reporting extra: never costs the line
                 out["serving"]["same_ids_second_run"] = "not checked: %s" % type(e).__name__
+            try:
+                # the first 256 prompts alone (round 2's queue): two rounds of 128 slots, so the tail weighs more
+                if args.serve > 256:
+                    t0 = time.perf_counter()
+                    _, st2 = batch.serve(prompts[:256], N_CTX, -1, args.serve_slice, max_new_each=budgets[:256])
+                    dt2 = time.perf_counter() - t0
+                    out["serving"]["first_256_prompts"] = {"new_tok_s": round(st2["new_tokens"] / dt2, 1), "wall_s": round(dt2, 3),
+                                                           "shared_steps": int(st2["steps"]),
+                                                           "slot_utilisation": round(st2["new_tokens"] / max(st2["steps"] * S, 1), 3)}
+            except Exception as e:
+                out["serving"]["first_256_prompts"] = "not measured: %s" % type(e).__name__
             batch.close()
     # secondary: prompt processing on the matrix cores (not part of `value`)
     if secondary and args.prefill > 0:

@@ -879,7 +879,10 @@ static int partial_scratch(size_t bytes, float** out)
 static int splitk_factor(int rows, int d_in, int d_out)
 {
     // (2048 rows, round 3: factors 2 / 2, 2 / 4, 1 / 2, 1 / 4 for K = 2048 / 5632 -- 6.92 / 7.08 / 6.55 / 6.68 ms of W.x against 6.67)
-    if (rows > 512 || d_out > 2560 || d_out % 32 != 0) return 1;
+    // (with the lean epilogue the unshared loops won back what the plane sums cost: sharing up to 512 / 256 / 128 / 0 rows -- W.x of a
+    //  384-id prompt 2.75 / 2.55 / 2.57 / 2.59 ms, 512 ids 3.08 / 2.76 / 2.75 / 2.75, 256 ids 2.20 / 2.21 / 2.27 / 2.30, 128 ids 1.76 / 1.75 /
+    //  1.74 / 2.03: shared up to 256 rows)
+    if (rows > 256 || d_out > 2560 || d_out % 32 != 0) return 1;
     return (d_in >= 4096 ? 4 : 2) * (rows <= 128 ? 2 : 1);
 }
 
@@ -1011,6 +1014,8 @@ static int launch_wt(const void* x, size_t x_pitch, const gtr::MfmaMats& m, int 
         //  loop knocked out (W.x ms, base 8.60): no MFMA 8.42, no fragment reads 7.71, no weight expansion 7.04, no DMA 7.03,
         //  no barrier 8.08, no epilogue 5.9 -- the matrix pipe is the smallest term; what the kernels wait for adds up from
         //  VALU issue (the epilogue), the LDS store path and exposed latencies at 2 waves per SIMD: DESIGN.md 3.3.)
+        // (64 x 128 tiles only for the launches with fewer than 300 / 512 / 1024 of the 128 x 128 tiles: W.x 6.40 / 6.42 / 6.43 ms at 2048 rows
+        //  against 6.44, 3.91 / 3.91 / 4.22 at 1024 rows against 3.91 -- the tile shape is not what this kernel waits for)
         if (rows > 64 && wgs(128, 128) >= 256) return launch_cfg<WT, 4, 4, FAST, 2>(x, x_pitch, m, out_dtype, n, d_in, start_pos, converted);
     }
     if (rows > 32 && wgs(64, 128) >= 384) MF_GO(2, 4);
