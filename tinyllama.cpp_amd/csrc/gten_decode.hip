@@ -344,6 +344,8 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     constexpr int LPB = 32 / EPT;                 // lanes per Q8 block
     constexpr int NW = NT / 64;
     static_assert(NT == 256 || NT == 512, "256 or 512 threads");
+    // (round 3, built and measured: the FFN slice launch on 1024 threads -- sixteen waves of four rows, the prologue on the
+    //  first 512 threads, the same bits -- 6.23 against 5.86 us per launch: not kept)
     static_assert(EPI != EPI_SILUMUL || NT == 512, "the FFN slice epilogue wants 8 waves");
     constexpr bool F16W = (WT == GTEN_F16);        // f16 weights <=> f16 activations (tinyllama.cpp:258-265)
     const int d = hot.d_in, nb = d >> 5;
@@ -3619,8 +3621,11 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         o.step = dc->step; o.d_in = E; o.n_mats = 1; set_mat(o, 0, L.wo, WT, E, E); o.out = dc->proj_raw;
         o.att_part = dc->att_part; o.d_head = dh; o.d_head_shift = __builtin_ctz(dh); o.n_chunks = dc->n_chunks;
         o.att_stats = dc->stats;
-        rc = attention_one_pass(dh) ? launch_gemv8<WT, PRO_ATTW, NE, 2, 512, 1>(KT_DEC_GEMV_O, o, E)
-                                    : launch_gemv8<WT, PRO_ATT, NE, 2, 512, 1>(KT_DEC_GEMV_O, o, E);
+        // rows per wave and threads per workgroup, measured (q4, step ms; 0.4976 with 2 rows on 512 threads everywhere but down's
+        // 256): q|k|v 1 row 0.510, on 256 threads 0.500; o 1 row 0.4845 (3.90 against 4.22 us per launch: every CU gets a workgroup),
+        // 4 rows 0.512, 1 row on 256 threads 0.504, 2 rows on 256 threads 0.489; down 1 row 0.494, 1 row on 512 threads 0.496
+        rc = attention_one_pass(dh) ? launch_gemv8<WT, PRO_ATTW, NE, 1, 512, 1>(KT_DEC_GEMV_O, o, E)
+                                    : launch_gemv8<WT, PRO_ATT, NE, 1, 512, 1>(KT_DEC_GEMV_O, o, E);
         if (rc) return rc;
         Gemv8Args gu{};
         gu.step = dc->step; gu.d_in = E; gu.n_mats = 2; set_mat(gu, 0, L.wgate, WT, F, E); set_mat(gu, 1, L.wup, WT, F, E);
