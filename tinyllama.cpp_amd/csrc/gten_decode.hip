@@ -3623,7 +3623,8 @@ static int enqueue_step_q8act(gten_hip_decoder* dc)
         o.att_stats = dc->stats;
         // rows per wave and threads per workgroup, measured (q4, step ms; 0.4976 with 2 rows on 512 threads everywhere but down's
         // 256): q|k|v 1 row 0.510, on 256 threads 0.500; o 1 row 0.4845 (3.90 against 4.22 us per launch: every CU gets a workgroup),
-        // 4 rows 0.512, 1 row on 256 threads 0.504, 2 rows on 256 threads 0.489; down 1 row 0.494, 1 row on 512 threads 0.496
+        // 4 rows 0.512, 1 row on 256 threads 0.504, 2 rows on 256 threads 0.489; down 1 row 0.494, 1 row on 512 threads 0.496;
+        // lm_head 4 / 8 / 16 rows per wave 0.486 / 0.488 / 0.487 (then, with o at 1 row)
         rc = attention_one_pass(dh) ? launch_gemv8<WT, PRO_ATTW, NE, 1, 512, 1>(KT_DEC_GEMV_O, o, E)
                                     : launch_gemv8<WT, PRO_ATT, NE, 1, 512, 1>(KT_DEC_GEMV_O, o, E);
         if (rc) return rc;
