@@ -140,7 +140,7 @@ def measured_traffic(mode, family):
     return v, (t.get("source") if v is not None else "no counters for %s / %s in profiles/traffic.json" % (mode, family))
 
 
-def dropin_leg(host, cfg, args, toks):
+def dropin_leg(host, cfg, args, toks, hip=None):
     """greedy generation to n = 2048 through oracle/_ref/libdropin.so = the reference's translation unit on this
     repository's gten API (what a user of the reference gets by swapping the gten/ directory)"""
     from oracle import orc
@@ -155,11 +155,16 @@ def dropin_leg(host, cfg, args, toks):
     G = min(args.generate, N_CTX - 16)
     P0 = N_CTX - G
     res = {}
-    for name, fused_rows in (("fused_rows", True), ("operators", False)):
+    for name, fused_rows in (("fused_rows", True), ("operators", False), ("fused_rows_exact", True)):
+        exact = name.endswith("_exact")
+        if exact and hip is None:
+            continue
         lib.set_fused_rows(fused_rows)
+        if exact:
+            hip.set_decode_exact(True)                         # (read when the model's decoder is made: two-launch attention, whole-row statistics)
         m = lib.tinyllama(N_CTX, wd, ad)
         m.load(path)
-        new = G if fused_rows else min(G, 32)                 # the operator-by-operator loop is ~15x slower: a short sample
+        new = G if (fused_rows and not exact) else min(G, 32)  # the operator-by-operator loop is ~15x slower: a short sample
         m.logits(toks[:P0], 0)                                 # warm-up: first-use allocations, weight repack
         m.logits(toks[:P0 + 1], P0)                            # ... and the decoder / its graph
         t0 = time.perf_counter(); m.logits(toks[:P0], 0); t_pre = time.perf_counter() - t0
@@ -169,9 +174,15 @@ def dropin_leg(host, cfg, args, toks):
         res[name] = {"new_tokens": int(len(ids) - P0), "tok_s": round((len(ids) - P0) / max(dt - t_pre, 1e-9), 1),
                      "prefill_ms": round(t_pre * 1e3, 2), "wall_ms": round(dt * 1e3, 2), "ids_head": [int(x) for x in ids[P0:P0 + 8]]}
         m.close()
+        if exact:
+            hip.set_decode_exact(False)
     lib.set_fused_rows(True)
     a, b = res["fused_rows"]["ids_head"], res["operators"]["ids_head"]
-    return {"prompt_tokens": P0, "tok_s": res["fused_rows"]["tok_s"], **res,
+    extra = {}
+    if "fused_rows_exact" in res:
+        c = res["fused_rows_exact"]["ids_head"]
+        extra["first_ids_agree_exact"] = next((i for i in range(8) if c[i] != b[i]), 8)
+    return {"prompt_tokens": P0, "tok_s": res["fused_rows"]["tok_s"], **res, **extra,
             "first_ids_agree": next((i for i in range(8) if a[i] != b[i]), 8),
             "note": "reference's unmodified TinyLlama::logits + host argmax per token on this repository's gten/ headers "
                     "(libdropin.so); ids generated up to n = %d; tok/s = new ids / (wall - prompt processing); first_ids_agree = how many of "
@@ -869,7 +880,7 @@ def worker(args, rank, local_rank, world, dist):
     # single-row module calls and runs them as one fused decoder step.
     if secondary and fused and args.generate > 0 and args.mode == "q4":
         try:
-            out["dropin"] = dropin_leg(host, cfg, args, toks)
+            out["dropin"] = dropin_leg(host, cfg, args, toks, hip)
         except Exception as e:
             out["dropin"] = {"tok_s": None, "note": "drop-in leg unavailable: %r" % (e,)}
     # the CPU path beside it: once per run, on rank 0, after the other ranks have exited
