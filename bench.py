@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--wide-streams", type=int, default=64, choices=[0, 16, 32, 48, 64, 128, 192, 256],
+    ap.add_argument("--wide-streams", type=int, default=64, choices=[0, 16, 32, 48, 64, 128, 192, 256, 384, 512],
                     help="also report the aggregate rate of this many sequences on the matrix-core decode path (0: skip)")
     ap.add_argument("--streams", type=int, default=8, choices=[0, 2, 4, 8, 16, 32, 48, 64],
                     help="also measure this many sequences sharing each weight pass on the GPU (0 = skip); "
@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--generate", type=int, default=256, help="also time real greedy generation of this many ids ending at the context limit (0 = skip)")
     ap.add_argument("--serve", type=int, default=1024, help="also serve a queue of this many synthetic prompts through the serving slots (0 = skip)")
-    ap.add_argument("--serve-slots", type=int, default=128, choices=[0, 16, 32, 48, 64, 128, 192, 256],
+    ap.add_argument("--serve-slots", type=int, default=128, choices=[0, 16, 32, 48, 64, 128, 192, 256, 384, 512],
                     help="slots of the serving leg (0: --wide-streams); measured, 1024 prompts: 64 slots 25.6k new ids/s, 128 30.0k, 256 22.5k "
                          "(four lanes leave the prompt stream too little of the chip)")
     ap.add_argument("--serve-slice", type=int, default=8, help="shared steps per slice of the serving leg")
@@ -757,9 +757,10 @@ def worker(args, rank, local_rank, world, dist):
             # round 3: 256 sequences in ONE decoder -- four lanes of 64, each lane's launch chain a parallel branch of the
             # step's graph (round 2 measured the effect with two separate decoders on two streams: multi_stream_wide_x2)
             try:
-                out["multi_stream_lanes"] = multi_stream(256, "one decoder, four lanes of 64 sequences: the lanes' launch chains are parallel "
-                                                              "branches of one graph and fill each other's gaps; per sequence the kernels and the bits "
-                                                              "of a 64-sequence decoder (tests/test_multiseq_gpu.py)")
+                out["multi_stream_lanes"] = multi_stream(256, "one decoder, two lanes of 128 sequences (q8 / q4; f16: four lanes of 64): the lanes' launch "
+                                                              "chains are parallel branches of one graph and fill each other's gaps, a lane's W.x workgroups "
+                                                              "run eight row tiles per expanded weight fragment; per sequence the bits of a 64-sequence "
+                                                              "decoder (tests/test_multiseq_gpu.py); 384 / 512 sequences measured 69.5 k / 71.2 k tok/s")
             except Exception as e:
                 out["multi_stream_lanes"] = {"tok_s": None, "note": "lanes leg unavailable: %r" % (e,)}
         model = host.model(cfg)

@@ -199,7 +199,7 @@ int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_la
 int gten_hip_decoder_create_multi(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, const gten_hip_kv_ptrs* kv, int n_seq,
                                   gten_hip_decoder** out)
 {
-    const bool ok = n_seq == 2 || n_seq == 4 || n_seq == 8 || n_seq == 16 || n_seq == 32 || n_seq == 48 || n_seq == 64 || n_seq == 128 || n_seq == 192 || n_seq == 256;
+    const bool ok = n_seq == 2 || n_seq == 4 || n_seq == 8 || n_seq == 16 || n_seq == 32 || n_seq == 48 || n_seq == 64 || n_seq == 128 || n_seq == 192 || n_seq == 256 || n_seq == 384 || n_seq == 512;
     if (!ok || !kv) return fail("decoder_create_multi: %d sequences", n_seq);
     return create_common(desc, layers, n_seq, out);
 }

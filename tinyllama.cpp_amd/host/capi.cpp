@@ -190,7 +190,7 @@ struct gten_host_batch {
 
 gten_host_batch* gten_host_batch_create(const gten_host_config* cfg, int n_seq)
 {
-    if (!cfg || !(n_seq == 2 || n_seq == 4 || n_seq == 8 || (n_seq >= 16 && n_seq <= 64 && n_seq % 16 == 0) || (n_seq > 64 && n_seq <= 256 && n_seq % 64 == 0))) return nullptr;
+    if (!cfg || !(n_seq == 2 || n_seq == 4 || n_seq == 8 || (n_seq >= 16 && n_seq <= 64 && n_seq % 16 == 0) || (n_seq > 64 && n_seq <= 256 && n_seq % 64 == 0) || n_seq == 384 || n_seq == 512)) return nullptr;
     auto* b = new gten_host_batch;
     b->cfg = *cfg;
     b->batch.reset(new TinyLlamaBatch(n_seq, cfg->max_ctx, ModuleDtype{to_dtype(cfg->wdtype), to_dtype(cfg->adtype)}, to_params(*cfg)));

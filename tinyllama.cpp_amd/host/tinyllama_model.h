@@ -345,8 +345,9 @@ class TinyLlamaBatch {
 public:
     TinyLlamaBatch(int n_seq, int n_ctx, ModuleDtype dtype, TinyLLamaParams p = TinyLLamaParams{}) : n_ctx_{n_ctx}, dtype_{dtype}, params_{p}
     {
-        GTEN_ASSERTM(n_seq == 2 || n_seq == 4 || n_seq == 8 || (n_seq >= 16 && n_seq <= 64 && n_seq % 16 == 0) || (n_seq > 64 && n_seq <= 256 && n_seq % 64 == 0),
-                     "TinyLlamaBatch: n_seq %d not in {2, 4, 8, 16, 32, 48, 64, 128, 192, 256}", n_seq);
+        GTEN_ASSERTM(n_seq == 2 || n_seq == 4 || n_seq == 8 || (n_seq >= 16 && n_seq <= 64 && n_seq % 16 == 0) || (n_seq > 64 && n_seq <= 256 && n_seq % 64 == 0) ||
+                         n_seq == 384 || n_seq == 512,
+                     "TinyLlamaBatch: n_seq %d not in {2, 4, 8, 16, 32, 48, 64, 128, 192, 256, 384, 512}", n_seq);
         for (int i = 0; i < n_seq; i++) {
             seqs_.emplace_back(new TinyLlama(n_ctx, dtype, p));
             seqs_.back()->set_fast_decode(false);
