@@ -225,8 +225,9 @@ typedef struct { void* kcache; void* vcache; } gten_hip_kv_ptrs;
 
 int gten_hip_decoder_create(const gten_hip_decoder_desc* desc, const gten_hip_layer_ptrs* layers, gten_hip_decoder** out);
 /* Multi-sequence decode: n_seq in {2, 4, 8}, 16/32/48/64 (W.x on the matrix cores, rows =
- * sequences) or 128/192/256 (2/3/4 LANES of 64 sequences: each lane's launch chain is a parallel branch of the step's
- * graph, per sequence the kernels and results of a 64-sequence decoder) independent sequences, each with
+ * sequences) or 128/192/256/384/512 (LANES: each lane's launch chain is a parallel branch of the step's graph; q8 / q4
+ * weights run lanes of 128 sequences -- eight row tiles per W.x workgroup --, f16 weights, the exact forms and 192 lanes of
+ * 64, at most four lanes; per sequence the results of a 64-sequence decoder) independent sequences, each with
  * its own K/V caches (kv[seq * n_layers + layer]) and token ids, advance by one token per step and
  * SHARE every weight pass (weights are streamed once per step, not once per sequence).  Per sequence
  * the results are bit-identical to the single-sequence decoder for n_seq <= 8 (n_seq >= 16: the linears follow
