@@ -88,7 +88,7 @@ def parse_args(argv=None):
                          "(default) or one prompt-processing call -- the latter keeps a rocprofv3 kernel trace to "
                          "thousands instead of hundreds of thousands of launches")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
-    ap.add_argument("--no-lanes", action="store_true", help="skip the 256-sequence (four lanes) leg")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the 256-sequence (lanes) leg")
     ap.add_argument("--brief", action="store_true", help="only the metric line: no secondary legs, no CPU baseline")
     ap.add_argument("--curve", action="store_true",
                     help="with --gpus N > 1 under this file's own launcher: first run 1, 2, 4, ... < N replicas (brief) and "
@@ -753,7 +753,7 @@ def worker(args, rank, local_rank, world, dist):
                                                     "per sequence inside the model band around single-sequence decode, "
                                                     "graph == eager bit for bit (tests/test_multiseq_gpu.py)")
         if args.wide_streams == 64 and use_graph and total <= N_CTX - 1 and not args.no_lanes:
-            # round 3: 256 sequences in ONE decoder -- four lanes of 64, each lane's launch chain a parallel branch of the
+            # round 3: 256 sequences in ONE decoder -- lanes of 128 (f16: 64), each lane's launch chain a parallel branch of the
             # step's graph (round 2 measured the effect with two separate decoders on two streams: multi_stream_wide_x2)
             try:
                 out["multi_stream_lanes"] = multi_stream(256, "one decoder, two lanes of 128 sequences (q8 / q4; f16: four lanes of 64): the lanes' launch "
