@@ -4043,7 +4043,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         }
         if (rc) return rc;
         const int QW = E + 2 * KV;
-        const int ks_qkv = S <= 32 ? ks_of(E) : 1;             // (measured: 160 x 2 workgroups of 4 row tiles run slower than 160)
+        // (measured: 160 x 2 workgroups of 4 row tiles run slower than 160; of 8 row tiles too: 11.8 against 9.0 us per launch)
+        const int ks_qkv = S <= 32 ? ks_of(E) : 1;
         if ((rc = mmk(KT_DEC_GEMV_QKV, b.stg_q, b.stg_d, b.qkv_raw, QW, E, ks_qkv, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
         AttnArgs t{};
         t.step = b.step; t.qkv_raw = b.qkv_raw; t.kv_pitch = kv_pitch; t.scores = b.scores; t.stats = b.stats;
