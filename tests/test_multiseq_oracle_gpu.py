@@ -20,7 +20,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("name,wd,ad", MODES())
-@pytest.mark.parametrize("n_seq", [8, 16, 32, 64, 128])
+@pytest.mark.parametrize("n_seq", [8, 16, 32, 64, 128, 256])
 def test_batch_slots_against_the_oracle(hip, oracle, name, wd, ad, n_seq):
     """every watched slot of an n_seq batch decodes its own token stream from n = 1 across the 256-position attention
     chunk boundary; its logits are compared with the oracle model run on the same stream (own K/V history each)"""
@@ -30,7 +30,8 @@ def test_batch_slots_against_the_oracle(hip, oracle, name, wd, ad, n_seq):
     cfg = host_cfg(ocfg)
     N = 262
     checks = (1, 2, 33, 100, 255, 256, 257, N)
-    watch = (0, 1, n_seq // 2, n_seq - 1) if n_seq <= 64 else (0, 63, 64, n_seq - 1)      # (lanes of 64: both sides of the seam)
+    # (lanes of 64 -- f16 -- or of 128 rows -- q8 / q4: both sides of every seam)
+    watch = (0, 1, n_seq // 2, n_seq - 1) if n_seq <= 64 else tuple(sorted({0, 63, 64, 127, 128, n_seq - 1} & set(range(n_seq))))
     streams = [host.synthetic_tokens(N, seed=500 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
     batch = host.batch(cfg, n_seq)
     weights = [host.synth_weight(cfg, 2468, i) for i in range(len(cfg.weight_shapes()))]
@@ -73,7 +74,7 @@ def full_golden():
     return np.load(path)
 
 
-@pytest.mark.parametrize("name,wd,ad,S", [m + (64,) for m in MODES()] + [m + (128,) for m in MODES() if m[0] == "q4"])
+@pytest.mark.parametrize("name,wd,ad,S", [m + (64,) for m in MODES()] + [m + (S,) for m in MODES() if m[0] == "q4" for S in (128, 256)])
 def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name, wd, ad, S):
     """TinyLlama-1.1B, 64 sequences sharing the weight passes: every slot carries the reference's golden token stream
     (15-id prompt through the slot's operator path, then 23 teacher-forced steps of the whole batch on the matrix-core
@@ -83,7 +84,7 @@ def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name,
     host = pkg.load_host()
     cfg = host.default_config(wd, ad)
     cfg.max_ctx = 256
-    batch = host.batch(cfg, S)                  # (128: two lanes of 64 in one decoder)
+    batch = host.batch(cfg, S)                  # (128: one lane of 128 rows; 256: two of them in one decoder)
     batch.load_synthetic(int(g["seed"][0]))
     toks = g[f"{name}.avx.tokens"]
     probe = g["probe_ids"]
@@ -121,17 +122,17 @@ def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name,
     print(f"{name} S={S} full size: worst rms {worst[0]:.4f} max {worst[1]:.4f} over {S} slots x {steps - 1} steps")
 
 
-def test_wide_path_long_context_probe_q4(hip, full_golden):
-    """the 64-sequence path at the BASELINE.json metric point: every slot steps the long.q4 token stream from n = 1 to
-    n = 2048; slots 0 / 31 / 63 are held to the reference's probe at n = 257, 1024, 2047, 2048 with the yardstick of
-    tests/test_golden_gpu.py::test_long_context_probe_q4 (the reference's own AVX-vs-scalar spread at that length)"""
+@pytest.mark.parametrize("S", [64, 128])
+def test_wide_path_long_context_probe_q4(hip, full_golden, S):
+    """the 64-sequence path -- and a lane of 128 rows -- at the BASELINE.json metric point: every slot steps the long.q4 token
+    stream from n = 1 to n = 2048; slots 0 / 31 / S - 1 are held to the reference's probe at n = 257, 1024, 2047, 2048 with the
+    yardstick of tests/test_golden_gpu.py::test_long_context_probe_q4 (the reference's own AVX-vs-scalar spread at that length)"""
     g = full_golden
     if "long.q4.ns" not in g:
         pytest.skip("long-context probe not in the fixture")
     pkg = load_package()
     host = pkg.load_host()
     cfg = host.default_config(Q4, Q8)
-    S = 64
     batch = host.batch(cfg, S)
     batch.load_synthetic(int(g["seed"][0]))
     toks = host.synthetic_tokens(2048, seed=int(g["token_seed"][0]))
@@ -147,11 +148,11 @@ def test_wide_path_long_context_probe_q4(hip, full_golden):
         own_rms = float(np.sqrt((own * own).mean()))
         ids = g[f"long.q4.n{n}.top_ids"]
         ref_vals = np.concatenate([g[f"long.q4.n{n}.top_logits"], g[f"long.q4.n{n}.probes"]])
-        for q in (0, 31, 63):
+        for q in (0, 31, S - 1):
             lg = batch.logits(q)
             d = np.concatenate([lg[ids], lg[probe]]) - ref_vals
             rms, mx = float(np.sqrt((d * d).mean())), float(np.abs(d).max())
-            print(f"S=64 slot {q} n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} "
+            print(f"S={S} slot {q} n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} "
                   f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} scalar {int(g[f'long.q4.n{n}.top_ids.scalar'][0])}")
             assert rms <= 1.35 * own_rms and mx <= 0.5, (q, n, rms, own_rms, mx)
     batch.close()
