@@ -277,8 +277,15 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, c
 int gten_hip_decoder_slot_start(gten_hip_decoder* dec, int seq, int n_first);
 int gten_hip_decoder_slot_start_until(gten_hip_decoder* dec, int seq, int n_first, int n_last);
 int gten_hip_decoder_slot_park(gten_hip_decoder* dec, int seq);
+/* several slots at once, one wait at the end: slot seqs[i] is started at n_first[i] with its last step n_last[i] (0: none) and --
+ * when tokens and tokens[i] are given -- its ids [0, n_first[i]) set; n_first[i] == 0 parks it.  A sequence may appear once. */
+int gten_hip_decoder_slots_apply(gten_hip_decoder* dec, int count, const int* seqs, const int* n_first, const int* n_last,
+                                 const int32_t* const* tokens);
 int gten_hip_decoder_run(gten_hip_decoder* dec, int steps);
 int gten_hip_decoder_slot_ids(gten_hip_decoder* dec, int seq, int n_from, int count, int32_t* ids_host);
+/* ... of EVERY sequence at once: ids_host[q * count + i] = the argmax of step n_from[q] + i of sequence q (count <= 64; a
+ * sequence's entries past the steps it ran are unspecified) -- one gather launch and one copy instead of n_seq copies */
+int gten_hip_decoder_slot_ids_all(gten_hip_decoder* dec, const int* n_from, int count, int32_t* ids_host);
 /* multi-sequence decoders: sequence q decodes row n_per_seq[q] - 1 (continuous batching: sequences of different
  * lengths share the weight passes); results are read per sequence with gten_hip_decoder_result_seq(dec, q, n_per_seq[q]) */
 int gten_hip_decoder_step_ragged(gten_hip_decoder* dec, const int* n_per_seq, int use_graph);

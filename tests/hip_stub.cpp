@@ -305,6 +305,20 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
     dc->slots[(size_t)seq] = Slot{1, 0, 0};
     return 0;
 }
+int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seqs, const int* n_first, const int* n_last, const int32_t* const* tokens)
+{
+    if (!dc || count < 0 || (count > 0 && (!seqs || !n_first || !n_last))) return fail("slots_apply: arguments");
+    for (int i = 0; i < count; i++) {
+        if (n_first[i] == 0) {
+            if (int rc = gten_hip_decoder_slot_park(dc, seqs[i])) return rc;
+            continue;
+        }
+        if (tokens && tokens[i])
+            if (int rc = gten_hip_decoder_set_tokens_seq(dc, seqs[i], tokens[i], 0, n_first[i])) return rc;
+        if (int rc = gten_hip_decoder_slot_start_until(dc, seqs[i], n_first[i], n_last[i])) return rc;
+    }
+    return 0;
+}
 int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
 {
     if (!dc || steps < 0) return fail("decoder_run: arguments");
@@ -325,6 +339,18 @@ int gten_hip_decoder_slot_ids(gten_hip_decoder* dc, int seq, int n_from, int cou
 {
     if (!dc || seq < 0 || seq >= dc->n_seq || n_from < 1 || count < 0 || n_from + count > dc->d.max_ctx + 1 || !ids) return fail("slot_ids: range");
     for (int i = 0; i < count; i++) ids[i] = dc->tokens[(size_t)seq][(size_t)(n_from + i)];
+    return 0;
+}
+int gten_hip_decoder_slot_ids_all(gten_hip_decoder* dc, const int* n_from, int count, int32_t* ids)
+{
+    if (!dc || !n_from || !ids || count < 0 || count > 64) return fail("slot_ids_all: arguments");
+    for (int q = 0; q < dc->n_seq; q++) {
+        if (n_from[q] < 0 || n_from[q] > dc->d.max_ctx + 1) return fail("slot_ids_all: sequence %d from step %d", q, n_from[q]);
+        for (int i = 0; i < count; i++) {
+            const int n = std::min(n_from[q] + i, dc->d.max_ctx);
+            ids[(size_t)q * count + i] = dc->tokens[(size_t)q][(size_t)n];
+        }
+    }
     return 0;
 }
 int gten_hip_decoder_time_family(gten_hip_decoder*, int, int, int, double* avg_us, int* launches)

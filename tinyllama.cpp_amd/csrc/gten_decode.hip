@@ -3269,6 +3269,7 @@ struct gten_hip_decoder {
     DecStep* step = nullptr;
     int32_t* tokens = nullptr;     // [max_ctx + 1] teacher-forcing / prompt ids
     int32_t* result = nullptr;     // [max_ctx + 2] argmax per step, indexed by n
+    int32_t* ids_stage = nullptr;  // [n_seq][64]: gten_hip_decoder_slot_ids_all's gather (made on first use)
     float *qkv_raw = nullptr, *proj_raw = nullptr, *down_raw = nullptr;
     float *scores = nullptr, *stats = nullptr, *att_part = nullptr;
     uint8_t *xbuf = nullptr, *hbuf = nullptr;
@@ -4322,7 +4323,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     if (dc->graph) hipGraphDestroy(dc->graph);
     if (dc->exec_k) hipGraphExecDestroy(dc->exec_k);
     if (dc->graph_k) hipGraphDestroy(dc->graph_k);
-    void* bufs[] = {dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
+    void* bufs[] = {dc->ids_stage, dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
                     dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now, dc->dummy_kv};
@@ -4613,6 +4614,50 @@ int gten_hip_decoder_slot_start_until(gten_hip_decoder* dc, int seq, int n_first
     return 0;
 }
 
+// Several slots at once (a harvest of a 128-slot queue parks ~8 slots and starts ~8: 40 small copies each followed by a wait):
+// slot seqs[i] is started at n_first[i] with its last step n_last[i] (0: none) and, when tokens[i] is given, its ids
+// [0, n_first[i]) set -- or parked when n_first[i] == 0.  The step words and the cache table go up once, one wait at the end.
+int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seqs, const int* n_first, const int* n_last, const int32_t* const* tokens)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && count >= 0 && (count == 0 || (seqs && n_first && n_last)), "decoder_slots_apply: bad arguments");
+    if (int rc = slots_view(dc)) return rc;
+    if (count == 0) return 0;
+    const size_t L = (size_t)dc->d.n_layers;
+    const size_t cache_bytes = (size_t)dc->d.max_ctx * gten_hip_row_bytes(dc->d.adtype, (dc->d.n_embd / dc->d.n_heads) * dc->d.n_kv_heads);
+    for (int i = 0; i < count; i++) {
+        const int q = seqs[i];
+        GTR_REQUIRE(q >= 0 && q < dc->n_seq, "decoder_slots_apply: sequence %d outside [0, %d)", q, dc->n_seq);
+        GTR_REQUIRE(n_first[i] >= 0 && n_first[i] <= dc->d.max_ctx, "decoder_slots_apply: n_first=%d outside [0, %d]", n_first[i], dc->d.max_ctx);
+        GTR_REQUIRE(n_first[i] == 0 || n_last[i] == 0 || (n_last[i] >= n_first[i] && n_last[i] <= dc->d.max_ctx), "decoder_slots_apply: n_last=%d outside [%d, %d]",
+                    n_last[i], n_first[i], dc->d.max_ctx);
+        if (tokens && tokens[i] && n_first[i] > 0)
+            for (int k = 0; k < n_first[i]; k++)
+                GTR_REQUIRE(tokens[i][k] >= 0 && tokens[i][k] < dc->d.n_vocab, "decoder_slots_apply: token id %d at position %d outside [0, %d)", tokens[i][k], k, dc->d.n_vocab);
+    }
+    std::vector<const void*> rows((size_t)count * L * 2);
+    for (int i = 0; i < count; i++) {
+        const int q = seqs[i];
+        const bool park = n_first[i] == 0;
+        dc->slots[(size_t)q] = park ? DecStep{1, 0, 0} : DecStep{n_first[i], 3, n_last[i]};
+        if (!dc->kv_parked.empty() && (bool)dc->kv_parked[(size_t)q] != park) {
+            const void** row = rows.data() + (size_t)i * L * 2;            // (alive until the wait below)
+            for (size_t l = 0; l < L; l++) {
+                const size_t o = (size_t)q * L * 2 + 2 * l;
+                row[2 * l] = park ? dc->dummy_kv : dc->kv_real[o];
+                row[2 * l + 1] = park ? (const void*)((const uint8_t*)dc->dummy_kv + cache_bytes) : dc->kv_real[o + 1];
+            }
+            dc->kv_parked[(size_t)q] = park;
+            GTR_CHECK(hipMemcpyAsync(dc->kv_tab + (size_t)q * L * 2, row, L * 2 * sizeof(void*), hipMemcpyHostToDevice, stream()));
+        }
+        if (!park && tokens && tokens[i])
+            GTR_CHECK(hipMemcpyAsync(dc->tokens + (size_t)q * (dc->d.max_ctx + 1), tokens[i], (size_t)n_first[i] * 4, hipMemcpyHostToDevice, stream()));
+        GTR_CHECK(hipMemcpyAsync(dc->step + q, &dc->slots[(size_t)q], sizeof(DecStep), hipMemcpyHostToDevice, stream()));
+    }
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    return 0;
+}
+
 int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
 {
     GTR_NEED_INIT();
@@ -4651,6 +4696,34 @@ int gten_hip_decoder_slot_ids(gten_hip_decoder* dc, int seq, int n_from, int cou
     GTR_CHECK(hipStreamSynchronize(stream()));
     if (count > 0)
         GTR_CHECK(hipMemcpy(ids_host, dc->result + (size_t)seq * (dc->d.max_ctx + 2) + n_from, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// the ids of steps [n_from[q], n_from[q] + count) of EVERY sequence in one gather launch and one copy (a harvest of 128 slots was
+// 128 synchronous 32-byte copies: 1.5 ms per slice of 8 shared steps); n_from by value in the kernel arguments
+struct IdsFrom { int n[128 * DEC_MAX_LANES]; };
+__global__ __launch_bounds__(64) void k_dec_gather_ids(const int32_t* __restrict__ result, int stride, int last, const IdsFrom from, int count, int32_t* __restrict__ out)
+{
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (t < count) out[(size_t)q * count + t] = result[(size_t)q * stride + min(max(from.n[q], 0) + t, last)];
+}
+
+int gten_hip_decoder_slot_ids_all(gten_hip_decoder* dc, const int* n_from, int count, int32_t* ids_host)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && n_from && ids_host && count >= 0 && count <= 64, "decoder_slot_ids_all: bad arguments (count %d, at most 64)", count);
+    GTR_REQUIRE(dc->n_seq <= 128 * DEC_MAX_LANES, "decoder_slot_ids_all: %d sequences", dc->n_seq);
+    if (count == 0) { GTR_CHECK(hipStreamSynchronize(stream())); return 0; }
+    if (!dc->ids_stage) GTR_CHECK(hipMalloc((void**)&dc->ids_stage, (size_t)dc->n_seq * 64 * 4));
+    IdsFrom from{};
+    for (int q = 0; q < dc->n_seq; q++) {
+        GTR_REQUIRE(n_from[q] >= 0 && n_from[q] <= dc->d.max_ctx + 1, "decoder_slot_ids_all: sequence %d from step %d", q, n_from[q]);
+        from.n[q] = n_from[q];
+    }
+    // (steps past max_ctx + 1 read the row's last entry: the caller takes only the steps a slot really ran)
+    GTR_LAUNCH(KT_DEC_ARGMAX, k_dec_gather_ids, dim3(dc->n_seq), dim3(64), 0, (const int32_t*)dc->result, dc->d.max_ctx + 2, dc->d.max_ctx + 1, from, count, dc->ids_stage);
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    GTR_CHECK(hipMemcpy(ids_host, dc->ids_stage, (size_t)dc->n_seq * count * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

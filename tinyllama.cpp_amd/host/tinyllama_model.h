@@ -538,7 +538,7 @@ public:
         std::vector<char> live((size_t)S, 0);
         size_t next = 0;
         int n_live = 0, n_ready = 0;
-        std::vector<int32_t> ids((size_t)std::max(slice, 1));
+        slice = std::min(std::max(slice, 1), 64);                          // (gten_hip_decoder_slot_ids_all reads up to 64 steps at once)
         GTEN_HIP_OK(gten_hip_select_stream(0));
         for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
         // the next prompt of the queue onto free slot q (stream 1); false when the queue is empty
@@ -620,18 +620,24 @@ public:
         };
         int cnt = 0;                                                       // steps of the slice in flight (0: none)
         auto t_slice = clock::now();
+        std::vector<int> ap_seq, ap_first, ap_last;                        // gten_hip_decoder_slots_apply's arguments
+        std::vector<const int32_t*> ap_tok;
         // ready slots join, then the next slice starts (stream 0, asynchronous)
         auto launch_slice = [&]() {
             // (the caches of the joining slots were filled on stream 1: the host has waited for that, and the explicit
             //  stream-to-stream dependency makes the next launch on stream 0 acquire what another queue has written)
             if (n_ready > 0) GTEN_HIP_OK(gten_hip_stream_wait(0, 1));
+            // (all joining slots in one call: their ids, step words and cache-table rows go up behind each other, one wait)
+            ap_seq.clear(); ap_first.clear(); ap_last.clear(); ap_tok.clear();
             for (int q = 0; q < S && n_ready > 0; q++)
                 if (job[(size_t)q] >= 0 && !live[(size_t)q]) {
                     const std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
-                    GTEN_HIP_OK(gten_hip_decoder_set_tokens_seq(dec_, q, row.data(), 0, (int)row.size()));
-                    GTEN_HIP_OK(gten_hip_decoder_slot_start_until(dec_, q, cur[(size_t)q], last[(size_t)q]));
+                    GTEN_ASSERTM((int)row.size() == cur[(size_t)q], "serve: slot %d holds %zu ids at step %d", q, row.size(), cur[(size_t)q]);
+                    ap_seq.push_back(q); ap_first.push_back(cur[(size_t)q]); ap_last.push_back(last[(size_t)q]); ap_tok.push_back(row.data());
                     live[(size_t)q] = 1; n_live++; n_ready--;
                 }
+            if (!ap_seq.empty())
+                GTEN_HIP_OK(gten_hip_decoder_slots_apply(dec_, (int)ap_seq.size(), ap_seq.data(), ap_first.data(), ap_last.data(), ap_tok.data()));
             if (n_live == 0) return;
             // (a slot whose run ends inside the slice repeats its last step until the slice is over, slot_start_until: the slice
             //  is cut only when EVERY live slot ends earlier)
@@ -644,11 +650,17 @@ public:
             st.steps += cnt;
         };
         // the ids of the finished slice; slots that ended are parked (their caches are free for the next prompt)
+        std::vector<int> from((size_t)S, 0);
+        std::vector<int32_t> all_ids((size_t)S * (size_t)std::max(slice, 1));
         auto harvest = [&]() {
+            // every live slot's ids of the slice in ONE gather + copy (waits for stream 0)
+            for (int q = 0; q < S; q++) from[(size_t)q] = live[(size_t)q] ? cur[(size_t)q] : 0;
+            GTEN_HIP_OK(gten_hip_decoder_slot_ids_all(dec_, from.data(), cnt, all_ids.data()));
+            ap_seq.clear(); ap_first.clear(); ap_last.clear();
             for (int q = 0; q < S; q++) {
                 if (!live[(size_t)q]) continue;
                 const int got = std::min(cnt, last[(size_t)q] - cur[(size_t)q] + 1);                  // (its steps of this slice)
-                GTEN_HIP_OK(gten_hip_decoder_slot_ids(dec_, q, cur[(size_t)q], got, ids.data()));   // (waits for stream 0)
+                const int32_t* ids = all_ids.data() + (size_t)q * (size_t)cnt;
                 std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
                 bool stop = false;
                 for (int i = 0; i < got && !stop; i++) {
@@ -657,10 +669,11 @@ public:
                 }
                 cur[(size_t)q] += got;
                 if (stop || cur[(size_t)q] > last[(size_t)q]) {
-                    GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
+                    ap_seq.push_back(q); ap_first.push_back(0); ap_last.push_back(0);                  // parked, all of them at once below
                     job[(size_t)q] = -1; live[(size_t)q] = 0; n_live--;
                 }
             }
+            if (!ap_seq.empty()) GTEN_HIP_OK(gten_hip_decoder_slots_apply(dec_, (int)ap_seq.size(), ap_seq.data(), ap_first.data(), ap_last.data(), nullptr));
             st.decode_s += std::chrono::duration<double>(clock::now() - t_slice).count();
             cnt = 0;
             GTEN_HIP_OK(gten_hip_stream_wait(1, 0));            // (... and the other way round for the caches the parked slots leave)
