@@ -596,7 +596,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 for (int t = 0; t < WM; t++) a[t] = *(const half8*)(sa + (wr * 16 * WM + 16 * t + l16) * APITCH + (((kb * 4 + g) ^ (l16 & C::SWZ)) * 16));
             };
             frags(0, af[0], bf[0]);
-            if (s + 1 < nstage) store_stage(land, buf ^ 1);
+            // The next stage's tile is stored BEHIND the first block's matrix instructions: LDS operations complete in order and
+            // s_waitcnt lgkmcnt counts them all, so with the eight ds_write_b128 (13 cycles each) issued ahead of them the
+            // first matrix instructions waited for the store queue, not for their fragments.  2048-id prompt: W.x 6.51 -> 6.27-6.35 ms,
+            // 512 ids 2.76 -> 2.65 (behind the LAST block's matrix instructions instead: 6.45 / 2.63).
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) {
                 if (kb + 1 < KB) frags(kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
@@ -604,6 +607,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 for (int t = 0; t < WM; t++)
 #pragma unroll
                     for (int j = 0; j < WN; j++) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb & 1][t], bf[kb & 1][j], acc[t][j], 0, 0, 0);
+                if (kb == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < nstage) store_stage(land, buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // (measured and not kept: the expansion made unconditional -- one basic block -- and woven between the matrix
             //  instructions with sched_group_barrier: 2048-id prompt 13.2 -> 15.1 ms; woven by hand, one 8-element unit behind
