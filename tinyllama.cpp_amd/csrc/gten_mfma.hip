@@ -599,7 +599,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // The next stage's tile is stored BEHIND the first block's matrix instructions: LDS operations complete in order and
             // s_waitcnt lgkmcnt counts them all, so with the eight ds_write_b128 (13 cycles each) issued ahead of them the
             // first matrix instructions waited for the store queue, not for their fragments.  2048-id prompt: W.x 6.51 -> 6.27-6.35 ms,
-            // 512 ids 2.76 -> 2.65 (behind the LAST block's matrix instructions instead: 6.45 / 2.63).
+            // 512 ids 2.76 -> 2.65 (behind the LAST block's matrix instructions instead: 6.45 / 2.63).  In this order the compiler
+            // sinks the prefetch requests among the matrix instructions and waits vmcnt(0) at the loop header; with the requests
+            // pinned at the top (no such wait: vmcnt(7) / (6) at the store) W.x measured 6.46 ms, with the store made unconditional
+            // as well 6.52 -- the loop does not wait for memory.
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) {
                 if (kb + 1 < KB) frags(kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
