@@ -603,6 +603,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             // sinks the prefetch requests among the matrix instructions and waits vmcnt(0) at the loop header; with the requests
             // pinned at the top (no such wait: vmcnt(7) / (6) at the store) W.x measured 6.46 ms, with the store made unconditional
             // as well 6.52 -- the loop does not wait for memory.
+            // (Also built into THIS kernel and measured: only the activation tile by LDS-DMA (inline assembly, the swizzle made by
+            // the source addresses, one stage ahead into the other buffer, a counted s_waitcnt vmcnt ahead of the stage's barrier;
+            // 148 instead of 188 VGPRs, half the ds_write_b128): the same bits, W.x 6.97 against 6.40 ms at 2048 ids, 2.88 against
+            // 2.67 at 512 -- one stage of lookahead does not cover the tile's latency, the register path's two stages do.)
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) {
                 if (kb + 1 < KB) frags(kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
