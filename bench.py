@@ -103,11 +103,32 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def code_only(text):
+    """C / C++ source without its comments and with runs of white space collapsed (string and character literals kept as they
+    are): what csrc_fingerprint() hashes, so that a note added to a kernel does not orphan the counters collected on it"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                       # a literal: copied up to its closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i); i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2); i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def csrc_fingerprint():
-    """sha256 (16 hex digits) over what the in-tree libgten_hip.so is built from -- the kernel sources AND the compiler
-    flags (build.HIP_FLAGS, HIP_FILE_FLAGS: round 2 changed code generation of every kernel by a flag change alone):
-    what ties profiles/traffic.json (PMC counters collected by tools/collect_profiles.sh) to the kernels being
-    benched -- the GPU box has no .git, so a hash rather than a commit id"""
+    """sha256 (16 hex digits) over what the in-tree libgten_hip.so is built from -- the kernel sources (comments and white
+    space aside: code_only) AND the compiler flags (build.HIP_FLAGS, HIP_FILE_FLAGS: round 2 changed code generation of every
+    kernel by a flag change alone): what ties profiles/traffic.json (PMC counters collected by tools/collect_profiles.sh) to
+    the kernels being benched -- the GPU box has no .git, so a hash rather than a commit id"""
     import hashlib
     from __graft_entry__ import load_package
     b = load_package().build
@@ -116,7 +137,7 @@ def csrc_fingerprint():
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(code_only(open(os.path.join(d, name), "r", encoding="utf-8", errors="replace").read()).encode())
     flags = [f for f in b.HIP_FLAGS if not f.startswith("-I")]          # (-I carries the checkout's absolute path)
     h.update(repr((flags, sorted(b.HIP_FILE_FLAGS.items()))).encode())
     return h.hexdigest()[:16]

@@ -128,3 +128,16 @@ def test_shards_partition_the_queue():
             shards = [rep.shard_prompts(n_prompts, r, world) for r in range(world)]
             assert sorted(j for sh in shards for j in sh) == list(range(n_prompts))
             assert max(len(sh) for sh in shards) - min(len(sh) for sh in shards) <= 1
+
+
+def test_source_fingerprint_ignores_comments_not_code():
+    """profiles/traffic.json is tied to the kernels by bench.csrc_fingerprint(): a note added to a kernel source must not
+    orphan the counters collected on it, any change of code (or of a string / character literal) must"""
+    import bench
+    a = 'int a = 1; // note "x"\n/* block\n comment */ const char* s = "http://x // not a comment"; char c = \'"\';\n#define M(x) x // tail\n'
+    b = 'int a = 1;\nconst char* s = "http://x // not a comment";   char c = \'"\';   /* other words */\n#define M(x) x\n'
+    assert bench.code_only(a) == bench.code_only(b)
+    assert bench.code_only(a) != bench.code_only(a.replace("a = 1", "a = 2"))
+    assert bench.code_only(a) != bench.code_only(a.replace("// not a comment", "// NOT a comment"))
+    assert "note" not in bench.code_only(a) and "block" not in bench.code_only(a)
+    assert len(bench.csrc_fingerprint()) == 16
