@@ -79,8 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--prefill", type=int, default=512, help="also time a prompt of this many ids (0 = skip)")
     ap.add_argument("--generate", type=int, default=256, help="also time real greedy generation of this many ids ending at the context limit (0 = skip)")
     ap.add_argument("--serve", type=int, default=1024, help="also serve a queue of this many synthetic prompts through the serving slots (0 = skip)")
-    ap.add_argument("--serve-slots", type=int, default=128, choices=[0, 16, 32, 48, 64, 128, 192, 256, 384, 512],
-                    help="slots of the serving leg (0: --wide-streams); measured, 1024 prompts: 64 slots 25.6k new ids/s, 128 31.5k, 256 32.9k (but its first 256 prompts 23.7k against 25.8k)")
+    ap.add_argument("--serve-slots", type=int, default=256, choices=[0, 16, 32, 48, 64, 128, 192, 256, 384, 512],
+                    help="slots of the serving leg (0: --wide-streams); measured, 1024 prompts (its first 256 alone): 64 slots 27.2k (24.5k) new ids/s, "
+                         "128 34.7k (28.1k), 256 37.0k (27.5k)")
     ap.add_argument("--serve-slice", type=int, default=8, help="shared steps per slice of the serving leg")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",

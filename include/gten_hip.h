@@ -177,7 +177,8 @@ int gten_hip_set_block_rows(int on);
 
 /* SEVERAL prompts as one row matrix (batched prompt processing; round 3).  The rows of a prompt-sized call are
  * row-independent in every operator except two: the position RoPE rotates by, and the rows attention looks back over.
- * With row segments set -- starts[0] = 0 < starts[1] < ... < starts[n_segments] = the row count, every segment >= 16 rows --
+ * With row segments set -- starts[0] = 0 < starts[1] < ... < starts[n_segments] = the row count (<= 4096), every segment 16 ..
+ * 2048 rows --
  * gten_hip_block_rows (start_pos 0, n = starts[n_segments]) treats rows [starts[k], starts[k + 1]) as prompt k: position =
  * row - starts[k], attention inside the segment only; everything else runs once over all rows (one W.x per projection for
  * all prompts).  Per prompt the results do not depend on the other segments: the W.x launches of a segmented call never

@@ -190,25 +190,27 @@ def test_full_size_prompt_in_a_shared_row_matrix_against_reference_golden(hip, e
 
 
 def test_row_matrix_at_its_limits(hip):
-    """2048 rows in all (the shared matrix's capacity), sixteen prompts (the most one call takes), a 16-id prompt (the shortest
-    a segment may be) beside a 1-id-short-of-the-limit one: each prompt's logits are those of the prompt alone; what does not fit
-    is refused, not computed wrongly"""
+    """4096 rows in all (the shared matrix's capacity), thirty-two prompts (the most one call takes), 16-id prompts (the shortest
+    a segment may be) beside one of 2048 ids (the longest: the RoPE table): each prompt's logits are those of the prompt alone;
+    what does not fit is refused, not computed wrongly"""
     from helpers import Q4, Q8, tiny_config
     from test_model_gpu import host_cfg
     pkg = load_package()
     host = pkg.load_host()
     cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=2048, n_layers=1))
     weights = [host.synth_weight(cfg, 17, i) for i in range(len(cfg.weight_shapes()))]
-    b = host.batch(cfg, 16)
+    b = host.batch(cfg, 32)
     for i, w in enumerate(weights):
         b.set_weight(i, w)
-    lens = [16] * 14 + [1024, 800]                     # 16 prompts, 2048 rows
+    lens = [16] * 30 + [2048, 1568]                    # 32 prompts, 4096 rows
     prompts = [host.synthetic_tokens(n, seed=70 + i, n_vocab=cfg.n_vocab) for i, n in enumerate(lens)]
-    lg = b.prefill_many(list(range(16)), prompts)
-    for q in (0, 13, 14, 15):
+    lg = b.prefill_many(list(range(32)), prompts)
+    for q in (0, 29, 30, 31):
         assert np.array_equal(lg[q], b.prefill(q, prompts[q])), q
     with pytest.raises(Exception):
-        b.prefill_many(list(range(16)), prompts[:15] + [host.synthetic_tokens(801, seed=1, n_vocab=cfg.n_vocab)])   # 2049 rows
+        b.prefill_many(list(range(32)), prompts[:31] + [host.synthetic_tokens(1569, seed=1, n_vocab=cfg.n_vocab)])   # 4097 rows
+    with pytest.raises(Exception):
+        hip.set_row_segments([0, 2049, 2100])                                                                      # a 2049-row segment
     with pytest.raises(Exception):
         b.prefill_many([0, 1], [prompts[0], host.synthetic_tokens(15, seed=2, n_vocab=cfg.n_vocab)])                 # a 15-id segment
     # the raw C-ABI: segments are refused by the operators that would rotate / attend across prompts

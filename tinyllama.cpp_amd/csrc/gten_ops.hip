@@ -988,7 +988,7 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     const bool q8cfg = b->adtype == GTEN_Q8 && (b->wdtype == GTEN_Q8 || b->wdtype == GTEN_Q4);
     const bool f16cfg = b->adtype == GTEN_F16 && b->wdtype == GTEN_F16;
     if (off || !(q8cfg || f16cfg) || rows < GTEN_MFMA_MIN_ROWS ||
-        rows > 65535 || n > GTEN_ROPE_MAX_POS || start_pos < 0 || dh != 64 || E % 128 != 0 || F % 128 != 0 || KV % 32 != 0 || (F / 32) % 2 != 0 ||
+        rows > 65535 || n > (seg ? GTEN_SEG_MAX_ROWS : GTEN_ROPE_MAX_POS) || start_pos < 0 || dh != 64 || E % 128 != 0 || F % 128 != 0 || KV % 32 != 0 || (F / 32) % 2 != 0 ||
         b->n_heads % b->n_kv_heads != 0)
         return GTEN_HIP_NOT_HANDLED;
     const void* ptrs[] = {b->attn_norm_w, b->wq, b->wk, b->wv, b->wo, b->ffn_norm_w, b->wgate, b->wup, b->wdown, b->inp, b->attn_norm_out,
@@ -1147,7 +1147,10 @@ int gten_hip_set_row_segments(const int32_t* starts, int n_segments)
     GTR_REQUIRE(starts && starts[0] == 0, "set_row_segments: starts[0] must be 0");
     for (int k = 0; k < n_segments; k++)
         GTR_REQUIRE(starts[k + 1] - starts[k] >= GTEN_MFMA_MIN_ROWS, "set_row_segments: segment %d has %d rows (at least %d)", k, starts[k + 1] - starts[k], GTEN_MFMA_MIN_ROWS);
-    GTR_REQUIRE(starts[n_segments] <= GTEN_ROPE_MAX_POS, "set_row_segments: %d rows in all (at most %d)", starts[n_segments], GTEN_ROPE_MAX_POS);
+    for (int k = 0; k < n_segments; k++)
+        GTR_REQUIRE(starts[k + 1] - starts[k] <= GTEN_ROPE_MAX_POS, "set_row_segments: segment %d has %d rows (at most %d: the RoPE table)", k, starts[k + 1] - starts[k],
+                    GTEN_ROPE_MAX_POS);
+    GTR_REQUIRE(starts[n_segments] <= GTEN_SEG_MAX_ROWS, "set_row_segments: %d rows in all (at most %d)", starts[n_segments], GTEN_SEG_MAX_ROWS);
     g_seg.assign(starts, starts + n_segments + 1);
     return 0;
 }

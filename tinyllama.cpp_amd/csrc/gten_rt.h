@@ -6,6 +6,7 @@
 #include "../../include/gten_hip.h"
 
 #define GTEN_ROPE_MAX_POS 2048   // TinyLLamaParams::max_ctx, tinyllama.cpp:14
+#define GTEN_SEG_MAX_ROWS 4096   // rows of a segmented call (gten_hip_set_row_segments): several prompts, each <= GTEN_ROPE_MAX_POS rows
 
 namespace gtr {
 

@@ -382,8 +382,8 @@ public:
     // matrix into its slot's caches.  A prompt's bits do not depend on what shares the matrix with it (no K loop is shared
     // between workgroups in segmented calls), so serve(), generate() and prefill() agree whatever they batch together.
     // Up to 8 sequences keep the per-sequence operator path: there the ids are those of a lone TinyLlama, bit for bit.
-    static constexpr int kPreRows = 2048;      // rows of the shared matrix (the RoPE table's positions, GTEN_ROPE_MAX_POS)
-    static constexpr int kPreMax = 16;         // prompts per call (two copy ranges per prompt and layer: GTEN_HIP_MAX_COPY_RANGES)
+    static constexpr int kPreRows = 4096;      // rows of the shared matrix (GTEN_SEG_MAX_ROWS; a prompt has at most max_ctx of them)
+    static constexpr int kPreMax = 32;         // prompts per call (two copy ranges per prompt and layer: GTEN_HIP_MAX_COPY_RANGES)
     bool batched_prompts() const
     {
         return n_seq() >= 16 && gten_hip_row_segments_ok(params_.n_embd, params_.n_ffn, params_.n_heads, params_.n_query_groups,
