@@ -81,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--serve", type=int, default=1024, help="also serve a queue of this many synthetic prompts through the serving slots (0 = skip)")
     ap.add_argument("--serve-slots", type=int, default=256, choices=[0, 16, 32, 48, 64, 128, 192, 256, 384, 512],
                     help="slots of the serving leg (0: --wide-streams); measured, 1024 prompts (its first 256 alone): 64 slots 27.2k (24.5k) new ids/s, "
-                         "128 34.7k (28.1k), 256 37.0k (27.5k)")
+                         "128 34.7k (28.1k), 256 37.0k (27.5k), 384 26.4k, 512 22.1k")
     ap.add_argument("--serve-slice", type=int, default=8, help="shared steps per slice of the serving leg")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
