@@ -157,7 +157,8 @@ int gten_hip_select_stream(int idx)
     GTR_NEED_INIT();
     GTR_REQUIRE(idx == 0 || idx == 1, "gten_hip_select_stream: stream %d (0 or 1)", idx);
     // (measured, serving through 128 slots: the prompt stream at the highest stream priority 29.7k against 29.4k new ids/s;
-    //  through 256 slots 19.2k against 11.8k, still behind 128 slots -- not kept)
+    //  through 256 slots 19.2k against 11.8k, still behind 128 slots -- not kept; with lanes of 128 rows: 256 slots 36.6k = 36.6k,
+    //  128 slots 34.6k = 34.7k, 512 slots 27.8k against 22.1k)
     if (!g_streams[idx]) GTR_CHECK(hipStreamCreateWithFlags(&g_streams[idx], hipStreamNonBlocking));
     g_cur = idx;
     return 0;
