@@ -128,6 +128,14 @@ int gten_hip_set_prefill_exact(int on);
  * of the probabilities, fp16 operand rounding in the wide W.x and p.V).  Up to 8 sequences and contexts <= 256 both forms
  * are the same bytes. */
 int gten_hip_set_decode_exact(int on);
+/* single-sequence q4 decoders created AFTER this call run the step as ONE persistent launch (1) or as the chain of 113
+ * launches (0, the default: it is the faster one on MI355X): the same bytes either way
+ * (tests/test_persist_gpu.py); csrc/gten_decode_persist.h */
+int gten_hip_set_decode_persistent(int on);
+/* the persistent step over every live decoder of the process: how many run it, its launches enqueued so far (captured
+ * launches count once), the abort code of a poll that gave up (0 = none; cleared by the call: that step's results are
+ * invalid), workgroup 0's phase stamps of the newest decoder created with GTEN_HIP_PERSIST_STAMPS=1.  Waits for the stream. */
+int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsigned* abort_code, unsigned* stamps_host, int n_stamps);
 
 /* ops::rms_norm, gten/ops.h:762-814.  w: f16[d]. */
 int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f16,

@@ -3309,6 +3309,8 @@ struct gten_hip_decoder {
     // graph (fork behind the previous replay, join at the end), so the chains fill each other's gaps.  Per sequence the
     // kernels, their arguments and therefore the results are those of a 64-sequence decoder.
     bool exact = false;               // gten_hip_set_decode_exact at creation
+    bool persist_on = false;          // gten_hip_set_decode_persistent at creation: the step as ONE persistent launch (gten_decode_persist.h)
+    struct PersistState* persist = nullptr;
     int lanes = 1;
     hipStream_t lane_stream[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};    // capture / eager side streams of lanes 1..
     hipEvent_t lane_fork = nullptr, lane_join[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -4114,9 +4116,19 @@ static int enqueue_multi(gten_hip_decoder* dc, int lane)
 }
 
 // one step of one lane (a decoder of up to 64 sequences has the single lane 0)
+#include "gten_decode_persist.h"
+
+static int persist_prepare(gten_hip_decoder* dc);
+
 static int enqueue_lane(gten_hip_decoder* dc, int lane)
 {
     g_exact_now = dc->exact;
+    // single sequence, Q8 activations: the whole step as one persistent launch (a family-restricted timing replay wants
+    // the launch chain's kernels)
+    if (dc->persist_on && dc->n_seq == 1 && !dc->exact && (g_only_family < 0 || g_only_family == KT_DEC_PERSIST)) {
+        if (int rc = persist_prepare(dc)) return rc;
+        if (dc->persist) return persist_launch<GTEN_Q4>(dc->persist);
+    }
     if (dc->n_seq > 1) {
         switch (dc->d.wdtype) {
         case GTEN_F16: return enqueue_multi<GTEN_F16>(dc, lane);
@@ -4210,6 +4222,7 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     dc->d = d;
     dc->n_seq = n_seq;
     dc->exact = g_decode_exact;
+    dc->persist_on = g_persist_on;
     {
         // Rows per lane: 128 where the folded W.x form runs eight row tiles per workgroup (k_dec_mmvh<.., 8, ..>: every expanded
         // weight fragment feeds eight matrix instructions and the weights are read once per 128 sequences), else 64 (f16 weights,
@@ -4298,7 +4311,78 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     if (int rc = rope_table(dh, &dc->rope)) return rc;
     GTR_CHECK(hipMalloc((void**)&dc->rope_now, S * (size_t)(dh / 2) * sizeof(float2)));
     GTR_CHECK(hipMemset(dc->rope_now, 0, S * (size_t)(dh / 2) * sizeof(float2)));
+    // the persistent step's state is allocated now: the first step may already be a stream capture
+    if (dc->persist_on && n_seq == 1 && !dc->exact)
+        if (int rc = persist_prepare(dc)) return rc;
     return 0;
+}
+
+// ---- the persistent step's state (gten_decode_persist.h): per-layer pointer table, granule buffers, control words
+static int g_cu_count = -1;
+static int persist_prepare(gten_hip_decoder* dc)
+{
+    if (dc->persist) return 0;
+    if (g_cu_count < 0) {
+        int dev = 0;
+        GTR_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        GTR_CHECK(hipGetDeviceProperties(&prop, dev));
+        g_cu_count = prop.multiProcessorCount;
+    }
+    const gten_hip_decoder_desc& d = dc->d;
+    if (!persist_supported(d, dc->n_seq, dc->n_chunks, g_cu_count)) { dc->persist_on = false; return 0; }
+    const int G = g_cu_count, E = d.n_embd, F = d.n_ffn, dh = E / d.n_heads, KV = dh * d.n_kv_heads;
+    auto* ps = new PersistState;
+    dc->persist = ps;
+    g_persist_all.push_back(ps);
+    std::vector<PLayer> tab((size_t)d.n_layers);
+    for (int l = 0; l < d.n_layers; l++) {
+        const gten_hip_layer_ptrs& L = dc->layers[l];
+        tab[l] = PLayer{(const uint8_t*)L.wq, (const uint8_t*)L.wk, (const uint8_t*)L.wv, (const uint8_t*)L.wo, (const uint8_t*)L.wgate,
+                        (const uint8_t*)L.wup, (const uint8_t*)L.wdown, (const uint16_t*)L.attn_norm, (const uint16_t*)L.ffn_norm,
+                        (uint8_t*)L.kcache, (uint8_t*)L.vcache};
+    }
+    GTR_CHECK(hipMalloc((void**)&ps->layers, tab.size() * sizeof(PLayer)));
+    GTR_CHECK(hipMemcpy(ps->layers, tab.data(), tab.size() * sizeof(PLayer), hipMemcpyHostToDevice));
+    GTR_CHECK(hipMalloc((void**)&ps->ctl, 64));
+    const unsigned ctl0[16] = {1u, 0u};
+    GTR_CHECK(hipMemcpy(ps->ctl, ctl0, 64, hipMemcpyHostToDevice));
+    PArgs& a = ps->args;
+    a.rpa = (E + 2 * KV + G - 1) / G; a.rpo = (E + G - 1) / G; a.rph = (d.n_vocab + G - 1) / G; a.rw = (a.rph + 7) / 8;
+    // granule buffers (8-byte {value, tag}), zeroed once: tag 0 never occurs (the epoch starts at 1)
+    const size_t n_q = (size_t)G * a.rpa, n_part = (size_t)d.n_heads * dc->n_chunks * 66, n_att = (size_t)E, n_proj = (size_t)G * a.rpo,
+                 n_act = (size_t)10 * (F / 32) + 8, n_down = (size_t)G * a.rpo, n_best = (size_t)2 * G;
+    const size_t total = n_q + n_part + n_att + n_proj + n_act + n_down + n_best + 64;
+    GTR_CHECK(hipMalloc((void**)&ps->gran, total * 8));
+    GTR_CHECK(hipMemset(ps->gran, 0, total * 8));
+    pu64* p = ps->gran;
+    a.gq = p; p += n_q; a.gpart = p; p += n_part; a.gatt = p; p += n_att; a.gproj = p; p += n_proj;
+    a.gact = p; p += (n_act + 7) / 8 * 8; a.gdown = p; p += n_down; a.gbest = p;
+    if (const char* e = getenv("GTEN_HIP_PERSIST_STAMPS"); e && e[0] == '1') {
+        ps->n_stamps = d.n_layers * 20 + 8;
+        GTR_CHECK(hipMalloc((void**)&ps->stamps, (size_t)(d.n_layers * 20 + 8) * 4));
+        GTR_CHECK(hipMemset(ps->stamps, 0, (size_t)(d.n_layers * 20 + 8) * 4));
+    }
+    a.layers = ps->layers; a.step = dc->step; a.tokens = dc->tokens; a.result = dc->result;
+    a.embed = (const uint8_t*)d.embed; a.final_norm = (const uint16_t*)d.final_norm; a.lm_head = (const uint8_t*)d.lm_head;
+    a.logits = d.logits; a.rope = dc->rope; a.ctl = ps->ctl; a.stamps = ps->stamps;
+    a.n_layers = d.n_layers; a.E = E; a.F = F; a.KV = KV; a.n_heads = d.n_heads; a.n_kv = d.n_kv_heads; a.n_vocab = d.n_vocab;
+    a.max_ctx = d.max_ctx; a.n_chunks = dc->n_chunks; a.kv_pitch = (int)gten_hip_row_bytes(d.adtype, KV);
+    ps->grid = G;
+    ps->smem = persist_smem();
+    return 0;
+}
+static void persist_free(gten_hip_decoder* dc)
+{
+    if (!dc->persist) return;
+    PersistState* ps = dc->persist;
+    g_persist_all.erase(std::remove(g_persist_all.begin(), g_persist_all.end(), ps), g_persist_all.end());
+    if (ps->layers) hipFree(ps->layers);
+    if (ps->ctl) hipFree(ps->ctl);
+    if (ps->gran) hipFree(ps->gran);
+    if (ps->stamps) hipFree(ps->stamps);
+    delete ps;
+    dc->persist = nullptr;
 }
 
 extern "C" {
@@ -4328,6 +4412,7 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
                     dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now, dc->dummy_kv};
     for (void* b : bufs) if (b) hipFree(b);
+    persist_free(dc);
     for (int g = 1; g < DEC_MAX_LANES; g++) {
         if (dc->lane_stream[g]) { hipStreamSynchronize(dc->lane_stream[g]); hipStreamDestroy(dc->lane_stream[g]); }
         if (dc->lane_join[g]) hipEventDestroy(dc->lane_join[g]);
@@ -4764,6 +4849,38 @@ int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int re
     hipGraphExecDestroy(ge); hipGraphDestroy(g);
     *avg_us = (double)ms * 1e3 / ((double)reps * (double)n_nodes);
     if (launches_per_replay) *launches_per_replay = (int)n_nodes;
+    return 0;
+}
+
+/* the persistent step (gten_decode_persist.h), over every live decoder of the process: how many run it, how many of its
+ * launches were enqueued so far, the abort code of a poll that gave up (0 = none; cleared by the call -- the step's results
+ * are invalid), and workgroup 0's phase stamps of the newest such decoder (10 ns ticks; GTEN_HIP_PERSIST_STAMPS=1 at its
+ * creation, else zeros).  Waits for the stream. */
+int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsigned* abort_code, unsigned* stamps_host, int n_stamps)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(n_decoders && launches && abort_code, "persist_status: null argument");
+    GTR_CHECK(hipStreamSynchronize(stream()));
+    *n_decoders = (int)g_persist_all.size();
+    *launches = g_persist_launches;
+    *abort_code = 0;
+    for (PersistState* ps : g_persist_all) {
+        unsigned ctl[2];
+        GTR_CHECK(hipMemcpy(ctl, ps->ctl, 8, hipMemcpyDeviceToHost));
+        if (ctl[1]) {
+            *abort_code = ctl[1];
+            const unsigned z = 0;
+            GTR_CHECK(hipMemcpy(ps->ctl + 1, &z, 4, hipMemcpyHostToDevice));
+        }
+    }
+    if (stamps_host && n_stamps > 0) {
+        for (int i = 0; i < n_stamps; i++) stamps_host[i] = 0;
+        for (auto it = g_persist_all.rbegin(); it != g_persist_all.rend(); ++it)
+            if ((*it)->stamps) {
+                GTR_CHECK(hipMemcpy(stamps_host, (*it)->stamps, (size_t)std::min((*it)->n_stamps, n_stamps) * 4, hipMemcpyDeviceToHost));
+                break;
+            }
+    }
     return 0;
 }
 

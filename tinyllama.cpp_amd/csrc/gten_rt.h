@@ -47,7 +47,7 @@ int rope_table(int d_head, const float2** out);
 enum {
     KT_PACK = 0, KT_EMBED, KT_MATMUL, KT_RMSNORM, KT_ROPE, KT_ELEMWISE, KT_ATTN,
     KT_DEC_GEMV_QKV, KT_DEC_ATTN_SCORE, KT_DEC_ATTN_PV, KT_DEC_GEMV_O, KT_DEC_GEMV_GATEUP, KT_DEC_GEMV_DOWN,
-    KT_DEC_GEMV_HEAD, KT_DEC_ARGMAX, KT_MATMUL_MFMA, KT_DEC_STAGE, KT_ATTN_TILED, KT_COUNT
+    KT_DEC_GEMV_HEAD, KT_DEC_ARGMAX, KT_MATMUL_MFMA, KT_DEC_STAGE, KT_ATTN_TILED, KT_DEC_PERSIST, KT_COUNT
 };
 
 // gten_mfma.hip: ops::matmul_2d for >= GTEN_MFMA_MIN_ROWS new rows

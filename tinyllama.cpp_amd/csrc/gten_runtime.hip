@@ -251,7 +251,7 @@ const char* gten_hip_prof_family_name(int family)
     static const char* names[KT_COUNT] = {
         "pack_weight", "token_embed", "matmul_2d", "rms_norm", "rotary_emb", "elementwise", "qkv_attn",
         "decode_gemv_qkv", "decode_attn_score", "decode_attn_pv", "decode_gemv_o", "decode_gemv_gateup",
-        "decode_gemv_down", "decode_gemv_head", "decode_argmax", "matmul_2d_mfma", "decode_stage", "qkv_attn_tiled"};
+        "decode_gemv_down", "decode_gemv_head", "decode_argmax", "matmul_2d_mfma", "decode_stage", "qkv_attn_tiled", "decode_persistent"};
     return (family >= 0 && family < KT_COUNT) ? names[family] : nullptr;
 }
 

@@ -85,7 +85,7 @@ class GtenHip:
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
         "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_block_rows", "gten_hip_set_block_rows", "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
-        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact", "gten_hip_set_decode_exact", "gten_hip_set_row_segments", "gten_hip_row_segments_ok", "gten_hip_copy_ranges",
+        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact", "gten_hip_set_decode_exact", "gten_hip_set_decode_persistent", "gten_hip_persist_status", "gten_hip_set_row_segments", "gten_hip_row_segments_ok", "gten_hip_copy_ranges",
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
         # the export check covers the whole header
         "gten_hip_decoder_create", "gten_hip_decoder_destroy", "gten_hip_decoder_set_tokens",
@@ -131,6 +131,8 @@ class GtenHip:
         self._block_rows = _sig(L, "gten_hip_block_rows", ci, [C.POINTER(BlockDesc), ci, ci])
         self._set_block_rows = _sig(L, "gten_hip_set_block_rows", ci, [ci])
         self._decode_exact = _sig(L, "gten_hip_set_decode_exact", ci, [ci])
+        self._decode_persistent = _sig(L, "gten_hip_set_decode_persistent", ci, [ci])
+        self._persist_status = _sig(L, "gten_hip_persist_status", ci, [C.POINTER(ci), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.c_void_p, ci])
         self._set_row_segments = _sig(L, "gten_hip_set_row_segments", ci, [C.c_void_p, ci])
         self._copy_ranges = _sig(L, "gten_hip_copy_ranges", ci, [C.c_void_p, ci])
         self.initialised = False
@@ -181,6 +183,17 @@ class GtenHip:
     def set_decode_exact(self, on):
         """exact forms of the decode step for decoders created from now on (include/gten_hip.h)"""
         self._check(self._decode_exact(1 if on else 0))
+
+    def set_decode_persistent(self, on):
+        """single-sequence q4 decoders created from now on: the step as ONE persistent launch, or the launch chain (default)"""
+        self._check(self._decode_persistent(1 if on else 0))
+
+    def persist_status(self, n_stamps=0):
+        """(decoders running the persistent step, launches enqueued, abort code [cleared], stamps) -- waits for the stream"""
+        nd, nl, ab = C.c_int(0), C.c_ulonglong(0), C.c_uint(0)
+        st = (C.c_uint * max(n_stamps, 1))()
+        self._check(self._persist_status(C.byref(nd), C.byref(nl), C.byref(ab), C.cast(st, C.c_void_p) if n_stamps else None, n_stamps))
+        return nd.value, nl.value, ab.value, list(st)[:n_stamps]
 
     def set_prefill_exact(self, on):
         """prompt-sized W.x with quantized weights: exact form (scalar-build order, bit for bit) instead of the fast one"""
