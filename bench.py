@@ -449,6 +449,10 @@ def main(argv=None):
     os.environ.setdefault("GTEN_HIP_DEVICE", str(local_rank))
     # weight synthesis is OpenMP code on the host: share the cores between the ranks of this node
     os.environ.setdefault("OMP_NUM_THREADS", str(max(4, (os.cpu_count() or 8) // max(world, 1))))
+    # ... and generate the synthetic weights ONCE per node: the first replica to get there writes them to /dev/shm, the others
+    # read them (host/tinyllama_model.h load_synthetic_cached); rank 0 removes the files when it is done
+    if world > 1 and os.path.isdir("/dev/shm"):
+        os.environ.setdefault("GTEN_SYNTH_CACHE_DIR", "/dev/shm")
     stub = args.engine == "stub"
 
     import torch
@@ -574,20 +578,47 @@ def worker(args, rank, local_rank, world, dist):
     sharded = None
     if dist is not None and world > 1 and fused and args.serve > 0 and (args.serve_slots or args.wide_streams) > 1 and not args.brief:
         S = args.serve_slots or args.wide_streams
-        if stub:
-            sbatch = StubBatch()
-            make_tokens = lambda n, j: np.random.default_rng(rep_seed(999, j)).integers(3, 31993, n).astype(np.int32)
+        # A failure on ONE rank (out of memory creating the slots, a serve error) must not take the already measured `value`
+        # with it nor leave the other ranks in a collective: every rank reports whether it got this far, the leg runs only
+        # if all did, and whatever it raises is recorded instead of propagated.
+        sbatch, err = None, None
+        try:
+            if stub:
+                sbatch = StubBatch()
+                make_tokens = lambda n, j: np.random.default_rng(rep_seed(999, j)).integers(3, 31993, n).astype(np.int32)
+            else:
+                sbatch = host.batch(cfg, S)
+                sbatch.load_synthetic(args.seed)
+                make_tokens = lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j))
+        except Exception as e:                       # noqa: BLE001 -- recorded below
+            err = "%s: %s" % (type(e).__name__, e)
+        okf = torch.tensor([0.0 if err else 1.0], device=ddev) if ddev else torch.tensor([0.0 if err else 1.0])
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if float(okf.item()) < 0.5:
+            sharded = {"error": err or "another rank could not set the leg up"}
         else:
-            sbatch = host.batch(cfg, S)
-            sbatch.load_synthetic(args.seed)
-            make_tokens = lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j))
-        sharded = sharded_serving(sbatch, S, args.serve * world, make_tokens, rep, rank, world, dist, ddev, sync, args.serve_slice)
-        sbatch.close()
+            try:
+                sharded = sharded_serving(sbatch, S, args.serve * world, make_tokens, rep, rank, world, dist, ddev, sync, args.serve_slice)
+            except Exception as e:                   # noqa: BLE001
+                sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+        if sbatch is not None:
+            try:
+                sbatch.close()
+            except Exception:                        # noqa: BLE001
+                pass
     # the replicas are done with each other: every rank leaves the process group here (rank 0 goes on alone with the
     # roofline / CPU-baseline legs, the others exit and free their host cores)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and os.environ.get("GTEN_SYNTH_CACHE_DIR"):          # every replica has read the shared weights by now
+            import glob
+            for f in glob.glob(os.path.join(os.environ["GTEN_SYNTH_CACHE_DIR"], "gten_synth_s*")):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+            os.environ.pop("GTEN_SYNTH_CACHE_DIR", None)                  # rank 0's later models generate their own
     if rank != 0:
         model.close()
         return 0

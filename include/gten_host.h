@@ -94,7 +94,8 @@ int  gten_host_batch_set_weight(gten_host_batch* b, int idx, const void* bytes, 
 /* prompt of sequence `seq` through the operator path (fills its caches); logits_out may be NULL */
 int  gten_host_batch_prefill(gten_host_batch* b, int seq, const int32_t* tokens, int n, float* logits_out);
 /* SEVERAL prompts as segments of one row matrix (wide batches, >= 16 sequences; gten_hip_set_row_segments): prompt k =
- * tokens[starts[k] .. starts[k + 1]) (>= 16 ids each, 2048 in all, at most 16 prompts) onto the caches of sequence seqs[k];
+ * tokens[starts[k] .. starts[k + 1]) (>= 16 ids each, at most 2048 per prompt, 4096 in all, at most 32 prompts) onto the caches of sequence seqs[k] (every
+ * sequence at most once: a repeated one returns -1);
  * logits_out, when given, is [n_prompts][n_vocab].  Returns -2 when this batch does not process prompts that way. */
 int  gten_host_batch_prefill_many(gten_host_batch* b, const int32_t* seqs, const int32_t* tokens, const int32_t* starts, int n_prompts, float* logits_out);
 /* greedy generation of every sequence with the sampler on the device: prompts is [n_seq][max_prompt] (sequence q uses its

@@ -133,6 +133,14 @@ int gten_hip_matmul_2d(const void* x, int, size_t, const void*, int, void* out, 
 }
 int gten_hip_set_prefill_exact(int) { return 0; }
 int gten_hip_set_decode_exact(int) { return 0; }
+int gten_hip_set_decode_persistent(int) { return 0; }
+int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsigned* abort_code, unsigned*, int)
+{
+    if (n_decoders) *n_decoders = 0;
+    if (launches) *launches = 0;
+    if (abort_code) *abort_code = 0;
+    return 0;
+}
 int gten_hip_row_segments_ok(int, int, int, int, int, int) { return g_block_rows; }
 int gten_hip_set_row_segments(const int32_t* starts, int n)
 {

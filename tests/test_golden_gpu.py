@@ -176,4 +176,11 @@ def test_long_context_probe_q4(hip, full_golden):
         print(f"n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} (std {std:.3f}) "
               f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} scalar {int(g[f'long.q4.n{n}.top_ids.scalar'][0])}")
         assert rms <= 1.35 * own_rms and mx <= 0.5, (n, rms, own_rms, mx)
+        # ... and the reference's top-1 wherever its own top-1 / top-2 gap is clear (the fixture's gaps at these
+        # lengths are 0.02-0.19 on synthetic weights, so this seldom binds -- at n = 257 the fused step's top-1 differs from
+        # both reference builds inside a gap of 0.02 -- but the rule is the rule)
+        gap = float(g[f"long.q4.n{n}.top_logits"][0] - g[f"long.q4.n{n}.top_logits"][1])
+        print(f"      reference gap {gap:.3f}; margin used: rms {rms / (1.35 * own_rms):.2f} of the bar, max {mx / 0.5:.2f}")
+        if gap > 0.5 * max(std / 0.91, 1.0):
+            assert int(np.argmax(lg)) == int(ids[0]), (n, gap)
     m.close()

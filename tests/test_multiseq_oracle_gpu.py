@@ -74,7 +74,7 @@ def full_golden():
     return np.load(path)
 
 
-@pytest.mark.parametrize("name,wd,ad,S", [m + (64,) for m in MODES()] + [m + (S,) for m in MODES() if m[0] == "q4" for S in (128, 256)])
+@pytest.mark.parametrize("name,wd,ad,S", [m + (64,) for m in MODES()] + [m + (S,) for m in MODES() if m[0] == "q4" for S in (128, 256, 384, 512)])
 def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name, wd, ad, S):
     """TinyLlama-1.1B, 64 sequences sharing the weight passes: every slot carries the reference's golden token stream
     (15-id prompt through the slot's operator path, then 23 teacher-forced steps of the whole batch on the matrix-core
@@ -107,52 +107,73 @@ def test_full_size_64_sequences_against_reference_golden(hip, full_golden, name,
         return rms, mx
 
     worst = [0.0, 0.0]
+    # (up to 256 sequences EVERY slot is held; three and four lanes of 128 rows: both sides of every lane seam and the ends)
+    held = range(S) if S <= 256 else sorted({0, 1, 127, 128, 255, 256, 383, 384, S - 1} & set(range(S)))
     for q in range(S):
-        lg = batch.prefill(q, toks[:15])
-        hold(0, lg, (name, "prefill", q))
+        lg = batch.prefill(q, toks[:15], want=(q in held))
+        if q in held:
+            hold(0, lg, (name, "prefill", q))
         batch.decode_begin(q, toks)
     for step in range(1, steps):
         n = 15 + step
         batch.decode_step(n, True)
-        for q in range(S):
+        for q in held:
             rms, mx = hold(step, batch.logits(q), (name, "slot", q, "step", step))
             worst = [max(worst[0], rms), max(worst[1], mx)]
             assert batch.decode_result(q, n) == int(np.argmax(batch.logits(q)))
     batch.close()
-    print(f"{name} S={S} full size: worst rms {worst[0]:.4f} max {worst[1]:.4f} over {S} slots x {steps - 1} steps")
+    print(f"{name} S={S} full size: worst rms {worst[0]:.4f} max {worst[1]:.4f} over {len(held)} slots x {steps - 1} steps")
 
 
-@pytest.mark.parametrize("S", [64, 128])
-def test_wide_path_long_context_probe_q4(hip, full_golden, S):
-    """the 64-sequence path -- and a lane of 128 rows -- at the BASELINE.json metric point: every slot steps the long.q4 token
-    stream from n = 1 to n = 2048; slots 0 / 31 / S - 1 are held to the reference's probe at n = 257, 1024, 2047, 2048 with the
-    yardstick of tests/test_golden_gpu.py::test_long_context_probe_q4 (the reference's own AVX-vs-scalar spread at that length)"""
-    g = full_golden
-    if "long.q4.ns" not in g:
+@pytest.fixture(scope="module")
+def extra_golden():
+    path = os.path.join(G, "full_extra_golden.npz")
+    if not os.path.exists(path):
+        pytest.skip("full_extra_golden.npz not generated")
+    return np.load(path)
+
+
+@pytest.mark.parametrize("name,wd,ad,S", [m + (S,) for m in MODES() if m[0] == "q4" for S in (64, 128)] + [m + (64,) for m in MODES() if m[0] != "q4"])
+def test_wide_path_long_context_probe(hip, full_golden, extra_golden, name, wd, ad, S):
+    """the 64-sequence path -- and, q4, a lane of 128 rows -- at the BASELINE.json metric point: every slot steps the reference's
+    long-context token stream from n = 1 to n = 2048; slots 0 / 31 / S - 1 are held to the reference's probe at n = 257, 1024,
+    2047, 2048.  q4 / q8: the yardstick of tests/test_golden_gpu.py::test_long_context_probe_q4 (1.35 x the reference's own
+    AVX-vs-scalar spread at that length, max <= 0.5; DESIGN.md section 5) plus the reference's top-1 wherever its gap is clear;
+    f16: max |dlogit| inside the 0.03 band and the reference's top-1 unless its gap is below 0.03 (tests/test_prefill_gpu.py)."""
+    g = full_golden if name == "q4" else extra_golden
+    if f"long.{name}.ns" not in g:
         pytest.skip("long-context probe not in the fixture")
     pkg = load_package()
     host = pkg.load_host()
-    cfg = host.default_config(Q4, Q8)
+    cfg = host.default_config(wd, ad)
     batch = host.batch(cfg, S)
     batch.load_synthetic(int(g["seed"][0]))
     toks = host.synthetic_tokens(2048, seed=int(g["token_seed"][0]))
     for q in range(S):
         batch.decode_begin(q, toks)
-    ns = [int(n) for n in g["long.q4.ns"]]
+    ns = [int(n) for n in g[f"long.{name}.ns"]]
     probe = g["probe_ids"]
     for n in range(1, 2049):
         batch.decode_step(n, True)
         if n not in ns:
             continue
-        own = g[f"long.q4.n{n}.probes"] - g[f"long.q4.n{n}.probes.scalar"]
+        own = g[f"long.{name}.n{n}.probes"] - g[f"long.{name}.n{n}.probes.scalar"]
         own_rms = float(np.sqrt((own * own).mean()))
-        ids = g[f"long.q4.n{n}.top_ids"]
-        ref_vals = np.concatenate([g[f"long.q4.n{n}.top_logits"], g[f"long.q4.n{n}.probes"]])
+        ids = g[f"long.{name}.n{n}.top_ids"]
+        ref_vals = np.concatenate([g[f"long.{name}.n{n}.top_logits"], g[f"long.{name}.n{n}.probes"]])
+        std = float(g[f"long.{name}.n{n}.stats"][1])
+        gap = float(g[f"long.{name}.n{n}.top_logits"][0] - g[f"long.{name}.n{n}.top_logits"][1])
         for q in (0, 31, S - 1):
             lg = batch.logits(q)
             d = np.concatenate([lg[ids], lg[probe]]) - ref_vals
             rms, mx = float(np.sqrt((d * d).mean())), float(np.abs(d).max())
-            print(f"S={S} slot {q} n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} "
-                  f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} scalar {int(g[f'long.q4.n{n}.top_ids.scalar'][0])}")
-            assert rms <= 1.35 * own_rms and mx <= 0.5, (q, n, rms, own_rms, mx)
+            print(f"{name} S={S} slot {q} n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} "
+                  f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} scalar {int(g[f'long.{name}.n{n}.top_ids.scalar'][0])} (gap {gap:.3f})")
+            if name == "f16":
+                assert mx <= 0.03 * max(std / 0.91, 1.0), (q, n, mx)
+                assert int(np.argmax(lg)) == int(ids[0]) or gap < 0.03, (q, n, gap)
+            else:
+                assert rms <= 1.35 * own_rms and mx <= 0.5, (q, n, rms, own_rms, mx)
+                if gap > 0.5 * max(std / 0.91, 1.0):
+                    assert int(np.argmax(lg)) == int(ids[0]), (q, n, gap)
     batch.close()

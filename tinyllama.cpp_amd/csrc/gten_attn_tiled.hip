@@ -49,8 +49,9 @@ __device__ __forceinline__ float row16_max(float v)
     asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
-        : "+v"(v));
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"                       // ... and behind the LAST write too: whatever the compiler places next (a DPP or
+        : "+v"(v));                     // readlane consumer of v) gets its wait states -- it pads nothing behind an asm
     return v;
 }
 // the first four steps of wave_sum(): every lane of a 16-lane row ends with the row's sum

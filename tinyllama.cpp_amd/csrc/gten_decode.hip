@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(512) void k_dec_mmv(const int8_t* __restrict__ a_aq
 // the activations as f16(q * da) fragments, a weight fragment becomes f16((n - 7) * dw) as it leaves the slab (once per
 // block and feature tile, shared by the row tiles), and v_mfma_f32_16x16x32_f16 accumulates ACROSS the blocks of a wave's K
 // slice: no delta table, no per-block arithmetic on the outputs.  One fp16 rounding per operand element (relative 2^-11);
-// the sequences' logits stay inside the wide path's band (tests/test_multiseq_oracle_gpu.py).  GTEN_HIP_MMV_EXACT=1: k_dec_mmv.
+// the sequences' logits stay inside the wide path's band (tests/test_multiseq_oracle_gpu.py).  gten_hip_set_decode_exact(1): k_dec_mmv.
 typedef _Float16 mmvh_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 mmvh_h8 __attribute__((ext_vector_type(8)));
 typedef float mmvh_f4 __attribute__((ext_vector_type(4)));
@@ -3879,13 +3879,15 @@ static int launch_mmvh_silu(int tag, const uint16_t* ah, const void* wgate, cons
 {
     constexpr int WQ = (WT == GTEN_F16) ? GTEN_Q8 : WT;
     GTR_REQUIRE(n_ffn % 32 == 0 && d_in % 256 == 0, "decoder: FFN %d x %d does not tile", n_ffn, d_in);
-    const size_t nbs = (size_t)d_in / 32, rt = (S + 15) / 16;
+    // (row tiles of the KERNEL instance: five to eight tiles run the eight-tile instance, whose LDS layout and fragment stride
+    //  are those of eight tiles -- and the staging launches must have written eight, so only full 128-row lanes take it)
+    const size_t nbs = (size_t)d_in / 32, rt_s = (S + 15) / 16, rt = rt_s <= 4 ? rt_s : 8;
+    GTR_REQUIRE(rt_s <= 4 || rt_s == 8, "decoder: a lane of %d rows (one to four row tiles, or exactly eight)", S);
     const size_t smem = std::max((size_t)64 * nbs * (WQ == GTEN_Q4 ? 16 : 32), (size_t)8 * 16 * rt * 64) + 64 * nbs * 2 + 4 * 16 * rt * 16 * 4;
     GTR_REQUIRE(smem <= 150 * 1024 && nbs * (WQ == GTEN_Q4 ? 1 : 2) <= (size_t)32 * (MMV_MAXP / 4), "decoder: the FFN slab of d_in %d does not fit", d_in);
     const MmvRest rest{wup, nullptr, n_ffn, 0, 0};
     const dim3 grid(n_ffn / 32, 1);
 #define MMVH_S(RT_) DEC_LAUNCH(tag, (k_dec_mmvh<WQ, RT_, 4, true>), grid, dim3(512), smem, ah, wgate, (float*)out_frag, d_in, n_ffn, 0, S, 2, rest)
-    GTR_REQUIRE(rt <= 8, "decoder: %d rows in one lane (at most 128)", S);
     switch ((int)rt) {
     case 1: MMVH_S(1); break;
     case 2: MMVH_S(2); break;
@@ -3901,6 +3903,8 @@ template <int WT>
 static int launch_mmvh(int tag, const MmvhArgs& a)
 {
     GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && a.S <= 128, "decoder: skinny W.x wants d_in %% 256 == 0 and <= 128 rows");
+    GTR_REQUIRE((a.S + 15) / 16 <= 4 || (a.S + 15) / 16 == 8, "decoder: a lane of %d rows (one to four row tiles, or exactly eight: the eight-tile "
+                "instance reads the staging with a stride of eight tiles)", a.S);
     GTR_REQUIRE((size_t)16 * (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) <= (size_t)MMV_MAXP * 512 * 16, "decoder: d_in %d too long for the weight slab", a.d_in);
     for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
     constexpr int WQ = (WT == GTEN_F16) ? GTEN_Q8 : WT;
@@ -4372,17 +4376,17 @@ static int persist_prepare(gten_hip_decoder* dc)
     ps->smem = persist_smem();
     return 0;
 }
-static void persist_free(gten_hip_decoder* dc)
+static hipError_t persist_free(gten_hip_decoder* dc)
 {
-    if (!dc->persist) return;
+    if (!dc->persist) return hipSuccess;
     PersistState* ps = dc->persist;
     g_persist_all.erase(std::remove(g_persist_all.begin(), g_persist_all.end(), ps), g_persist_all.end());
-    if (ps->layers) hipFree(ps->layers);
-    if (ps->ctl) hipFree(ps->ctl);
-    if (ps->gran) hipFree(ps->gran);
-    if (ps->stamps) hipFree(ps->stamps);
+    hipError_t first = hipSuccess;
+    for (void* b : {(void*)ps->layers, (void*)ps->ctl, (void*)ps->gran, (void*)ps->stamps})
+        if (b) { const hipError_t e = hipFree(b); if (e != hipSuccess && first == hipSuccess) first = e; }
     delete ps;
     dc->persist = nullptr;
+    return first;
 }
 
 extern "C" {
@@ -4403,21 +4407,28 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     if (!dc) return 0;
     GTR_NEED_INIT();
     GTR_CHECK(hipStreamSynchronize(stream()));
-    if (dc->exec) hipGraphExecDestroy(dc->exec);
-    if (dc->graph) hipGraphDestroy(dc->graph);
-    if (dc->exec_k) hipGraphExecDestroy(dc->exec_k);
-    if (dc->graph_k) hipGraphDestroy(dc->graph_k);
+    // (every release is attempted; the first failure is what the call reports)
+    hipError_t first = hipSuccess;
+    auto rel = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    if (dc->exec) rel(hipGraphExecDestroy(dc->exec));
+    if (dc->graph) rel(hipGraphDestroy(dc->graph));
+    if (dc->exec_k) rel(hipGraphExecDestroy(dc->exec_k));
+    if (dc->graph_k) rel(hipGraphDestroy(dc->graph_k));
     void* bufs[] = {dc->ids_stage, dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
                     dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now, dc->dummy_kv};
-    for (void* b : bufs) if (b) hipFree(b);
-    persist_free(dc);
+    for (void* b : bufs) if (b) rel(hipFree(b));
+    rel(persist_free(dc));
     for (int g = 1; g < DEC_MAX_LANES; g++) {
-        if (dc->lane_stream[g]) { hipStreamSynchronize(dc->lane_stream[g]); hipStreamDestroy(dc->lane_stream[g]); }
-        if (dc->lane_join[g]) hipEventDestroy(dc->lane_join[g]);
+        if (dc->lane_stream[g]) { rel(hipStreamSynchronize(dc->lane_stream[g])); rel(hipStreamDestroy(dc->lane_stream[g])); }
+        if (dc->lane_join[g]) rel(hipEventDestroy(dc->lane_join[g]));
     }
-    if (dc->lane_fork) hipEventDestroy(dc->lane_fork);
+    if (dc->lane_fork) rel(hipEventDestroy(dc->lane_fork));
+    if (first != hipSuccess) {
+        delete dc;
+        return fail((int)first, "decoder_destroy: %s", hipGetErrorString(first));
+    }
     delete dc;
     return 0;
 }
@@ -4710,9 +4721,12 @@ int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seq
     if (count == 0) return 0;
     const size_t L = (size_t)dc->d.n_layers;
     const size_t cache_bytes = (size_t)dc->d.max_ctx * gten_hip_row_bytes(dc->d.adtype, (dc->d.n_embd / dc->d.n_heads) * dc->d.n_kv_heads);
+    std::vector<char> seen((size_t)dc->n_seq, 0);
     for (int i = 0; i < count; i++) {
         const int q = seqs[i];
         GTR_REQUIRE(q >= 0 && q < dc->n_seq, "decoder_slots_apply: sequence %d outside [0, %d)", q, dc->n_seq);
+        GTR_REQUIRE(!seen[(size_t)q], "decoder_slots_apply: sequence %d appears twice (two step words / cache rows for one slot)", q);
+        seen[(size_t)q] = 1;
         GTR_REQUIRE(n_first[i] >= 0 && n_first[i] <= dc->d.max_ctx, "decoder_slots_apply: n_first=%d outside [0, %d]", n_first[i], dc->d.max_ctx);
         GTR_REQUIRE(n_first[i] == 0 || n_last[i] == 0 || (n_last[i] >= n_first[i] && n_last[i] <= dc->d.max_ctx), "decoder_slots_apply: n_last=%d outside [%d, %d]",
                     n_last[i], n_first[i], dc->d.max_ctx);

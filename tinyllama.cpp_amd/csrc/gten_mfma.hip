@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     unsigned pd_src[WP], pd_hi[WP], w16_dst[WP], w16_pi[WP], w16_fm[WP];
 #pragma unroll
     for (int k = 0; k < C::W_PIECES; k++) {
-        const int p = threadIdx.x + 256 * k, pr = WROW / 16, f = p / pr, c = p % pr;
+        constexpr int pr = (WROW / 16) > 0 ? WROW / 16 : 1;      // (f16 weights have no packed rows: W_PIECES is 0 and this loop is empty)
+        const int p = threadIdx.x + 256 * k, f = p / pr, c = p % pr;
         const unsigned frow = (unsigned)min(colw + f, d_out - 1);
         const int blk = (WT == GTEN_Q4) ? c : c % KB, pl = (WT == GTEN_Q4) ? 0 : c / KB;
         const unsigned di = frow * nb + blk;                 // + s * KB per stage: KB is even, the parity is the piece's own

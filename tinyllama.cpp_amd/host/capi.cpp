@@ -236,6 +236,8 @@ int gten_host_batch_prefill_many(gten_host_batch* b, const int32_t* seqs, const 
     for (int k = 0; k < n_prompts; k++) {
         const int len = starts[k + 1] - starts[k];
         if (seqs[k] < 0 || seqs[k] >= b->batch->n_seq() || len < 16 || len > b->cfg.max_ctx || starts[k + 1] > TinyLlamaBatch::kPreRows) return -1;
+        for (int j = 0; j < k; j++)
+            if (seqs[j] == seqs[k]) return -1;        // two prompts onto ONE slot's caches: the copy launch would race
         prompts[(size_t)k].assign(tokens + starts[k], tokens + starts[k + 1]);
         ps.push_back(&prompts[(size_t)k]);
         slots.push_back(seqs[k]);

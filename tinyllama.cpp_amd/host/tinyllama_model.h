@@ -7,6 +7,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -251,15 +256,68 @@ public:
 
     // Synthetic weights (host/synth.h): generated, quantized like the reference
     // converter, and staged to HBM tensor by tensor.
+    // GTEN_SYNTH_CACHE_DIR (bench.py --gpus N sets it to /dev/shm): the replicas of one node generate the synthetic weights
+    // ONCE -- the first process to create the lock file generates them (OpenMP over all cores, seconds) and publishes the
+    // file with a rename, the others wait for it and read it -- instead of N OpenMP generations at the same time.
     void load_synthetic(uint64_t seed)
     {
         Timer load_timer{&load_time};
+        const char* dir = std::getenv("GTEN_SYNTH_CACHE_DIR");
+        if (dir && dir[0] && load_synthetic_cached(dir, seed)) return;
         std::vector<float> f32;
         for (int i = 0; i < n_weights(); i++) {
             Tensor& w = weight(i);
             synth_weight_bytes(params, dtype_, seed, i, f32, w.data_ptr<uint8_t>(), w.nbytes());
             w.device_weight();
         }
+    }
+
+    bool load_synthetic_cached(const char* dir, uint64_t seed)
+    {
+        size_t total = 0;
+        for (int i = 0; i < n_weights(); i++) total += weight(i).nbytes();
+        char base[512];
+        std::snprintf(base, sizeof(base), "%s/gten_synth_s%llu_w%d_a%d_e%d_f%d_l%d_v%d_h%d_g%d.bin", dir, (unsigned long long)seed,
+                      (int)dtype_.wdtype, (int)dtype_.adtype, params.n_embd, params.n_ffn, params.n_layers, params.n_vocab, params.n_heads,
+                      params.n_query_groups);
+        const std::string path = base, lock = path + ".lock", tmp = path + ".tmp";
+        auto ready = [&]() { struct stat st; return ::stat(path.c_str(), &st) == 0 && (size_t)st.st_size == total; };
+        if (!ready()) {
+            const int fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
+            if (fd >= 0) {                                       // this process generates
+                ::close(fd);
+                std::FILE* f = std::fopen(tmp.c_str(), "wb");
+                bool ok = f != nullptr;
+                std::vector<float> f32;
+                for (int i = 0; i < n_weights(); i++) {
+                    Tensor& w = weight(i);
+                    synth_weight_bytes(params, dtype_, seed, i, f32, w.data_ptr<uint8_t>(), w.nbytes());
+                    if (ok) ok = std::fwrite(w.data_ptr<uint8_t>(), 1, w.nbytes(), f) == w.nbytes();
+                    w.device_weight();
+                }
+                if (f) ok = (std::fclose(f) == 0) && ok;
+                if (ok) std::rename(tmp.c_str(), path.c_str());
+                else std::remove(tmp.c_str());
+                std::remove(lock.c_str());
+                return true;
+            }
+            for (int waited = 0; waited < 1200 && !ready(); waited++) {          // somebody else generates: up to two minutes
+                struct stat st;
+                if (::stat(lock.c_str(), &st) != 0 && !ready()) break;            // the generator gave up
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            if (!ready()) return false;
+        }
+        std::FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return false;
+        bool ok = true;
+        for (int i = 0; i < n_weights() && ok; i++) {
+            Tensor& w = weight(i);
+            ok = std::fread(w.data_ptr<uint8_t>(), 1, w.nbytes(), f) == w.nbytes();
+            if (ok) w.device_weight();
+        }
+        std::fclose(f);
+        return ok;                                               // (a short read: the caller generates everything again)
     }
 
     // shape of tensor idx: rows, cols, storage dtype
