@@ -90,6 +90,7 @@ def parse_args(argv=None):
                          "thousands instead of hundreds of thousands of launches")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (counter collection)")
     ap.add_argument("--no-lanes", action="store_true", help="skip the 256-sequence (lanes) leg")
+    ap.add_argument("--lane-skip", action="store_true", help="serving: a shared run leaves out lanes whose slots are all parked (A/B; measured slower)")
     ap.add_argument("--brief", action="store_true", help="only the metric line: no secondary legs, no CPU baseline")
     ap.add_argument("--curve", action="store_true",
                     help="with --gpus N > 1 under this file's own launcher: first run 1, 2, 4, ... < N replicas (brief) and "
@@ -159,6 +160,41 @@ def measured_traffic(mode, family):
             t.get("csrc_sha256_16"), csrc_fingerprint())
     v = t.get(mode, {}).get(family)
     return v, (t.get("source") if v is not None else "no counters for %s / %s in profiles/traffic.json" % (mode, family))
+
+
+def measured_counters(section):
+    """profiles/counters.json (tools/collect_counters.sh: PMC passes of the secondary legs' kernels), or (None, why) when it
+    is absent or was collected on other kernel sources"""
+    cpath = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(cpath):
+        return None, "profiles/counters.json absent"
+    try:
+        t = json.load(open(cpath))
+    except Exception as e:
+        return None, "profiles/counters.json unreadable: %r" % (e,)
+    if t.get("csrc_sha256_16") != csrc_fingerprint():
+        return None, "profiles/counters.json was collected on other kernel sources (%s, now %s): stale, not reported" % (
+            t.get("csrc_sha256_16"), csrc_fingerprint())
+    v = t.get(section)
+    return v, (t.get("source") if v is not None else "no %s section in profiles/counters.json" % section)
+
+
+MFMA_F16_PEAK_TFLOPS = 2500.0       # dense fp16 / bf16 matrix peak of MI355X (MI355X_MICROARCH.md; the 5 PF figure is 2:1 sparsity)
+
+
+def prefill_roofline(args, P, flops, wx_ms):
+    """the prompt GEMM (k_matmul_mfma) against the dense f16 matrix peak: achieved = linear-layer FLOPs (lm_head: last row only)
+    / the event-bracketed time of the W.x launches; mfma_busy_frac = the PMC share of matrix-pipe cycles (2048-id prompt)"""
+    if wx_ms <= 0:
+        return None
+    ach = (flops - 2.0 * 32003 * 2048 * (P - 1)) / (wx_ms * 1e-3) / 1e12
+    cnt, why = measured_counters("prefill2048") if args.mode == "q4" else (None, "counters are collected for q4")
+    gemm = (cnt or {}).get("k_matmul_mfma", {})
+    return {"bound": "mfma", "kernel": "k_matmul_mfma", "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "mfma_busy_frac": gemm.get("mfma_busy_frac"),
+            "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the GEMM's dispatches of a 2048-id prompt",
+            "attention_mfma_busy_frac": (cnt or {}).get("k_attn_tiled", {}).get("mfma_busy_frac"),
+            "traffic": None, "counters_source": why}
 
 
 def dropin_leg(host, cfg, args, toks, hip=None):
@@ -732,6 +768,34 @@ def worker(args, rank, local_rank, world, dist):
             med = float(np.median(per))
             out["per_step_synced"] = {"steps": K, "median_ms": round(med * 1e3, 4), "mean_ms": round(float(np.mean(per)) * 1e3, 4),
                                       "tok_s_from_median": round(1.0 / med, 1)}
+    # secondary: the same K steps as ONE persistent launch per step (csrc/gten_decode_persist.h: granule hand-offs instead of 113
+    # launch boundaries; the same bytes, tests/test_persist_gpu.py) -- measured slower than the launch chain on MI355X, reported
+    # beside `value`, never in it
+    if secondary and fused and args.mode == "q4" and use_graph:
+      with Leg(out, "persistent_step"):
+            hip.set_decode_persistent(True)
+            try:
+                pm = host.model(cfg)
+                pm.load_synthetic(args.seed)
+                pm.decode_begin(toks)
+            finally:
+                hip.set_decode_persistent(False)
+            n0 = N_CTX - K + 1
+            pm.decode_steps(1, n0 - 1, True)                     # fill the context through the persistent step itself
+            pm.decode_steps(n0, K, True); hip.sync()             # warm: the four-step graph
+            t0 = time.perf_counter()
+            pm.decode_steps(n0, K, True)
+            hip.sync()
+            dtp = time.perf_counter() - t0
+            nd, launches, ab, _ = hip.persist_status()
+            same = pm.decode_result(N_CTX) == model.decode_result(N_CTX) if total <= N_CTX - 1 else None
+            out["persistent_step"] = {"ms_per_step": round(dtp / K * 1e3, 4), "tok_s": round(K / dtp, 1), "decoders": nd, "launches": int(launches),
+                                      "abort_code": ab, "same_last_id_as_chain": same,
+                                      "vs_launch_chain": round((elapsed / K) / (dtp / K), 3),
+                                      "note": "gten_hip_set_decode_persistent(1): one workgroup per CU, 8-byte {value, tag} granules between "
+                                              "the phases of a block, weights requested ahead of the dependency chain; per-phase profile: "
+                                              "profiles/r04_persistent_phases.txt, edge costs: profiles/r04_microbench_edge.txt"}
+            pm.close()
     # secondary: the short-context window n in [16, 80) of the same single-sequence decode path
     if secondary and fused:
       with Leg(out, "short_ctx"):
@@ -780,11 +844,18 @@ def worker(args, rank, local_rank, world, dist):
                 fams[fam] = {"us": round(us, 2), "launches": per}
             except Exception:
                 pass                                 # a family this path does not launch
+        ach = bytes_step / (ms * 1e-3) / 1e9
+        cnt, why = measured_counters("lanes%d" % S) if args.mode == "q4" else (None, "counters are collected for q4")
         res = {"streams": S, "tok_s": round(S * K / dt, 1), "ms_per_step": round(ms, 4),
                "speedup_vs_single": round(S * K / dt / tok_s, 2),
-               "hbm": {"achieved": round(bytes_step / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+               "hbm": {"achieved": round(ach, 1), "unit": "GB/s",
                        "algorithmic_bytes_per_step": int(bytes_step),
                        "note": "weights once per step + one K/V history per sequence"},
+               # the WHOLE step against the HBM roof (its kernels are W.x launches and attention launches in about equal parts)
+               "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": (cnt or {}).get("hbm_bytes_per_step"),
+                            "traffic_unit": "HBM bytes per step (PMC)", "traffic_source": why,
+                            "algorithmic_bytes_per_step": int(bytes_step)},
                "gateup_kernel_us": fams["decode_gemv_gateup"]["us"], "kernel_us": fams,
                "last_tokens": [batch.decode_result(q, n_of(W + K - 1, total)) for q in range(min(S, 8))],
                "note": note}
@@ -846,6 +917,7 @@ def worker(args, rank, local_rank, world, dist):
     if secondary and fused and args.serve > 0 and (args.serve_slots or args.wide_streams) > 1:
       with Leg(out, "serving"):
             S = args.serve_slots or args.wide_streams
+            hip.set_lane_skip(args.lane_skip)
             batch = host.batch(cfg, S)
             batch.load_synthetic(args.seed)
             prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
@@ -858,11 +930,33 @@ def worker(args, rank, local_rank, world, dist):
                               "all_tok_s": round((st["new_tokens"] + st["prompt_tokens"]) / dt, 1),
                               "shared_steps": int(st["steps"]), "prefill_s": round(st["prefill_s"], 3), "decode_s": round(st["decode_s"], 3),
                               "slot_utilisation": round(st["new_tokens"] / max(st["steps"] * S, 1), 3),
+                              # (round 4: a lane whose slots are all parked sits a run out -- the share of COMPUTED slot-steps that made an id)
+                              "lane_steps": int(st.get("lane_steps", 0)), "lane_rows": int(st.get("lane_rows", 0)),
+                              "computed_slot_utilisation": round(st["new_tokens"] / max(st.get("lane_steps", 0) * st.get("lane_rows", 0), 1), 3),
                               "slice_steps": args.serve_slice,
                               "note": "sustained rates over the whole queue (prompts of 64..512 ids, 32..224 new ids each); prompt processing runs on "
                                       "the library's second stream BESIDE the slices of shared steps (prefill_s = host time spent in it, "
                                       "overlapped); a slot whose run ends inside a slice repeats its last step until the slice is over; "
                                       "slot_utilisation = new ids / (shared steps x slots)"}
+            # the queue against the two roofs it is made of: its shared steps' weight + K/V bytes against HBM, its prompt ids'
+            # linear-layer FLOPs against the matrix peak -- both over the SAME wall time, so the two fractions add up to what the
+            # chip was asked for (prompts and steps overlap on two streams)
+            try:
+                w_bytes = algorithmic_bytes(args.mode, 0)
+                kv_per_pos = algorithmic_bytes(args.mode, 1) - w_bytes
+                # mean context of a live slot ~ prompt (64..512) + half its budget (32..224): ~350 positions
+                mean_ctx = (st["prompt_tokens"] + 0.5 * st["new_tokens"]) / max(args.serve, 1)
+                step_bytes = st["steps"] * w_bytes + st["new_tokens"] * kv_per_pos * mean_ctx
+                ach_gbps = step_bytes / dt / 1e9
+                ach_tf = 2.0 * 1_034_426_368 * st["prompt_tokens"] / dt / 1e12
+                out["serving"]["roofline"] = {
+                    "bound": "hbm", "achieved": round(ach_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach_gbps / HBM_PEAK_GBPS, 4),
+                    "traffic": None,
+                    "what": "shared steps x weight bytes + new ids x K/V bytes at the queue's mean context (%.0f positions), over the whole wall time" % mean_ctx,
+                    "prompt_side": {"bound": "mfma", "achieved": round(ach_tf, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(ach_tf / MFMA_F16_PEAK_TFLOPS, 4), "what": "prompt ids x linear-layer FLOPs over the same wall time"}}
+            except Exception as e:                                       # a reporting extra: never costs the line
+                out["serving"]["roofline"] = "not computed: %s" % type(e).__name__
             try:
                 # the same queue once more, untimed: the ids must not depend on which prompt overlapped which slice
                 got2, _ = batch.serve(prompts, N_CTX, -1, args.serve_slice, max_new_each=budgets)
@@ -905,6 +999,7 @@ def worker(args, rank, local_rank, world, dist):
                               "linear_tflops": round(flops / dt / 1e12, 2),
                               "family_ms": fams,
                               "wx_tflops": round((flops - 2.0 * 32003 * 2048 * (P - 1)) / (wx_ms * 1e-3) / 1e12, 1) if wx_ms > 0 else None,
+                              "roofline": prefill_roofline(args, P, flops, wx_ms),
                               "note": "W.x on v_mfma_f32_16x16x32_f16 (gten_mfma.hip, fast form: block deltas folded into the f16 operands, K accumulated in the matrix core), "
                                       "attention on gten_attn_tiled.hip (int8 / f16 MFMA scores), element-wise ops on the "
                                       "block-pair kernel; linear_tflops = linear-layer FLOPs / whole prefill time; wx_tflops = the same FLOPs (lm_head: last row only) / "

@@ -291,6 +291,11 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dec, int seq);
 int gten_hip_decoder_slots_apply(gten_hip_decoder* dec, int count, const int* seqs, const int* n_first, const int* n_last,
                                  const int32_t* const* tokens);
 int gten_hip_decoder_run(gten_hip_decoder* dec, int steps);
+/* lanes (round 4): with set_lane_skip(1) a run leaves out every lane whose slots are all parked (its launch chain costs a full
+ * lane's time however few slots are live); off by default -- it measured slower on the bench's serving queue, DESIGN.md 3.6 --
+ * and the ids never depend on it (tests/test_serving_gpu.py).  lane_info: sequences per lane, lanes, how many the last run took. */
+int gten_hip_decoder_lane_info(gten_hip_decoder* dec, int* lane_rows, int* lanes, int* last_run_lanes);
+int gten_hip_set_lane_skip(int on);
 int gten_hip_decoder_slot_ids(gten_hip_decoder* dec, int seq, int n_from, int count, int32_t* ids_host);
 /* ... of EVERY sequence at once: ids_host[q * count + i] = the argmax of step n_from[q] + i of sequence q (count <= 64; a
  * sequence's entries past the steps it ran are unspecified) -- one gather launch and one copy instead of n_seq copies */

@@ -109,7 +109,8 @@ int  gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const 
  * gten_hip_decoder_slot_start / _run / _slot_ids).  `slice` = shared steps between two looks at the results; max_new > 0
  * additionally bounds the ids generated per prompt (max_new_each, when not NULL: prompt j's own bound).
  * out is [n_prompts][max(max_tokens, max_prompt)] (prompt + new ids), n_total [n_prompts]; stats (may be NULL) receives
- * {prompt tokens, new tokens, shared steps, admissions, seconds in prompt processing, seconds in shared steps}. */
+ * EIGHT doubles: {prompt tokens, new tokens, shared steps, admissions, seconds in prompt processing, seconds in shared steps,
+ * lane-steps (shared steps x the lanes each of them ran: a lane without a live slot sits a run out), slots per lane}. */
 int  gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
                            int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats);
 /* tests: k > 0 fixes the admission schedule of gten_host_batch_serve -- exactly k prompts are processed beside every slice

@@ -134,6 +134,7 @@ int gten_hip_matmul_2d(const void* x, int, size_t, const void*, int, void* out, 
 int gten_hip_set_prefill_exact(int) { return 0; }
 int gten_hip_set_decode_exact(int) { return 0; }
 int gten_hip_set_decode_persistent(int) { return 0; }
+int gten_hip_set_lane_skip(int) { return 0; }
 int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsigned* abort_code, unsigned*, int)
 {
     if (n_decoders) *n_decoders = 0;
@@ -325,6 +326,15 @@ int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seq
             if (int rc = gten_hip_decoder_set_tokens_seq(dc, seqs[i], tokens[i], 0, n_first[i])) return rc;
         if (int rc = gten_hip_decoder_slot_start_until(dc, seqs[i], n_first[i], n_last[i])) return rc;
     }
+    return 0;
+}
+int gten_hip_decoder_lane_info(gten_hip_decoder* dc, int* lane_rows, int* lanes, int* last_run_lanes)
+{
+    if (!dc) return fail("decoder_lane_info: arguments");
+    // (the stand-in has no lanes: one lane of every sequence)
+    if (lane_rows) *lane_rows = dc->n_seq;
+    if (lanes) *lanes = 1;
+    if (last_run_lanes) *last_run_lanes = 1;
     return 0;
 }
 int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)

@@ -104,7 +104,7 @@ int main()
         for (int k : {0, 1, 2, 8})
             for (int slice : {16, 5, 3}) {
                 CHECK(gten_host_batch_set_serve_schedule(b, k) == 0);
-                double stats[6] = {0, 0, 0, 0, 0, 0};
+                double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 CHECK(gten_host_batch_serve(b, pr.data(), npr.data(), NP, total, total, eos, slice, 0, nullptr, out.data(), tot.data(), stats) == 0);
                 long new_ids = 0;
                 for (int j = 0; j < NP; j++) {

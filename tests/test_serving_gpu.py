@@ -127,6 +127,38 @@ def test_queue_through_128_slots_equals_16_slots(hip):
         assert outs[0][j].tolist() == outs[1][j].tolist(), j
 
 
+def test_lanes_without_a_live_slot_sit_the_run_out(hip):
+    """round 4: a shared run leaves out every lane whose slots are all parked, and admission fills the lanes that already run
+    first.  The ids must not depend on it: a queue through 256 slots (two lanes of 128 rows) -- short enough that the second
+    lane is empty at the start and again in the tail -- with and without lane skipping, and through 16 slots; the skipping run
+    must have computed fewer lane-steps than steps x lanes."""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 1414, i) for i in range(len(cfg.weight_shapes()))]
+    lengths = [16 + (23 * i) % 140 for i in range(330)]
+    prompts = make_prompts(host, cfg, lengths, 17)
+    budgets = np.array([4 + (11 * i) % 70 for i in range(330)], np.int32)
+    outs, stats = [], []
+    try:
+        for slots, skip in ((256, True), (256, False), (16, True)):
+            hip.set_lane_skip(skip)
+            b = host.batch(cfg, slots)
+            for i, w in enumerate(weights):
+                b.set_weight(i, w)
+            got, st = b.serve(prompts, 300, -1, 8, max_new_each=budgets)
+            assert st["admissions"] == 330
+            outs.append(got); stats.append(st)
+            b.close()
+    finally:
+        hip.set_lane_skip(False)
+    for j in range(330):
+        assert outs[0][j].tolist() == outs[1][j].tolist() == outs[2][j].tolist(), j
+    assert stats[0]["lane_rows"] == 128 and stats[1]["lane_steps"] == 2 * stats[1]["steps"]
+    assert stats[0]["lane_steps"] < 2 * stats[0]["steps"], stats[0]
+    print("lane-steps with / without skipping:", stats[0]["lane_steps"], stats[1]["lane_steps"], "steps", stats[0]["steps"], stats[1]["steps"])
+
+
 def test_slot_api_errors_are_reported(hip):
     pkg = load_package()
     host = pkg.load_host()

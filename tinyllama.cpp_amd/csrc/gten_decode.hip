@@ -3301,6 +3301,12 @@ struct gten_hip_decoder {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph_k = nullptr;       // DEC_GRAPH_STEPS consecutive steps in one graph (the position lives on the device and
     hipGraphExec_t exec_k = nullptr;    // the last kernel of a step advances it): one replay per DEC_GRAPH_STEPS tokens
+    // continuous batching (gten_hip_decoder_run): the same two graphs per SUBSET of lanes -- a lane whose slots are all parked is
+    // left out of the step (its launch chain costs what a full lane costs however few slots are live); index = lane mask
+    hipGraph_t graph_m[1 << DEC_MAX_LANES] = {}, graph_km[1 << DEC_MAX_LANES] = {};
+    hipGraphExec_t exec_m[1 << DEC_MAX_LANES] = {}, exec_km[1 << DEC_MAX_LANES] = {};
+    unsigned lane_mask = 0;             // lanes the NEXT enqueue takes (0: all)
+    int last_run_lanes = 0;             // lanes the last gten_hip_decoder_run took
     const float2* rope = nullptr;
     float2* rope_now = nullptr;       // [n_seq][d_head / 2], see Gemv8Args
     // ---- more than 64 sequences: LANES.  The step of a wide decoder is a chain of ~180 dependent launches that leaves most
@@ -3354,6 +3360,9 @@ static LaneBufs lane_bufs(const gten_hip_decoder* dc, int lane)
 // choice while one of its steps is being enqueued.
 static bool g_decode_exact = false;
 static bool g_exact_now = false;
+// off by default: on the bench's serving queue (1024 prompts through two lanes of 128 slots) only 3 % of the lane-steps have an
+// empty lane, and the extra graphs cost more than that returns: 33.5 k against 37.0 k new ids/s, A/B on one box
+static bool g_lane_skip = false;         // gten_hip_decoder_run leaves lanes without a live slot out of the step (gten_hip_set_lane_skip)
 extern "C" int gten_hip_set_decode_exact(int on)
 {
     g_decode_exact = on != 0;
@@ -4159,17 +4168,26 @@ static int enqueue(gten_hip_decoder* dc, int count = 1)
             if (int rc = enqueue_lane(dc, 0)) return rc;
         return 0;
     }
+    const unsigned all = (1u << dc->lanes) - 1u, mask = (dc->lane_mask & all) ? (dc->lane_mask & all) : all;
+    int g0 = 0;
+    while (!((mask >> g0) & 1u)) g0++;                       // the first lane taken runs on the current stream
+    const bool side = (mask & ~(1u << g0)) != 0;
     hipStream_t main_s = stream();
-    GTR_CHECK(hipEventRecord(dc->lane_fork, main_s));
-    for (int g = 1; g < dc->lanes; g++) GTR_CHECK(hipStreamWaitEvent(dc->lane_stream[g], dc->lane_fork, 0));
+    if (side) {
+        GTR_CHECK(hipEventRecord(dc->lane_fork, main_s));
+        for (int g = g0 + 1; g < dc->lanes; g++)
+            if ((mask >> g) & 1u) GTR_CHECK(hipStreamWaitEvent(dc->lane_stream[g], dc->lane_fork, 0));
+    }
     int rc = 0;
-    for (int g = 0; g < dc->lanes && !rc; g++) {
-        if (g) gtr::stream_override(dc->lane_stream[g]);
+    for (int g = g0; g < dc->lanes && !rc; g++) {
+        if (!((mask >> g) & 1u)) continue;
+        if (g != g0) gtr::stream_override(dc->lane_stream[g]);
         for (int i = 0; i < count && !rc; i++) rc = enqueue_lane(dc, g);
         gtr::stream_override(nullptr);
     }
     // (join even after a failure: a capture must not be left with dangling branches)
-    for (int g = 1; g < dc->lanes; g++) {
+    for (int g = g0 + 1; g < dc->lanes; g++) {
+        if (!((mask >> g) & 1u)) continue;
         GTR_CHECK(hipEventRecord(dc->lane_join[g], dc->lane_stream[g]));
         GTR_CHECK(hipStreamWaitEvent(main_s, dc->lane_join[g], 0));
     }
@@ -4414,6 +4432,12 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
     if (dc->graph) rel(hipGraphDestroy(dc->graph));
     if (dc->exec_k) rel(hipGraphExecDestroy(dc->exec_k));
     if (dc->graph_k) rel(hipGraphDestroy(dc->graph_k));
+    for (int m = 0; m < (1 << DEC_MAX_LANES); m++) {
+        if (dc->exec_m[m]) rel(hipGraphExecDestroy(dc->exec_m[m]));
+        if (dc->graph_m[m]) rel(hipGraphDestroy(dc->graph_m[m]));
+        if (dc->exec_km[m]) rel(hipGraphExecDestroy(dc->exec_km[m]));
+        if (dc->graph_km[m]) rel(hipGraphDestroy(dc->graph_km[m]));
+    }
     void* bufs[] = {dc->ids_stage, dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
@@ -4457,21 +4481,30 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t
 #define DEC_GRAPH_STEPS 4
 static int slots_leave(gten_hip_decoder* dc);     // continuous batching (below): back to every sequence's own caches
 static int run_step(gten_hip_decoder* dc, int use_graph);
+// (the graphs of the lane subset dc->lane_mask selects: slot 0 = every lane)
+static unsigned graph_slot(const gten_hip_decoder* dc)
+{
+    const unsigned all = (1u << dc->lanes) - 1u, m = dc->lane_mask & all;
+    return (dc->lanes <= 1 || m == 0 || m == all) ? 0u : m;
+}
 static int run_steps_free(gten_hip_decoder* dc, int count)
 {
     if (prof_on()) { for (int i = 0; i < count; i++) if (int rc = run_step(dc, 0)) return rc; return 0; }
+    const unsigned gs = graph_slot(dc);
+    hipGraph_t& graph_k = gs ? dc->graph_km[gs] : dc->graph_k;
+    hipGraphExec_t& exec_k = gs ? dc->exec_km[gs] : dc->exec_k;
     while (count >= DEC_GRAPH_STEPS) {
-        if (!dc->exec_k) {
+        if (!exec_k) {
             GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
             const int rc = enqueue(dc, DEC_GRAPH_STEPS);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(stream(), &g);
             if (rc) { if (g) hipGraphDestroy(g); return rc; }
             GTR_CHECK(e);
-            dc->graph_k = g;
-            GTR_CHECK(hipGraphInstantiate(&dc->exec_k, dc->graph_k, nullptr, nullptr, 0));
+            graph_k = g;
+            GTR_CHECK(hipGraphInstantiate(&exec_k, graph_k, nullptr, nullptr, 0));
         }
-        GTR_CHECK(hipGraphLaunch(dc->exec_k, stream()));
+        GTR_CHECK(hipGraphLaunch(exec_k, stream()));
         count -= DEC_GRAPH_STEPS;
     }
     for (int i = 0; i < count; i++)
@@ -4482,17 +4515,20 @@ static int run_steps_free(gten_hip_decoder* dc, int count)
 static int run_step(gten_hip_decoder* dc, int use_graph)
 {
     if (!use_graph || prof_on()) return enqueue(dc);    // event pairs cannot be recorded into a capture
-    if (!dc->exec) {
+    const unsigned gs = graph_slot(dc);
+    hipGraph_t& graph = gs ? dc->graph_m[gs] : dc->graph;
+    hipGraphExec_t& exec = gs ? dc->exec_m[gs] : dc->exec;
+    if (!exec) {
         GTR_CHECK(hipStreamBeginCapture(stream(), hipStreamCaptureModeThreadLocal));
         const int rc = enqueue(dc);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(stream(), &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         GTR_CHECK(e);
-        dc->graph = g;
-        GTR_CHECK(hipGraphInstantiate(&dc->exec, dc->graph, nullptr, nullptr, 0));
+        graph = g;
+        GTR_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     }
-    GTR_CHECK(hipGraphLaunch(dc->exec, stream()));
+    GTR_CHECK(hipGraphLaunch(exec, stream()));
     return 0;
 }
 
@@ -4781,9 +4817,37 @@ int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
     for (const DecStep& s : dc->slots)
         GTR_REQUIRE(!(s.advance & 1) || s.stop > 0 || s.n + steps - 1 <= dc->d.max_ctx, "decoder_run: %d steps would take a slot at n=%d past max_ctx %d", steps, s.n,
                     dc->d.max_ctx);
-    if (int rc = run_steps_free(dc, steps)) return rc;
+    // lanes whose slots are ALL parked sit this run out (a parked slot only recomputes row 0 of the dummy caches; its ids are
+    // never read).  Nobody live at all: every lane, as before.
+    unsigned mask = 0;
+    const int SL = dc->n_seq / dc->lanes;
+    for (int q = 0; q < dc->n_seq; q++)
+        if (dc->slots[(size_t)q].advance & 1) mask |= 1u << (q / SL);
+    dc->lane_mask = (dc->lanes > 1 && g_lane_skip) ? mask : 0;
+    dc->last_run_lanes = (dc->lanes > 1 && g_lane_skip && mask) ? __builtin_popcount(mask) : dc->lanes;
+    const int rc_run = run_steps_free(dc, steps);
+    dc->lane_mask = 0;
+    if (rc_run) return rc_run;
     for (DecStep& s : dc->slots)
         if (s.advance & 1) s.n = s.stop > 0 ? std::min(s.n + steps, s.stop) : s.n + steps;   // (a slot that reaches max_ctx + 1 has to be parked or restarted before the next run)
+    return 0;
+}
+
+/* rows (sequences) per lane, the number of lanes, and how many of them the last gten_hip_decoder_run took */
+int gten_hip_decoder_lane_info(gten_hip_decoder* dc, int* lane_rows, int* lanes, int* last_run_lanes)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc, "decoder_lane_info: null decoder");
+    if (lane_rows) *lane_rows = dc->n_seq / dc->lanes;
+    if (lanes) *lanes = dc->lanes;
+    if (last_run_lanes) *last_run_lanes = dc->last_run_lanes ? dc->last_run_lanes : dc->lanes;
+    return 0;
+}
+
+/* test hook: 0 = gten_hip_decoder_run always takes every lane (the behaviour before round 4) */
+int gten_hip_set_lane_skip(int on)
+{
+    g_lane_skip = on != 0;
     return 0;
 }
 

@@ -92,7 +92,7 @@ class GtenHip:
         "gten_hip_decoder_step", "gten_hip_decoder_steps", "gten_hip_decoder_generate", "gten_hip_decoder_generate_multi", "gten_hip_decoder_step_ragged", "gten_hip_decoder_result", "gten_hip_decoder_time_family",
         "gten_hip_decoder_create_multi", "gten_hip_decoder_set_tokens_seq", "gten_hip_decoder_result_seq",
         "gten_hip_decoder_logits_seq",
-        "gten_hip_decoder_slot_start", "gten_hip_decoder_slot_start_until", "gten_hip_decoder_slot_park", "gten_hip_decoder_slots_apply", "gten_hip_decoder_run", "gten_hip_decoder_slot_ids", "gten_hip_decoder_slot_ids_all",
+        "gten_hip_decoder_lane_info", "gten_hip_set_lane_skip", "gten_hip_decoder_slot_start", "gten_hip_decoder_slot_start_until", "gten_hip_decoder_slot_park", "gten_hip_decoder_slots_apply", "gten_hip_decoder_run", "gten_hip_decoder_slot_ids", "gten_hip_decoder_slot_ids_all",
     ]
 
     def __init__(self, path=None):
@@ -132,6 +132,7 @@ class GtenHip:
         self._set_block_rows = _sig(L, "gten_hip_set_block_rows", ci, [ci])
         self._decode_exact = _sig(L, "gten_hip_set_decode_exact", ci, [ci])
         self._decode_persistent = _sig(L, "gten_hip_set_decode_persistent", ci, [ci])
+        self._lane_skip = _sig(L, "gten_hip_set_lane_skip", ci, [ci])
         self._persist_status = _sig(L, "gten_hip_persist_status", ci, [C.POINTER(ci), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.c_void_p, ci])
         self._set_row_segments = _sig(L, "gten_hip_set_row_segments", ci, [C.c_void_p, ci])
         self._copy_ranges = _sig(L, "gten_hip_copy_ranges", ci, [C.c_void_p, ci])
@@ -187,6 +188,10 @@ class GtenHip:
     def set_decode_persistent(self, on):
         """single-sequence q4 decoders created from now on: the step as ONE persistent launch, or the launch chain (default)"""
         self._check(self._decode_persistent(1 if on else 0))
+
+    def set_lane_skip(self, on):
+        """gten_hip_decoder_run leaves lanes without a live slot out of the step (default) or always takes every lane"""
+        self._check(self._lane_skip(1 if on else 0))
 
     def persist_status(self, n_stamps=0):
         """(decoders running the persistent step, launches enqueued, abort code [cleared], stamps) -- waits for the stream"""

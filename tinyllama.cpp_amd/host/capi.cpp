@@ -341,6 +341,7 @@ int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int3
     if (stats) {
         stats[0] = (double)st.prompt_tokens; stats[1] = (double)st.new_tokens; stats[2] = (double)st.steps;
         stats[3] = (double)st.admissions; stats[4] = st.prefill_s; stats[5] = st.decode_s;
+        stats[6] = (double)st.lane_steps; stats[7] = (double)st.lane_rows;
     }
     return 0;
 }

@@ -581,7 +581,9 @@ public:
     // (gten_hip_decoder_slot_start_until; cutting the slice to the shortest remaining run instead left 128 slots with
     // slices of one to three steps and prompt batches of two).  Per sequence the ids are those of
     // generating it alone (bit for bit up to 8 slots; tests/test_serving_gpu.py).
-    struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0; double prefill_s = 0.0, decode_s = 0.0; };
+    // (lane_steps: shared steps x the lanes each of them ran -- a lane whose slots are all parked is left out of a run; lane_rows:
+    //  slots per lane; new ids / (lane_steps x lane_rows) is the share of COMPUTED slot-steps that produced an id)
+    struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0, lane_steps = 0; int lane_rows = 0; double prefill_s = 0.0, decode_s = 0.0; };
     // (max_new_each, when given, bounds the new ids of prompt j by max_new_each[j] instead of max_new)
     ServeStats serve(const std::vector<std::vector<int32_t>>& prompts, int max_tokens, int eos, int slice,
                      std::vector<std::vector<int32_t>>* out, int max_new = 0, const int32_t* max_new_each = nullptr)
@@ -597,6 +599,20 @@ public:
         size_t next = 0;
         int n_live = 0, n_ready = 0;
         slice = std::min(std::max(slice, 1), 64);                          // (gten_hip_decoder_slot_ids_all reads up to 64 steps at once)
+        int lane_rows = S, n_lanes = 1;
+        GTEN_HIP_OK(gten_hip_decoder_lane_info(dec_, &lane_rows, &n_lanes, nullptr));
+        st.lane_rows = lane_rows;
+        // free slots in the order they are filled: slots of lanes that already run first (a lane without a live slot sits a
+        // run out, so a half-empty queue should occupy as few lanes as possible), then by index
+        auto free_slots = [&]() {
+            std::vector<int> busy((size_t)n_lanes, 0), fq;
+            for (int q = 0; q < S; q++)
+                if (job[(size_t)q] >= 0) busy[(size_t)(q / lane_rows)]++;
+            for (int pass = 0; pass < 2; pass++)
+                for (int q = 0; q < S; q++)
+                    if (job[(size_t)q] < 0 && (busy[(size_t)(q / lane_rows)] > 0) == (pass == 0)) fq.push_back(q);
+            return fq;
+        };
         GTEN_HIP_OK(gten_hip_select_stream(0));
         for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
         // the next prompt of the queue onto free slot q (stream 1); false when the queue is empty
@@ -630,9 +646,7 @@ public:
         // configurations the segmented call does not compute) go one by one through prepare().
         const bool batched = batched_prompts();
         auto prepare_many = [&](int cap) -> bool {
-            std::vector<int> fq;
-            for (int q = 0; q < S; q++)
-                if (job[(size_t)q] < 0) fq.push_back(q);
+            const std::vector<int> fq = free_slots();
             if (fq.empty()) return next < prompts.size();
             const size_t room = std::min<size_t>({fq.size(), (size_t)kPreMax, cap > 0 ? (size_t)cap : (size_t)kPreMax});
             std::vector<int> js, limits;
@@ -706,6 +720,9 @@ public:
             t_slice = clock::now();
             GTEN_HIP_OK(gten_hip_decoder_run(dec_, cnt));
             st.steps += cnt;
+            int ran = n_lanes;
+            GTEN_HIP_OK(gten_hip_decoder_lane_info(dec_, nullptr, nullptr, &ran));
+            st.lane_steps += (int64_t)cnt * ran;
         };
         // the ids of the finished slice; slots that ended are parked (their caches are free for the next prompt)
         std::vector<int> from((size_t)S, 0);
@@ -746,9 +763,10 @@ public:
                 if (serve_schedule_ > 0) idle = prepared_this_slice >= serve_schedule_;   // fixed schedule (tests): k prompts per slice
                 else GTEN_HIP_OK(gten_hip_stream_idle(0, &idle));
                 int free_q = -1;
-                if (!idle && queue_left)
-                    for (int q = 0; q < S && free_q < 0; q++)
-                        if (job[(size_t)q] < 0) free_q = q;
+                if (!idle && queue_left) {
+                    const std::vector<int> fq = free_slots();
+                    if (!fq.empty()) free_q = fq[0];
+                }
                 if (free_q >= 0) {                                          // slice still running: more prompts beside it
                     GTEN_HIP_OK(gten_hip_select_stream(1));
                     const int before = (int)st.admissions;
@@ -762,8 +780,10 @@ public:
             }
             if (n_live == 0 && n_ready == 0) {                              // nothing to decode: a prompt first
                 int free_q = -1;
-                for (int q = 0; q < S && free_q < 0 && queue_left; q++)
-                    if (job[(size_t)q] < 0) free_q = q;
+                if (queue_left) {
+                    const std::vector<int> fq = free_slots();
+                    if (!fq.empty()) free_q = fq[0];
+                }
                 if (free_q < 0) break;                                      // queue empty, nothing in flight
                 GTEN_HIP_OK(gten_hip_select_stream(1));
                 queue_left = batched ? prepare_many(serve_schedule_) : prepare(free_q);

@@ -346,13 +346,13 @@ class HostBatch:
             npr[j] = len(p)
         out = np.zeros((len(prompts), width), np.int32)
         tot = np.zeros(len(prompts), np.int32)
-        st = np.zeros(6, np.float64)
+        st = np.zeros(8, np.float64)
         each = None if max_new_each is None else np.ascontiguousarray(max_new_each, dtype=np.int32)
         assert each is None or len(each) == len(prompts)
         self._ck(self.host._bserve(self.h, pr.ctypes.data_as(C.c_void_p), npr.ctypes.data_as(C.c_void_p), len(prompts), mp, max_tokens, eos,
                                    slice_steps, max_new, None if each is None else each.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)),
                  "batch_serve")
-        keys = ("prompt_tokens", "new_tokens", "steps", "admissions", "prefill_s", "decode_s")
+        keys = ("prompt_tokens", "new_tokens", "steps", "admissions", "prefill_s", "decode_s", "lane_steps", "lane_rows")
         return [out[j, : tot[j]].copy() for j in range(len(prompts))], dict(zip(keys, st.tolist()))
 
     def decode_result(self, seq, n):
