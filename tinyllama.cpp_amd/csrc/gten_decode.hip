@@ -4392,6 +4392,7 @@ static int persist_prepare(gten_hip_decoder* dc)
     a.max_ctx = d.max_ctx; a.n_chunks = dc->n_chunks; a.kv_pitch = (int)gten_hip_row_bytes(d.adtype, KV);
     ps->grid = G;
     ps->smem = persist_smem();
+    GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_persist<GTEN_Q4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps->smem));
     return 0;
 }
 static hipError_t persist_free(gten_hip_decoder* dc)

@@ -93,19 +93,33 @@ __device__ __forceinline__ bool p_give_up(unsigned& spins, unsigned* ctl, unsign
     return false;
 }
 
-// N consecutive granules per thread (threads with !act take no part); false = the step was aborted
+// N consecutive granules per thread (threads with !act take no part); false = the step was aborted.
+// Four granules = 32 aligned bytes = TWO 16-byte sc1 loads: the texture path spends ~25 cycles per wave INSTRUCTION whatever
+// its width, and while a phase waits every wave of the chip is polling -- half the instructions, half the queue in front
+// of the loads and stores that matter (hipcc has no 16-byte atomic load: inline assembly, the wait inside the statement).
+typedef unsigned p_u4v __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ bool p_poll(const pu64* g, unsigned idx, unsigned tag, bool act, unsigned (&val)[N], unsigned* ctl, unsigned code, int lazy = 0)
 {
     const pgu64* p = (const pgu64*)(uintptr_t)g + idx;              // (uniform base + 32-bit lane index)
     for (unsigned spins = 0;;) {
-        pu64 x[N];
         bool ok = true;
-        if (act) {
+        if constexpr (N == 4) {
+            p_u4v x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+            if (act) {
+                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(x0), "=&v"(x1) : "v"(p) : "memory");
+                ok = (x0[1] == tag) & (x0[3] == tag) & (x1[1] == tag) & (x1[3] == tag);
+                val[0] = x0[0]; val[1] = x0[2]; val[2] = x1[0]; val[3] = x1[2];
+            }
+        } else {
+            pu64 x[N];
+            if (act) {
 #pragma unroll
-            for (int i = 0; i < N; i++) x[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < N; i++) x[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int i = 0; i < N; i++) { ok = ok & ((unsigned)(x[i] >> 32) == tag); val[i] = (unsigned)x[i]; }
+                for (int i = 0; i < N; i++) { ok = ok & ((unsigned)(x[i] >> 32) == tag); val[i] = (unsigned)x[i]; }
+            }
         }
         if (__all(ok)) return true;
         if (p_give_up(spins, ctl, code, lazy)) return false;
@@ -231,9 +245,11 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
     int8_t* vi8 = ki8 + dh;
     float* pr_l = (float*)(att + 1152);                  // 256 probabilities
     float* part = pr_l + DEC_CHUNK;                      // 256
-    unsigned* vl = (unsigned*)(part + DEC_CHUNK);        // 256 x 17 dwords: the chunk's V slices, row-major
-    unsigned* kl = vl + DEC_CHUNK * NWD;                 // ... and its K slices
-    pu64* tabl = (pu64*)(kl + DEC_CHUNK * NWD);          // the per-layer pointer table (PLayer x n_layers), copied once: a pointer is then an
+    // the chunk's V and K slices, row-major as they lie in the caches, TWO of each: while waves 0-3 work on this block's (buffer
+    // l & 1), waves 4-7 -- idle through the attention phase -- fetch the next block's into the other one
+    unsigned* vl0 = (unsigned*)(part + DEC_CHUNK);       // [2][256 x 17 dwords]
+    unsigned* kl0 = vl0 + 2 * DEC_CHUNK * NWD;
+    pu64* tabl = (pu64*)(kl0 + 2 * DEC_CHUNK * NWD);          // the per-layer pointer table (PLayer x n_layers), copied once: a pointer is then an
                                                          // LDS read (~0.1 us) instead of a scalar-cache miss per block and matrix (~1 us, measured)
 
     for (int i = threadIdx.x; i < a.n_layers * PL_N; i += PERSIST_NT) tabl[i] = ((const pu64*)a.layers)[i];
@@ -301,25 +317,29 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
 #pragma unroll
         for (int c = 0; c < 3; c++) p_ld_row<WT>(tab(Ll, PL_WDOWN), E, nbf, r, real ? c : 0, lane, wD[c]);
     };
-    auto issue_kv = [&](int Ll, float dep) {
-        const int tid = p_opaque_dep((int)threadIdx.x, dep);
-        constexpr bool kvreal = true;
+    // requests [k0, k1) of the 17 + 17 that fetch a block's K and V chunks (waves 4-7; both chunks as coalesced dwords, exactly
+    // as they lie in the cache: a thread's OWN K row -- 17 dwords at a pitch of 272 bytes -- would be 64 different lines per wave
+    // instruction).  The texture path takes ~25 cycles per wave instruction, i.e. ~1.5 us for all of them: they are issued in
+    // four pieces BETWEEN the barriers of the attention phase, so that no barrier waits for the issuing waves.
+    auto issue_kv = [&](int Ll, int k0, int k1) {
+        const int tid = p_opaque((int)threadIdx.x) - 256;
         const unsigned pitch_w = (unsigned)a.kv_pitch >> 2;
-        // (both chunks as coalesced dwords, exactly as they lie in the cache: a thread's OWN K row -- 17 dwords at a pitch of 272
-        //  bytes -- would be 64 different lines per wave instruction, ~1.2 us of address processing per block)
         const gmem_u32 kbase = as_global(tab(Ll, PL_KC) + (size_t)g * (2 * GTEN_Q8_BYTES));
-        int row = tid / NWD, w = tid % NWD;
-        const int rstep = kvreal ? 256 / NWD : 0, wstep = kvreal ? 256 % NWD : 0;
         const gmem_u32 vbase = as_global(tab(Ll, PL_VC) + (size_t)g * (2 * GTEN_Q8_BYTES));
         const int last = a.max_ctx - 1 - c0;
 #pragma unroll
         for (int k = 0; k < NWD; k++) {
-            const unsigned off = (unsigned)(kvreal ? c0 + min(row, last) : 0) * pitch_w + (unsigned)w;
+            if (k < k0 || k >= k1) continue;
+            const int d = tid + 256 * k, row = d / NWD, w = d - row * NWD;     // dword d of the chunk
+            const unsigned off = (unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w;
             kw[k] = kbase[off];
             vw[k] = vbase[off];
-            row += rstep; w += wstep;
-            if (w >= NWD) { w -= NWD; row++; }
         }
+    };
+    auto park_kv = [&](int buf) {                         // waves 4-7: the requested chunks into LDS buffer `buf`
+        const int t2 = (int)threadIdx.x - 256;
+#pragma unroll
+        for (int k = 0; k < NWD; k++) { vl0[buf * DEC_CHUNK * NWD + t2 + k * 256] = vw[k]; kl0[buf * DEC_CHUNK * NWD + t2 + k * 256] = kw[k]; }
     };
     // lm_head rows of this wave, batch jb (8 rows): row index clamped for the request, discarded later
     auto lm_row = [&](int jb, int j) { return b * a.rph + wid * a.rw + jb * 8 + j; };
@@ -352,6 +372,7 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
     }
     {
         issue_qkv(0, true, 0.f);
+        if (att_on && wid >= 4) { issue_kv(0, 0, NWD); park_kv(0); }      // block 0's K / V chunks (the barriers of phase A order them)
     }
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(0);
@@ -422,7 +443,6 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
             // this block's K rows / V chunk, o and down rows: requested now, consumed one to four phases on -- everything but
             // the q|k|v rows is requested and consumed inside ONE iteration of the block loop, so no in-flight register
             // crosses the loop's back edge (the compiler would copy it there, behind a wait for the request)
-            if (att_on && wid < 4) issue_kv(Lc, v[0]);
             issue_o(Lc, true, v[0]);
             issue_down(Lc, true, v[0]);
             PSTAMP(l * 20 + 2);
@@ -468,13 +488,12 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
                     if ((t & 31) == 0) store_global<uint16_t>(bk, d16[4 * pw + (t >> 5)]);
                 }
             }
-            (void)vnew;
             PSTAMP(l * 20 + 6);
-            if (tid < 256) {
-#pragma unroll
-                for (int k = 0; k < NWD; k++) { vl[tid + k * 256] = vw[k]; kl[tid + k * 256] = kw[k]; }
-            }
+            const unsigned* kl = kl0 + (l & 1) * DEC_CHUNK * NWD;
+            unsigned* vl = vl0 + (l & 1) * DEC_CHUNK * NWD;
             __syncthreads();
+            // waves 4-7: the NEXT block's chunks are requested now and parked after the phase's last barrier (below)
+            if (more && tid >= 256) issue_kv(Ln, 0, 4);
             const int c = c0 + (int)tid;
             if (tid < 256) {
 #pragma unroll
@@ -518,12 +537,14 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
             const int tid = p_opaque((int)threadIdx.x);
             const int t = tid & 63;
             const int c = c0 + (int)tid;
+            const unsigned* vl = vl0 + (l & 1) * DEC_CHUNK * NWD;
             // chunk maximum and sum of exponentials (block_max_n<4> / block_sum_n<4> of waves 0-3)
             {
                 const float wm = wave_max_dpp(sc);
                 if (lane == 0 && wid < 4) a_red[wid] = wm;
             }
             __syncthreads();
+            if (more && tid >= 256) issue_kv(Ln, 4, 8);
             float mx, sm;
             {
                 const float4 m4 = *(const float4*)a_red;
@@ -535,6 +556,8 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
                 if (lane == 0 && wid < 4) a_red[4 + wid] = ws;
             }
             __syncthreads();
+            if (more && tid >= 256) issue_kv(Ln, 8, 12);
+            PSTAMP(l * 20 + 18);
             {
                 const float4 s4 = *(const float4*)(a_red + 4);
                 sm = 0.f;
@@ -547,6 +570,7 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
                 pr_l[tid] = pr;
             }
             __syncthreads();
+            if (more && tid >= 256) issue_kv(Ln, 12, NWD);
             if (tid < 256) {
                 const int len = min(DEC_CHUNK, n - c0);
                 const int e = tid & 63, cg = tid >> 6;
@@ -585,7 +609,9 @@ __global__ __launch_bounds__(PERSIST_NT) void k_dec_persist(const PArgs a)
                 }
                 part[tid] = o;
             }
+            PSTAMP(l * 20 + 19);
             __syncthreads();
+            if (more && tid >= 256) park_kv((l + 1) & 1);           // (the data has had the whole phase to arrive; nobody waits for these waves)
             // publish o_c[64] and (m_c, l_c): wave 0, two store instructions (512 + 16 contiguous bytes)
             if (wid == 0) {
                 float r = 0.f;
@@ -855,7 +881,7 @@ static bool persist_supported(const gten_hip_decoder_desc& d, int n_seq, int n_c
     return true;
 }
 
-static size_t persist_smem() { return 1024 + 2560 + 7680 + 1152 + 2048 + 17408 + 17408 + PERSIST_MAX_LAYERS * sizeof(PLayer); }
+static size_t persist_smem() { return 1024 + 2560 + 7680 + 1152 + 2048 + 4 * 17408 + PERSIST_MAX_LAYERS * sizeof(PLayer); }
 
 template <int WT>
 static int persist_launch(const PersistState* ps)

@@ -1,7 +1,7 @@
 """first contact of the persistent step with the hardware: same ids / logits as the launch chain, abort word clean, timing"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/ -> repository root
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from __graft_entry__ import load_package
 pkg = load_package()
@@ -50,22 +50,19 @@ nd, nl, ab, st = hip.persist_status(20 * 22 + 8)
 print("status:", nd, nl, ab)
 if any(st):
     st = np.array(st, dtype=np.int64)
-    names = ["E-pub->A-poll", "issue kv,o,down", "norm+stage", "A dots", "A publish", "q-poll+headprep", "V->LDS, scores", "softmax, pV, publish",
-             "B2 poll", "B2 join+publish", "C-poll", "C stage+dot+publish", "D-poll", "D prologue+dots", "D epilogue+publish", "E-poll",
-             "E scatter+dots", "-", "-", "E publish"]
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 18, 19, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20]
+    names = ["E-pub->A-poll", "issue o,down", "norm+stage", "A dots", "A publish", "q-poll+headprep", "K row, scores", "max, exp, sum (2 barriers)",
+             "p, barrier, p.V", "barrier, 4-sum, publish", "B2 poll", "B2 join+publish", "C-poll", "C stage+dot+publish", "D-poll", "D prologue+dots",
+             "D epilogue+publish", "E-poll", "E scatter+dots", "E publish"]
     L = 22
     t = st[: 20 * L + 1].astype(np.float64) * 0.01
     per = np.zeros((L, 20))
     for l in range(L):
-        seg = t[20 * l: 20 * l + 21].copy()
-        # unused slots (18, 19) carry the previous stamp
-        for k in (18, 19):
-            seg[k] = seg[17]
+        seg = np.array([t[20 * l + k] for k in order])
         per[l] = np.diff(seg)
     m = per[1:].mean(0)
     for k in range(20):
-        if names[k] != "-":
-            print("  %-28s %6.2f us" % (names[k], m[k]))
+        print("  %-28s %6.2f us" % (names[k], m[k]))
     print("block us:", per[1:].sum(1).mean(), " step us:", (st[20 * L + 2] - st[0]) * 0.01, " tail (final norm+lm_head+argmax) us:", (st[20 * L + 2] - st[20 * L]) * 0.01)
 for m_ in models.values():
     m_.close()
