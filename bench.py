@@ -126,6 +126,29 @@ def code_only(text):
     return " ".join("".join(out).split())
 
 
+def usable_cpus():
+    """the cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box reports every core
+    of the host in os.cpu_count() while its container is held to a share of them)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 8
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def csrc_fingerprint():
     """sha256 (16 hex digits) over what the in-tree libgten_hip.so is built from -- the kernel sources (comments and white
     space aside: code_only) AND the compiler flags (build.HIP_FLAGS, HIP_FILE_FLAGS: round 2 changed code generation of every
@@ -484,7 +507,9 @@ def main(argv=None):
         os.environ["GTEN_HIP_DEVICE"] = "0"
     os.environ.setdefault("GTEN_HIP_DEVICE", str(local_rank))
     # weight synthesis is OpenMP code on the host: share the cores between the ranks of this node
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(4, (os.cpu_count() or 8) // max(world, 1))))
+    ncpu = usable_cpus()
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(2, ncpu // max(world, 1))))
+    os.environ.setdefault("GTEN_SYNTH_GEN_THREADS", str(ncpu))
     # ... and generate the synthetic weights ONCE per node: the first replica to get there writes them to /dev/shm, the others
     # read them (host/tinyllama_model.h load_synthetic_cached); rank 0 removes the files when it is done
     if world > 1 and os.path.isdir("/dev/shm"):

@@ -2014,20 +2014,23 @@ __global__ __launch_bounds__(256) void k_dec_attn_one64(const unsigned long long
     const int cs = min(c, a.max_ctx - 1);
     const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
     const gmem_u32 kp = as_global(a.kcache + (size_t)g * head_bytes) + (unsigned)cs * pitch_w;
+    // (round 4: a row's slice as 16-byte requests -- four and one dword for a Q8 slice of 68 bytes, eight for an f16 one.  The
+    //  texture path spends its time per wave INSTRUCTION and per line touched, not per byte: 17 dword requests per thread and
+    //  matrix were ~1.3 us of the launch; the slice is 4-byte aligned only, which gfx9 global loads take)
     unsigned kw[NW];
-#pragma unroll
-    for (int j = 0; j < NW; j++) kw[j] = kp[j];
     unsigned vw[NW];
     {
-        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
-        const gmem_u32 vbase = as_global(a.vcache + (size_t)g * head_bytes);
-        const int last = a.max_ctx - 1 - c0;
+        const gmem_u32 vp = as_global(a.vcache + (size_t)g * head_bytes) + (unsigned)cs * pitch_w;      // THIS thread's V row too
+        typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            vw[k] = vbase[(unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w];
-            row += 256 / NW; w += 256 % NW;
-            if (w >= NW) { w -= NW; row++; }
+        for (int j = 0; j + 4 <= NW; j += 4) {
+            const u4u kq = *(const __attribute__((address_space(1))) u4u*)(kp + j);
+            const u4u vq = *(const __attribute__((address_space(1))) u4u*)(vp + j);
+            kw[j] = kq.x; kw[j + 1] = kq.y; kw[j + 2] = kq.z; kw[j + 3] = kq.w;
+            vw[j] = vq.x; vw[j + 1] = vq.y; vw[j + 2] = vq.z; vw[j + 3] = vq.w;
         }
+#pragma unroll
+        for (int j = NW & ~3; j < NW; j++) { kw[j] = kp[j]; vw[j] = vp[j]; }
     }
     __builtin_amdgcn_sched_barrier(0);
     const int n = a.step->n, pos = n - 1;
@@ -2058,7 +2061,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_one64(const unsigned long long
     // the V chunk goes to LDS now (its requests were issued after the K rows: by the time the scores are done it is
     // there); the new position's slice is patched from the chip below
 #pragma unroll
-    for (int k = 0; k < NW; k++) vl[threadIdx.x + k * 256] = vw[k];
+    for (int k = 0; k < NW; k++) vl[threadIdx.x * NW + k] = vw[k];            // row-major, as before (NW odd / a row per bank group: no conflict)
     __syncthreads();
 
     // ---- scores (k_dec_attn_score64's arithmetic)

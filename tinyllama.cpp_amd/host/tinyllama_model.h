@@ -9,6 +9,8 @@
 #include <chrono>
 #include <cstdio>
 #include <fcntl.h>
+#include <omp.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -283,30 +285,39 @@ public:
         const std::string path = base, lock = path + ".lock", tmp = path + ".tmp";
         auto ready = [&]() { struct stat st; return ::stat(path.c_str(), &st) == 0 && (size_t)st.st_size == total; };
         if (!ready()) {
-            const int fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
-            if (fd >= 0) {                                       // this process generates
-                ::close(fd);
-                std::FILE* f = std::fopen(tmp.c_str(), "wb");
-                bool ok = f != nullptr;
-                std::vector<float> f32;
-                for (int i = 0; i < n_weights(); i++) {
-                    Tensor& w = weight(i);
-                    synth_weight_bytes(params, dtype_, seed, i, f32, w.data_ptr<uint8_t>(), w.nbytes());
-                    if (ok) ok = std::fwrite(w.data_ptr<uint8_t>(), 1, w.nbytes(), f) == w.nbytes();
-                    w.device_weight();
+            // an advisory lock on the lock FILE (never its existence): a generator that dies releases it, nobody waits for a
+            // stale file.  Whoever gets the exclusive lock generates; the others block on a shared lock until it is done.
+            const int fd = ::open(lock.c_str(), O_CREAT | O_RDWR, 0644);
+            if (fd < 0) return false;
+            if (::flock(fd, LOCK_EX | LOCK_NB) == 0) {
+                if (!ready()) {                                  // (it may have been finished between the check and the lock)
+                    if (const char* nt = std::getenv("GTEN_SYNTH_GEN_THREADS")) {
+                        const int n = std::atoi(nt);
+                        if (n > 0) omp_set_num_threads(n);       // the other replicas only wait: every core for this one
+                    }
+                    std::FILE* f = std::fopen(tmp.c_str(), "wb");
+                    bool ok = f != nullptr;
+                    std::vector<float> f32;
+                    for (int i = 0; i < n_weights(); i++) {
+                        Tensor& w = weight(i);
+                        synth_weight_bytes(params, dtype_, seed, i, f32, w.data_ptr<uint8_t>(), w.nbytes());
+                        if (ok) ok = std::fwrite(w.data_ptr<uint8_t>(), 1, w.nbytes(), f) == w.nbytes();
+                        w.device_weight();
+                    }
+                    if (f) ok = (std::fclose(f) == 0) && ok;
+                    if (ok) std::rename(tmp.c_str(), path.c_str());
+                    else std::remove(tmp.c_str());
+                    ::flock(fd, LOCK_UN);
+                    ::close(fd);
+                    return true;
                 }
-                if (f) ok = (std::fclose(f) == 0) && ok;
-                if (ok) std::rename(tmp.c_str(), path.c_str());
-                else std::remove(tmp.c_str());
-                std::remove(lock.c_str());
-                return true;
+                ::flock(fd, LOCK_UN);
+            } else {
+                ::flock(fd, LOCK_SH);                            // blocks while the generator works
+                ::flock(fd, LOCK_UN);
             }
-            for (int waited = 0; waited < 1200 && !ready(); waited++) {          // somebody else generates: up to two minutes
-                struct stat st;
-                if (::stat(lock.c_str(), &st) != 0 && !ready()) break;            // the generator gave up
-                std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            }
-            if (!ready()) return false;
+            ::close(fd);
+            if (!ready()) return false;                          // (the generator could not write the file: everybody for themselves)
         }
         std::FILE* f = std::fopen(path.c_str(), "rb");
         if (!f) return false;
