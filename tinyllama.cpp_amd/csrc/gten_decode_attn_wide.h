@@ -839,23 +839,36 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
     }
     const float2 rot = a.rope_now[t & 31];
     __builtin_amdgcn_sched_barrier(0);
+    // (round 4: 16-byte requests.  Piece q = tid + 256 k, k < 4: row q / 4, dwords 4 (q % 4) .. + 3 of its 17; then dword 16 of row
+    //  tid: FIVE requests per thread and matrix instead of seventeen dword ones.  The texture path spends ~25 cycles per wave
+    //  instruction whatever its width, and with sixteen of these workgroups per CU and launch that was ~54 k of its cycles.
+    //  A slice is 4-byte aligned only, which gfx9 global loads take.)
     unsigned kw[NW], vw[NW];
     {
-        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
         const gmem_u32 kbase = as_global(a.kcache + (size_t)g * head_bytes), vbase = as_global(a.vcache + (size_t)g * head_bytes);
         const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
         const int last = a.max_ctx - 1 - c0;
         // (all of K first, then all of V: requests return in order, and the scores must not wait for the V chunk)
-        unsigned off[NW];
+        unsigned off[5];
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            off[k] = (unsigned)(c0 + min(row, last)) * pitch_w + (unsigned)w;
-            kw[k] = kbase[off[k]];
-            row += 256 / NW; w += 256 % NW;
-            if (w >= NW) { w -= NW; row++; }
+        for (int k = 0; k < 4; k++) {
+            const int q = (int)threadIdx.x + 256 * k;
+            off[k] = (unsigned)(c0 + min(q >> 2, last)) * pitch_w + (unsigned)(4 * (q & 3));
         }
+        off[4] = (unsigned)(c0 + min((int)threadIdx.x, last)) * pitch_w + 16u;
 #pragma unroll
-        for (int k = 0; k < NW; k++) vw[k] = vbase[off[k]];
+        for (int k = 0; k < 4; k++) {
+            const u4u x = *(const __attribute__((address_space(1))) u4u*)(kbase + off[k]);
+            kw[4 * k] = x.x; kw[4 * k + 1] = x.y; kw[4 * k + 2] = x.z; kw[4 * k + 3] = x.w;
+        }
+        kw[16] = kbase[off[4]];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u4u x = *(const __attribute__((address_space(1))) u4u*)(vbase + off[k]);
+            vw[4 * k] = x.x; vw[4 * k + 1] = x.y; vw[4 * k + 2] = x.z; vw[4 * k + 3] = x.w;
+        }
+        vw[16] = vbase[off[4]];
     }
     __builtin_amdgcn_sched_barrier(0);
     const int n = a.step->n, pos = n - 1;
@@ -879,8 +892,14 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
         if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
     }
     // the K chunk goes to LDS now; the V chunk stays in its registers, in flight, until the scores are done
+    // (register j of piece k = dword 4 (q % 4) + j of row q / 4, q = tid + 256 k; register 16 = dword 16 of row tid)
 #pragma unroll
-    for (int k = 0; k < NW; k++) kl[threadIdx.x + k * 256] = kw[k];
+    for (int k = 0; k < 4; k++) {
+        const int q = (int)threadIdx.x + 256 * k;
+#pragma unroll
+        for (int j = 0; j < 4; j++) kl[(q >> 2) * NW + 4 * (q & 3) + j] = kw[4 * k + j];
+    }
+    kl[threadIdx.x * NW + 16] = kw[16];
     __syncthreads();
     if (pw < 2 && has_new) {
         // the new position's K / V slice comes from the chip (the cache row is being written by this very launch): K patched
@@ -962,14 +981,15 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
     }
     {
         // the V chunk lands in LDS (its requests have been in flight since kernel entry); the new position's slice from the chip
-        int row = (int)threadIdx.x / NW, w = (int)threadIdx.x % NW;
+        // (the registers hold the pieces the 16-byte requests fetched: see the requests above)
         const int newrow = has_new ? pos - c0 : -1;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            vl[threadIdx.x + k * 256] = (row == newrow) ? vnew[w] : vw[k];
-            row += 256 / NW; w += 256 % NW;
-            if (w >= NW) { w -= NW; row++; }
+        for (int k = 0; k < 4; k++) {
+            const int q = (int)threadIdx.x + 256 * k, row = q >> 2, w0 = 4 * (q & 3);
+#pragma unroll
+            for (int j = 0; j < 4; j++) vl[row * NW + w0 + j] = (row == newrow) ? vnew[w0 + j] : vw[4 * k + j];
         }
+        vl[threadIdx.x * NW + 16] = ((int)threadIdx.x == newrow) ? vnew[16] : vw[16];
     }
     __syncthreads();
 #pragma unroll
