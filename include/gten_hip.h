@@ -203,6 +203,10 @@ int gten_hip_row_segments_ok(int n_embd, int n_ffn, int n_heads, int n_kv_heads,
 typedef struct { void* dst; const void* src; size_t bytes; } gten_hip_copy_range;
 int gten_hip_copy_ranges(const gten_hip_copy_range* ranges, int n);
 
+/* the greedy sampler's argmax of one row of f32 logits on the device (tinyllama.cpp:416-424: strict >, the first maximum wins):
+ * out[0] = the id.  Asynchronous; used by the batched prompt path so that a prompt's first id costs 4 bytes of copy, not 128 KB. */
+int gten_hip_argmax_row(const float* logits, int n, int32_t* out);
+
 /* ---- single-token decode fast path -------------------------------------
  * One call = one decoded token = TinyLlama::logits(tokens, start_pos = n-1)
  * (tinyllama.cpp:45-61) plus the greedy argmax of tinyllama.cpp:416-424, for a

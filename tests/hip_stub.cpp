@@ -134,6 +134,15 @@ int gten_hip_matmul_2d(const void* x, int, size_t, const void*, int, void* out, 
 int gten_hip_set_prefill_exact(int) { return 0; }
 int gten_hip_set_decode_exact(int) { return 0; }
 int gten_hip_set_decode_persistent(int) { return 0; }
+int gten_hip_argmax_row(const float* logits, int n, int32_t* out)
+{
+    if (!logits || !out || n <= 0) return fail("argmax_row: arguments");
+    int best = 0;
+    for (int i = 1; i < n; i++)
+        if (logits[i] > logits[best]) best = i;
+    out[0] = best;
+    return 0;
+}
 int gten_hip_set_lane_skip(int) { return 0; }
 int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsigned* abort_code, unsigned*, int)
 {

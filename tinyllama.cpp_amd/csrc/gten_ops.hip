@@ -927,6 +927,41 @@ int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitc
     return 0;
 }
 
+// the greedy sampler's argmax on the device (tinyllama.cpp:416-424: strict >, the first maximum wins), one row of f32 logits
+__global__ __launch_bounds__(1024) void k_argmax_row(const float* __restrict__ v, int n, int32_t* __restrict__ out)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = v[i];
+        if (x > best) { best = x; idx = i; }                 // (ascending i per thread: its first maximum)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { bv[wid] = best; bi[wid] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[0] = (idx == 0x7fffffff) ? 0 : idx;
+    }
+}
+
+int gten_hip_argmax_row(const float* logits, int n, int32_t* out)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(logits && out && n > 0, "argmax_row: bad arguments");
+    GTR_LAUNCH(KT_ELEMWISE, k_argmax_row, dim3(1), dim3(1024), 0, logits, n, out);
+    return 0;
+}
+
 int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, int dtype,
                       size_t q_pitch, size_t kv_pitch, size_t out_pitch,
                       int n, int n_heads, int n_kv_heads, int d_head, int start_pos)

@@ -85,7 +85,7 @@ class GtenHip:
         "gten_hip_memcpy_d2d", "gten_hip_prof_enable", "gten_hip_prof_read", "gten_hip_prof_family_name",
         "gten_hip_selftest_q8scale", "gten_hip_row_bytes", "gten_hip_pack_weight", "gten_hip_token_embed",
         "gten_hip_block_rows", "gten_hip_set_block_rows", "gten_hip_matmul_2d", "gten_hip_rms_norm", "gten_hip_rotary_emb", "gten_hip_silu", "gten_hip_mul",
-        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_set_prefill_exact", "gten_hip_set_decode_exact", "gten_hip_set_decode_persistent", "gten_hip_persist_status", "gten_hip_set_row_segments", "gten_hip_row_segments_ok", "gten_hip_copy_ranges",
+        "gten_hip_add", "gten_hip_qkv_attn", "gten_hip_argmax_row", "gten_hip_set_prefill_exact", "gten_hip_set_decode_exact", "gten_hip_set_decode_persistent", "gten_hip_persist_status", "gten_hip_set_row_segments", "gten_hip_row_segments_ok", "gten_hip_copy_ranges",
         # fused single-token decoder: driven from C++ (host/tinyllama_model.h), listed here so that
         # the export check covers the whole header
         "gten_hip_decoder_create", "gten_hip_decoder_destroy", "gten_hip_decoder_set_tokens",

@@ -494,16 +494,20 @@ public:
             GTEN_HIP_OK(gten_hip_copy_ranges(ranges.data(), (int)ranges.size()));
         }
         first->assign((size_t)K, 0);
+        // a prompt's first id: its logits row stays on the device and so does the sampler (gten_hip_argmax_row, the greedy rule
+        // of tinyllama.cpp:416-424) -- the K ids come back in ONE 4 K-byte copy and one wait instead of K copies of 128 KB, K
+        // waits and K host loops over the vocabulary (round 4); a caller that wants a prompt's logits gets them as before
+        if (!first_ids_) first_ids_.reset(new Tensor({kPreMax}, kInt32));
+        int32_t* ids_dev = (int32_t*)first_ids_->device_ptr_mut();
         for (int k = 0; k < K; k++) {
             const Tensor lg = pre_->logits_of_row(hidden, starts[(size_t)k + 1] - 1);
-            const float* p = lg.data_ptr<float>();                   // (waits for the current stream)
-            int best_i = 0;
-            float best = -std::numeric_limits<float>::infinity();
-            for (int j = 0; j < lg.numel(); j++)
-                if (p[j] > best) { best = p[j]; best_i = j; }
-            (*first)[(size_t)k] = best_i;
-            if (logits_out && (*logits_out)[(size_t)k]) std::memcpy((*logits_out)[(size_t)k], p, (size_t)lg.numel() * sizeof(float));
+            GTEN_HIP_OK(gten_hip_argmax_row((const float*)lg.device_ptr(), lg.numel(), ids_dev + k));
+            if (logits_out && (*logits_out)[(size_t)k])
+                std::memcpy((*logits_out)[(size_t)k], lg.data_ptr<float>(), (size_t)lg.numel() * sizeof(float));   // (waits for the stream)
         }
+        std::vector<int32_t> got((size_t)K);
+        GTEN_HIP_OK(gten_hip_memcpy_d2h(got.data(), ids_dev, (size_t)K * sizeof(int32_t)));
+        for (int k = 0; k < K; k++) (*first)[(size_t)k] = got[(size_t)k];
     }
     // one prompt onto sequence seq_i's caches; returns the argmax of its logits (logits_out may be null)
     int prefill(int seq_i, const std::vector<int32_t>& prompt, float* logits_out = nullptr)
@@ -813,6 +817,7 @@ public:
 private:
     std::vector<std::unique_ptr<TinyLlama>> seqs_;
     std::unique_ptr<TinyLlama> pre_;         // the shared row matrix of batched prompt processing (prefill_many), made on first use
+    std::unique_ptr<Tensor> first_ids_;      // [kPreMax] int32 on the device: the prompts' first ids (gten_hip_argmax_row)
     gten_hip_decoder* dec_ = nullptr;
     int n_ctx_;
     ModuleDtype dtype_;
