@@ -66,6 +66,43 @@ def test_batch_slots_against_the_oracle(hip, oracle, name, wd, ad, n_seq):
     print(f"{name} S={n_seq}: worst rms {worst[0]:.4g} max {worst[1]:.4g} against the oracle")
 
 
+def test_wide_batch_with_three_heads_per_group_takes_the_per_head_attention(hip, oracle):
+    """3 query heads per kv head is not a group size the grouped attention kernels serve: a wide batch (16 sequences, W.x on the
+    matrix cores) then runs the per-head one-launch attention kernel with the sequence in the grid -- held to the oracle here,
+    slot by slot, across the attention chunk boundary (round 4: this combination had no test)"""
+    pkg = load_package()
+    host = pkg.load_host()
+    ocfg = tiny_config(Q4, Q8, n_embd=768, n_ffn=512, n_heads=12, n_kv_heads=4, max_ctx=320, n_layers=2)
+    cfg = host_cfg(ocfg)
+    n_seq, N = 16, 262
+    checks = (1, 2, 40, 255, 256, 257, N)
+    watch = (0, 7, 15)
+    streams = [host.synthetic_tokens(N, seed=900 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
+    weights = [host.synth_weight(cfg, 8642, i) for i in range(len(cfg.weight_shapes()))]
+    batch = host.batch(cfg, n_seq)
+    for i, w in enumerate(weights):
+        batch.set_weight(i, w)
+    for q in range(n_seq):
+        batch.decode_begin(q, streams[q])
+    got = {}
+    for n in range(1, N + 1):
+        batch.decode_step(n, n % 2 == 0)
+        if n in checks:
+            got[n] = {q: (batch.decode_result(q, n), batch.logits(q).copy()) for q in watch}
+    batch.close()
+    for q in watch:
+        om = oracle.model(ocfg)
+        for i, w in enumerate(weights):
+            om.set_weight(i, w)
+        for n in range(1, N + 1):
+            want = om.logits(streams[q][:n], n - 1)
+            if n in checks:
+                gid, glog = got[n][q]
+                check_logits("q4", glog, want, float(want.std()))
+                assert gid == int(np.argmax(glog))
+        om.close()
+
+
 @pytest.fixture(scope="module")
 def full_golden():
     path = os.path.join(G, "full_model_golden.npz")

@@ -203,10 +203,11 @@ extern "C" int gten_hip_set_decode_exact(int on)
 static bool attention_grouped_ok(const AttnArgs& t, int n_seq)
 {
     const int grp = t.n_heads / t.n_kv;
-    const bool off = false;
     const int min_seq = 8;                                       // measured (q4, ctx 2048): 8 sequences +6 %, 4 and 2 slower
     if (t.adtype == GTEN_F16 && n_seq < 16) return false;        // f16 below 16 sequences: the per-head kernels (one launch, k_dec_attn_one64)
-    return !off && n_seq >= min_seq && (t.adtype == GTEN_Q8 || t.adtype == GTEN_F16) && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
+    // (group sizes other than 8 / 4 / 2 / 1 and head widths other than 64 keep the per-head kernels at every sequence count:
+    //  tests/test_multiseq_gpu.py decodes such a model -- 3 query heads per kv head -- against single-sequence decode)
+    return n_seq >= min_seq && (t.adtype == GTEN_Q8 || t.adtype == GTEN_F16) && t.d_head == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1);
 }
 
 static int grp_shift1_of(int n_heads, int n_kv)
