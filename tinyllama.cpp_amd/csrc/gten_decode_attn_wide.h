@@ -839,36 +839,34 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
     }
     const float2 rot = a.rope_now[t & 31];
     __builtin_amdgcn_sched_barrier(0);
-    // (round 4: 16-byte requests.  Piece q = tid + 256 k, k < 4: row q / 4, dwords 4 (q % 4) .. + 3 of its 17; then dword 16 of row
-    //  tid: FIVE requests per thread and matrix instead of seventeen dword ones.  The texture path spends ~25 cycles per wave
-    //  instruction whatever its width, and with sixteen of these workgroups per CU and launch that was ~54 k of its cycles.
-    //  A slice is 4-byte aligned only, which gfx9 global loads take.)
-    unsigned kw[NW], vw[NW];
+    // (round 4: 16-byte requests, FIVE per thread and matrix instead of seventeen dword ones -- the texture path spends ~25 cycles
+    //  per wave instruction whatever its width.  Piece q = tid + 256 k, k < 5: row q / 5, part q % 5 = bytes 16 part .. + 15 of the
+    //  row's 68-byte slice; the fifth part holds the slice's last dword and 12 bytes of whatever follows (the next head's slice or
+    //  the next row; for the cache's very last row the piece starts 12 bytes early instead).  Five neighbouring lanes fetch one
+    //  row's slice in ONE instruction: with four pieces per row and the last dwords as a fifth request of their own -- 256 rows x
+    //  4 bytes out of 256 different lines, long after those lines were first touched -- the requests alone took 21.1 / 39.9 us
+    //  per launch at 64 / 128 sequences against 18.2 / 33.5 us this way.  A slice is 4-byte aligned only, which gfx9 global loads take.)
+    typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
+    u4u kw[5], vw[5];
+    int prow[5], ppart[5];
+    bool pback[5];
     {
-        typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
         const gmem_u32 kbase = as_global(a.kcache + (size_t)g * head_bytes), vbase = as_global(a.vcache + (size_t)g * head_bytes);
         const unsigned pitch_w = (unsigned)(a.kv_pitch >> 2);
         const int last = a.max_ctx - 1 - c0;
-        // (all of K first, then all of V: requests return in order, and the scores must not wait for the V chunk)
         unsigned off[5];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             const int q = (int)threadIdx.x + 256 * k;
-            off[k] = (unsigned)(c0 + min(q >> 2, last)) * pitch_w + (unsigned)(4 * (q & 3));
+            prow[k] = q / 5; ppart[k] = q - 5 * prow[k];
+            pback[k] = ppart[k] == 4 && prow[k] >= last;
+            off[k] = (unsigned)(c0 + min(prow[k], last)) * pitch_w + (unsigned)(4 * ppart[k]) - (pback[k] ? 3u : 0u);
         }
-        off[4] = (unsigned)(c0 + min((int)threadIdx.x, last)) * pitch_w + 16u;
+        // (all of K first, then all of V: requests return in order, and the scores must not wait for the V chunk)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u4u x = *(const __attribute__((address_space(1))) u4u*)(kbase + off[k]);
-            kw[4 * k] = x.x; kw[4 * k + 1] = x.y; kw[4 * k + 2] = x.z; kw[4 * k + 3] = x.w;
-        }
-        kw[16] = kbase[off[4]];
+        for (int k = 0; k < 5; k++) kw[k] = *(const __attribute__((address_space(1))) u4u*)(kbase + off[k]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u4u x = *(const __attribute__((address_space(1))) u4u*)(vbase + off[k]);
-            vw[4 * k] = x.x; vw[4 * k + 1] = x.y; vw[4 * k + 2] = x.z; vw[4 * k + 3] = x.w;
-        }
-        vw[16] = vbase[off[4]];
+        for (int k = 0; k < 5; k++) vw[k] = *(const __attribute__((address_space(1))) u4u*)(vbase + off[k]);
     }
     __builtin_amdgcn_sched_barrier(0);
     const int n = a.step->n, pos = n - 1;
@@ -891,15 +889,14 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
         store_global<uint8_t>(blk + 2 + (t & 31), (uint8_t)dq[t]);
         if ((t & 31) == 0) store_global<uint16_t>(blk, d16[4 * (GRP + pw) + (t >> 5)]);
     }
-    // the K chunk goes to LDS now; the V chunk stays in its registers, in flight, until the scores are done
-    // (register j of piece k = dword 4 (q % 4) + j of row q / 4, q = tid + 256 k; register 16 = dword 16 of row tid)
+    // the K chunk goes to LDS now ([row][17 dwords], as the slices lie in the cache); the V chunk stays in its registers, in
+    // flight, until the scores are done
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int q = (int)threadIdx.x + 256 * k;
-#pragma unroll
-        for (int j = 0; j < 4; j++) kl[(q >> 2) * NW + 4 * (q & 3) + j] = kw[4 * k + j];
+    for (int k = 0; k < 5; k++) {
+        unsigned* dst = kl + prow[k] * NW + 4 * ppart[k];
+        dst[0] = pback[k] ? kw[k].w : kw[k].x;
+        if (ppart[k] < 4) { dst[1] = kw[k].y; dst[2] = kw[k].z; dst[3] = kw[k].w; }
     }
-    kl[threadIdx.x * NW + 16] = kw[16];
     __syncthreads();
     if (pw < 2 && has_new) {
         // the new position's K / V slice comes from the chip (the cache row is being written by this very launch): K patched
@@ -981,15 +978,15 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
     }
     {
         // the V chunk lands in LDS (its requests have been in flight since kernel entry); the new position's slice from the chip
-        // (the registers hold the pieces the 16-byte requests fetched: see the requests above)
         const int newrow = has_new ? pos - c0 : -1;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int q = (int)threadIdx.x + 256 * k, row = q >> 2, w0 = 4 * (q & 3);
-#pragma unroll
-            for (int j = 0; j < 4; j++) vl[row * NW + w0 + j] = (row == newrow) ? vnew[w0 + j] : vw[4 * k + j];
+        for (int k = 0; k < 5; k++) {
+            unsigned* dst = vl + prow[k] * NW + 4 * ppart[k];
+            const unsigned* nw = vnew + 4 * ppart[k];
+            const bool isnew = prow[k] == newrow;
+            dst[0] = isnew ? nw[0] : (pback[k] ? vw[k].w : vw[k].x);
+            if (ppart[k] < 4) { dst[1] = isnew ? nw[1] : vw[k].y; dst[2] = isnew ? nw[2] : vw[k].z; dst[3] = isnew ? nw[3] : vw[k].w; }
         }
-        vl[threadIdx.x * NW + 16] = ((int)threadIdx.x == newrow) ? vnew[16] : vw[16];
     }
     __syncthreads();
 #pragma unroll
