@@ -244,7 +244,7 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     constexpr size_t NW = (ADT == GTEN_Q8) ? 17 : 32;
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
     if constexpr (ADT == GTEN_Q8) if (grouped_mm(t, n_seq)) {
-        const size_t smem = (size_t)2 * DEC_CHUNK * 68 + 16 * 64 + 32 * 4 + 8 * 4 + (size_t)4 * (DEC_MAXGRP + 2) * 2 + 128 + 128 * 4 + 80 + 64;
+        const size_t smem = (size_t)DEC_CHUNK * 68 + 2 * 8 * 264 * 2 + 16 * 64 + 32 * 4 + 8 * 4 + (size_t)4 * (DEC_MAXGRP + 2) * 2 + 128 + 128 * 4 + 80 + 64;
         GTR_REQUIRE((n_seq * t.n_chunks) % 8 == 0, "decoder: %d sequences x %d chunks is not a multiple of 8", n_seq, t.n_chunks);
         DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_mm_g<GRP>), dim3(n_seq * t.n_chunks * t.n_kv), dim3(256), smem, t, n_seq);
         return 0;
