@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                     for (int kk = 0; kk < 4; kk++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            s_vt[(16 * qtr + 4 * kk + j) * AT_VTPITCH + pos] = f2hv((float)(int8_t)(raw.v[kk] >> (8 * j)) * d);
+                            // (column ^ 16 x (row / 16): the four quarters of a position -- rows 16 apart, 576 dwords, the SAME bank
+                            //  with any 16-byte aligned pitch -- land 8 dwords apart instead of on top of each other)
+                            s_vt[(16 * qtr + 4 * kk + j) * AT_VTPITCH + (pos ^ (16 * qtr))] = f2hv((float)(int8_t)(raw.v[kk] >> (8 * j)) * d);
                     if (vs + 1 < AT_TILE / AT_VSUB && c0 + AT_VSUB <= r_last) vload(c0 + AT_VSUB);
                 } else {
                     float* dst = s_v + pos * 64 + 16 * qtr;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 // (positions past r_last meet p = 0; their V rows are clamped reads of real rows)
 #pragma unroll
                 for (int ks = 0; ks < AT_VSUB / 32; ks++) {
-                    const h8 bv = *(const h8*)(s_vt + (16 * w + lc) * AT_VTPITCH + 32 * ks + 8 * lq);
+                    const h8 bv = *(const h8*)(s_vt + (16 * w + lc) * AT_VTPITCH + ((32 * ks + 8 * lq) ^ (16 * w)));
 #pragma unroll
                     for (int rt2 = 0; rt2 < 2; rt2++) {
                         const h8 av = *(const h8*)(s_ph + (16 * rt2 + lc) * AT_PHPITCH + vs * AT_VSUB + 32 * ks + 8 * lq);
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 float* dst = s_v + pos * 64 + 16 * qtr;
                 if (FAST) {
 #pragma unroll
-                    for (int e = 0; e < 16; e++) ((uint16_t*)s_vt)[(16 * qtr + e) * AT_VTPITCH + pos] = (uint16_t)(raw[e >> 1] >> (16 * (e & 1)));
+                    for (int e = 0; e < 16; e++) ((uint16_t*)s_vt)[(16 * qtr + e) * AT_VTPITCH + (pos ^ (16 * qtr))] = (uint16_t)(raw[e >> 1] >> (16 * (e & 1)));   // (swizzle: see k_attn_tiled_q8)
                 } else
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
                 // wave w: elements 16 w .. 16 w + 15 of both 16-row tiles (positions past r_last meet p = 0)
 #pragma unroll
                 for (int ks = 0; ks < AT_VSUB / 32; ks++) {
-                    const h8 bv = *(const h8*)(s_vt + (16 * w + lc) * AT_VTPITCH + 32 * ks + 8 * lq);
+                    const h8 bv = *(const h8*)(s_vt + (16 * w + lc) * AT_VTPITCH + ((32 * ks + 8 * lq) ^ (16 * w)));
 #pragma unroll
                     for (int rt2 = 0; rt2 < 2; rt2++) {
                         const h8 av = *(const h8*)(s_ph + (16 * rt2 + lc) * AT_PHPITCH + vs * AT_VSUB + 32 * ks + 8 * lq);
