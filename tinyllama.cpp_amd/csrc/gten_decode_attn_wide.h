@@ -810,7 +810,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const 
 
     // (28 KB per workgroup, five workgroups per CU: the V chunk waits in registers until the scores are done and then takes
     //  K's place; with a region of its own -- 36 KB, four per CU -- 256 sequences decoded at 68.9 k instead of 71.0 k tok/s,
-    //  64 at 37.0 k instead of 37.3 k)
+    //  64 at 37.0 k instead of 37.3 k.  SIX per CU -- 27 024 bytes with the new row's scratch over the reduction buffer and the
+    //  zero rows of the A operand supplied by the lanes, 78 VGPRs with the pieces' coordinates recomputed where used, no spill,
+    //  bit-identical -- measured 3.70 against 3.61 ms per step at 256 sequences, 1.762 against 1.717 at 64: not kept)
     unsigned* kl = (unsigned*)g_smem;                             // [256][17]: the chunk's K slices as they lie in the cache; dead after
     unsigned* vl = kl;                                            // the scores: the V chunk [256][17] takes their place
     _Float16* pl = (_Float16*)(kl + DEC_CHUNK * NW);              // the probability rows [2 halves][8 heads][PP]
