@@ -776,9 +776,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_one_g(const AttnArgs a0)
 // The VALU pair above spends ~1900 instructions per thread on a chunk (scores 8 heads x 17 dot4, exponentials and Q8
 // roundings per (head, position), 2 VALU operations per p.V term); merged as it stands it lost to the pair (occupancy,
 // DESIGN.md 3.3).  Here the two contractions are matrix instructions and a workgroup needs ~1000 instructions per thread:
-//   * the K and the V chunk are requested at entry as COALESCED dwords exactly as they lie in the cache (256 positions x
-//     17 dwords each, 17 requests per thread and matrix); K is parked in LDS at once, V stays in registers until the scores
-//     are done (its arrival hides behind them) and then takes K's place;
+//   * the K and the V chunk are requested at entry exactly as they lie in the cache (256 positions x 17 dwords each; five
+//     16-byte requests per thread and matrix, five neighbouring lanes per row: see the requests below); K is parked in LDS at
+//     once, V stays in registers until the scores are done (its arrival hides behind them) and then takes K's place in LDS;
 //   * scores: v_mfma_i32_16x16x32_i8, A = the group's head vectors (rows 8..15 zero), B = 16 positions of K; one
 //     instruction per (16 positions, quant block) gives the exact integer block dots, scaled dq dk as the scalar code;
 //   * chunk-local softmax (k_dec_attn_one64's scheme, hardware exponential), probabilities rounded to Q8 blocks of 32
@@ -792,7 +792,9 @@ typedef int att_v4i __attribute__((ext_vector_type(4)));
 // (Measured and not kept: the same kernel PERSISTENT -- at most 4 workgroups per CU walking the items, the next item's K / V
 // chunk requested into registers while the current one is computed, so that loading and computing overlap instead of
 // alternating in two rounds: 64 us against 37 us per launch at 64 sequences.  The 40 prefetch registers pushed the
-// compute phase into scratch, and a wait for a scratch reload is a wait for every older request -- the prefetch itself.)
+// compute phase into scratch, and a wait for a scratch reload is a wait for every older request -- the prefetch itself.
+// Round 4, without scratch: a workgroup walking 2 / 4 / 8 consecutive chunks of its (sequence, kv head) with the next chunk's
+// requests in flight during the current one's arithmetic, and the other experiments of DESIGN.md 3.4 (5) -- none faster.)
 template <int GRP>
 __global__ __launch_bounds__(256) void k_dec_attn_mm_g(const AttnArgs a0, const int n_seq)
 {
