@@ -83,6 +83,8 @@ def parse_args(argv=None):
                     help="slots of the serving leg (0: --wide-streams); measured, 1024 prompts (its first 256 alone): 64 slots 27.2k (24.5k) new ids/s, "
                          "128 34.7k (28.1k), 256 37.0k (27.5k), 384 26.4k, 512 22.1k")
     ap.add_argument("--serve-slice", type=int, default=8, help="shared steps per slice of the serving leg")
+    ap.add_argument("--serve-spares", type=int, default=-1,
+                    help="cache sets the serving leg fills ahead of the slots that will take them (-1: the library's default, a quarter of the slots, at most 64; 0: none)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
                     help="how the (untimed) context below the timed window is produced: single-token decode steps "
@@ -943,9 +945,11 @@ def worker(args, rank, local_rank, world, dist):
       with Leg(out, "serving"):
             S = args.serve_slots or args.wide_streams
             hip.set_lane_skip(args.lane_skip)
+            batch_spares = args.serve_spares
             batch = host.batch(cfg, S)
             batch.load_synthetic(args.seed)
             prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
+            batch.set_serve_spares(batch_spares)
             batch.serve(prompts[:S], N_CTX, -1, args.serve_slice, max_new=4)           # warm-up: graphs, first-use allocations
             t0 = time.perf_counter()
             got, st = batch.serve(prompts, N_CTX, -1, args.serve_slice, max_new_each=budgets)

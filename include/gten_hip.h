@@ -290,6 +290,10 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dec, const int* n_first, c
 int gten_hip_decoder_slot_start(gten_hip_decoder* dec, int seq, int n_first);
 int gten_hip_decoder_slot_start_until(gten_hip_decoder* dec, int seq, int n_first, int n_last);
 int gten_hip_decoder_slot_park(gten_hip_decoder* dec, int seq);
+/* a PARKED slot gets another set of caches (kv[layer], n_layers entries; the set it had stays untouched): the caller fills
+ * spare sets with the prompts to come while every slot is busy and hands a ready one to the next slot that ends
+ * (TinyLlamaBatch::serve).  The next slot_start / slots_apply of the slot makes the shared steps use it. */
+int gten_hip_decoder_slot_bind(gten_hip_decoder* dec, int seq, const gten_hip_kv_ptrs* kv);
 /* several slots at once, one wait at the end: slot seqs[i] is started at n_first[i] with its last step n_last[i] (0: none) and --
  * when tokens and tokens[i] are given -- its ids [0, n_first[i]) set; n_first[i] == 0 parks it.  A sequence may appear once. */
 int gten_hip_decoder_slots_apply(gten_hip_decoder* dec, int count, const int* seqs, const int* n_first, const int* n_last,

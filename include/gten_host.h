@@ -116,6 +116,10 @@ int  gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int
 /* tests: k > 0 fixes the admission schedule of gten_host_batch_serve -- exactly k prompts are processed beside every slice
  * (as far as free slots and the queue allow) instead of as many as fit while it runs; 0 restores the default */
 int  gten_host_batch_set_serve_schedule(gten_host_batch* b, int k);
+/* cache sets beyond the sequences' own that gten_host_batch_serve fills AHEAD of the slots that will take them, so that a slot
+ * which ends joins the next slice with a prompt that is already processed (gten_hip_decoder_slot_bind): -1 = a quarter of the
+ * slots, at most 64, for batches of 16 sequences and more (the default), 0 = a prompt is processed only once a slot is free */
+int  gten_host_batch_set_serve_spares(gten_host_batch* b, int n);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
 int  gten_host_batch_decode_steps(gten_host_batch* b, int n_first, int count, int use_graph);   /* asynchronous: count consecutive steps, four per graph replay */

@@ -323,6 +323,13 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
     dc->slots[(size_t)seq] = Slot{1, 0, 0};
     return 0;
 }
+int gten_hip_decoder_slot_bind(gten_hip_decoder* dc, int seq, const gten_hip_kv_ptrs* kv)
+{
+    if (!dc || !kv || seq < 0 || seq >= dc->n_seq) return fail("slot_bind: sequence %d", seq);
+    slots_view(dc);
+    if (dc->slots[(size_t)seq].advance != 0) return fail("slot_bind: slot %d is not parked", seq);
+    return 0;                                               // (the stand-in decodes without caches)
+}
 int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seqs, const int* n_first, const int* n_last, const int32_t* const* tokens)
 {
     if (!dc || count < 0 || (count > 0 && (!seqs || !n_first || !n_last))) return fail("slots_apply: arguments");

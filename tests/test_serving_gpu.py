@@ -208,6 +208,47 @@ def test_every_admission_schedule_gives_the_same_ids(hip, name, wd, ad):
     b.close()
 
 
+def test_prompts_processed_ahead_onto_spare_cache_sets_give_the_same_ids(hip):
+    """serve() fills SPARE cache sets with the prompts to come while every slot is busy and binds a ready set to the next slot
+    that ends (gten_hip_decoder_slot_bind) -- which slot, which set and which slice a prompt joins all change with the number
+    of spares and the schedule; the ids must not: 0 / 3 / 16 / default spares x two schedules x two slice lengths, 16 slots,
+    against the same queue through ONE sequence's generate; afterwards every slot is back on its own sequence's caches
+    (a fixed batch generates the same ids as before the queue)."""
+    from helpers import Q4, Q8
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
+    weights = [host.synth_weight(cfg, 4711, i) for i in range(len(cfg.weight_shapes()))]
+    lengths = [16 + (37 * i) % 200 for i in range(60)] + [5, 300, 17, 256]
+    prompts = make_prompts(host, cfg, lengths, 2000)
+    budgets = np.array([3 + (11 * i) % 40 for i in range(len(prompts))], np.int32)
+    total = 320
+    b = host.batch(cfg, 16)
+    for i, w in enumerate(weights):
+        b.set_weight(i, w)
+    cap = max(len(p) for p in prompts[:16]) + 6
+    fixed_before = b.generate(prompts[:16], cap)
+    runs = []
+    try:
+        for spares in (0, 3, 16, -1):
+            for k, slice_steps in ((0, 8), (2, 5)):
+                b.set_serve_spares(spares)
+                b.set_serve_schedule(k)
+                got, st = b.serve(prompts, total, -1, slice_steps, max_new_each=budgets)
+                runs.append(([g.tolist() for g in got], spares, k, st["steps"]))
+    finally:
+        b.set_serve_schedule(0)
+        b.set_serve_spares(-1)
+    for got, spares, k, _ in runs[1:]:
+        assert got == runs[0][0], (spares, k)
+    for j, g in enumerate(runs[0][0]):
+        assert len(g) == min(total, len(prompts[j]) + int(budgets[j])), (j, len(g))
+    assert min(r[3] for r in runs if r[1] != 0) <= min(r[3] for r in runs if r[1] == 0)      # (ahead: never more shared steps)
+    fixed_after = b.generate(prompts[:16], cap)
+    assert [x.tolist() for x in fixed_after] == [x.tolist() for x in fixed_before]
+    b.close()
+
+
 def test_full_size_queue_is_repeatable_and_equals_the_fixed_batch(hip):
     """TinyLlama-1.1B shapes, 64 slots, prompts of 64..512 ids processed on stream 1 BESIDE the shared steps: the ids must
     not depend on what overlapped what.  They did for most of round 2 (packed-f32 instructions beside another

@@ -1640,6 +1640,23 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
     return 0;
 }
 
+// A PARKED slot gets another set of caches (continuous batching with prompts processed ahead of the slots that will take
+// them: the host fills spare cache sets while every slot is busy and hands a ready set to the next slot that ends).  Only the
+// host copy of the table changes here; the device rows follow when the slot is started (slots_apply / slot_start).
+int gten_hip_decoder_slot_bind(gten_hip_decoder* dc, int seq, const gten_hip_kv_ptrs* kv)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc && kv && seq >= 0 && seq < dc->n_seq, "decoder_slot_bind: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
+    GTR_REQUIRE(!dc->kv_parked.empty() && dc->kv_parked[(size_t)seq], "decoder_slot_bind: slot %d is not parked", seq);
+    const size_t off = (size_t)seq * dc->d.n_layers * 2;
+    for (int l = 0; l < dc->d.n_layers; l++) {
+        GTR_REQUIRE(kv[l].kcache && kv[l].vcache, "decoder_slot_bind: null cache pointer (layer %d)", l);
+        dc->kv_real[off + 2 * (size_t)l] = kv[l].kcache;
+        dc->kv_real[off + 2 * (size_t)l + 1] = kv[l].vcache;
+    }
+    return 0;
+}
+
 int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
 {
     GTR_NEED_INIT();

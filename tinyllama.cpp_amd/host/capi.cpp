@@ -323,6 +323,13 @@ int gten_host_batch_set_serve_schedule(gten_host_batch* b, int k)
     return 0;
 }
 
+int gten_host_batch_set_serve_spares(gten_host_batch* b, int n)
+{
+    if (!b || n < -1 || n > 256) return -4;
+    b->batch->set_serve_spares(n);
+    return 0;
+}
+
 int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
                           int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats)
 {

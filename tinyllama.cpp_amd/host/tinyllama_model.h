@@ -22,6 +22,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <deque>
 
 #include "../gten/gten.h"
 #include "synth.h"
@@ -431,6 +432,18 @@ public:
 
     int n_seq() const { return (int)seqs_.size(); }
     TinyLlama& seq(int i) { return *seqs_[(size_t)i]; }
+    // cache sets: 0 .. n_seq - 1 are the sequences' own K / V caches, n_seq .. n_seq + spares - 1 the spare ones that serve()
+    // fills ahead of the slots that will take them (ensure_spares); prefill / prefill_many take a cache set
+    TinyLlama& cset(int c) { return c < n_seq() ? *seqs_[(size_t)c] : *spares_[(size_t)(c - n_seq())]; }
+    int n_sets() const { return n_seq() + (int)spares_.size(); }
+    void ensure_spares(int count)
+    {
+        while ((int)spares_.size() < count) {
+            spares_.emplace_back(new TinyLlama(n_ctx_, dtype_, params_));
+            TinyLlama& m = *spares_.back();
+            for (int w = 0; w < seqs_[0]->n_weights(); w++) m.weight(w) = seqs_[0]->weight(w);
+        }
+    }
 
     // call after sequence 0's weights are loaded: every other sequence aliases them
     void share_weights()
@@ -438,6 +451,8 @@ public:
         for (size_t i = 1; i < seqs_.size(); i++)
             for (int w = 0; w < seqs_[0]->n_weights(); w++) seqs_[i]->weight(w) = seqs_[0]->weight(w);
         pre_.reset();                                        // (the shared prompt matrix aliases the weights too: rebuilt on next use)
+        spares_.clear();                                     // (... and so do the spare cache sets)
+        set_kv_.clear();
     }
     void load_synthetic(uint64_t seed)
     {
@@ -486,7 +501,7 @@ public:
             AttentionBlock& src = pre_->block(l);
             const size_t pitch = (size_t)src.attn.key.acv.bstride(0);
             for (int k = 0; k < K; k++) {
-                AttentionBlock& dst = seq(slots[(size_t)k]).block(l);
+                AttentionBlock& dst = cset(slots[(size_t)k]).block(l);
                 const size_t off = (size_t)starts[(size_t)k] * pitch, bytes = prompts[(size_t)k]->size() * pitch;
                 ranges.push_back({dst.attn.key.acv.device_ptr_mut(), (const uint8_t*)src.attn.key.acv.device_ptr() + off, bytes});
                 ranges.push_back({dst.attn.value.acv.device_ptr_mut(), (const uint8_t*)src.attn.value.acv.device_ptr() + off, bytes});
@@ -519,7 +534,7 @@ public:
             return first[0];
         }
         Tensor tk(prompt.data(), {(int)prompt.size()}, kInt32);
-        const Tensor lg = seq(seq_i).logits(tk, 0);                  // operator path on this sequence's own caches
+        const Tensor lg = cset(seq_i).logits(tk, 0);                 // operator path on this cache set's own model object
         const float* p = lg.data_ptr<float>();
         int best_i = 0;
         float best = -std::numeric_limits<float>::infinity();
@@ -608,11 +623,22 @@ public:
         const int S = n_seq();
         ServeStats st;
         out->assign(prompts.size(), {});
-        // per slot: prompt index (-1: free), next step, last step; ready: prompt processed, waiting to join
-        std::vector<int> job((size_t)S, -1), cur((size_t)S, 0), last((size_t)S, 0);
+        // per slot: prompt index (-1: free), next step, last step, the cache set it decodes on (-1: none)
+        std::vector<int> job((size_t)S, -1), cur((size_t)S, 0), last((size_t)S, 0), set_of((size_t)S, -1);
         std::vector<char> live((size_t)S, 0);
+        // CACHE SETS (round 4).  A prompt is processed onto a free cache set, not onto a free slot: besides the S sets the
+        // sequences own there are `spare` more, so that prompts are ready BEFORE the slots that will take them end -- a slot
+        // that ends in a harvest gets a ready prompt's set bound (gten_hip_decoder_slot_bind) and joins the very next slice
+        // instead of sitting one or two slices out while its replacement is processed.  pool: the free sets; ready: processed
+        // prompts waiting for a slot, in queue order.
+        struct Ready { int j, set, cur, last; };
+        std::deque<Ready> ready;
+        const int spare = serve_spares_ >= 0 ? serve_spares_ : (batched_prompts() ? std::min(S / 4, 64) : 0);
+        ensure_spares(spare);
+        std::vector<int> pool;
+        for (int c = n_sets() - 1; c >= 0; c--) pool.push_back(c);           // (taken from the back: the sequences' own sets first)
         size_t next = 0;
-        int n_live = 0, n_ready = 0;
+        int n_live = 0;
         slice = std::min(std::max(slice, 1), 64);                          // (gten_hip_decoder_slot_ids_all reads up to 64 steps at once)
         int lane_rows = S, n_lanes = 1;
         GTEN_HIP_OK(gten_hip_decoder_lane_info(dec_, &lane_rows, &n_lanes, nullptr));
@@ -630,9 +656,9 @@ public:
         };
         GTEN_HIP_OK(gten_hip_select_stream(0));
         for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
-        // the next prompt of the queue onto free slot q (stream 1); false when the queue is empty
-        auto prepare = [&](int q) {
-            while (next < prompts.size()) {
+        // the next prompt of the queue onto a free cache set (stream 1); false when the queue is empty
+        auto prepare = [&]() {
+            while (next < prompts.size() && !pool.empty()) {
                 const int j = (int)next++;
                 std::vector<int32_t>& row = (*out)[(size_t)j];
                 row = prompts[(size_t)j];
@@ -643,27 +669,27 @@ public:
                 const int limit = std::min(std::min(max_tokens, n_ctx_), mn > 0 ? P + mn : n_ctx_);   // ids in all
                 if (P >= limit) continue;                                  // no room to generate: returned as is
                 const auto t0 = clock::now();
-                const int best_i = prefill(q, row);                        // this slot's caches now hold rows [0, P) (waits for stream 1 only)
+                const int c = pool.back();
+                const int best_i = prefill(c, row);                        // this set's caches now hold rows [0, P) (waits for stream 1 only)
                 st.prefill_s += std::chrono::duration<double>(clock::now() - t0).count();
                 st.admissions++;
-                if (best_i == eos) continue;                               // ended at once: the slot takes the next prompt
+                if (best_i == eos) continue;                               // ended at once: the set takes the next prompt
                 row.push_back(best_i);
                 st.new_tokens++;
                 if ((int)row.size() >= limit) continue;
-                job[(size_t)q] = j; cur[(size_t)q] = (int)row.size(); last[(size_t)q] = limit - 1;
-                n_ready++;
+                pool.pop_back();
+                ready.push_back(Ready{j, c, (int)row.size(), limit - 1});
                 return true;
             }
-            return false;
+            return next < prompts.size();
         };
-        // Wide batches: the next prompts of the queue -- as many as there are free slots, kPreMax at most, kPreRows rows in
+        // Wide batches: the next prompts of the queue -- as many as there are free cache sets, kPreMax at most, kPreRows rows in
         // all, `cap` when the schedule is fixed -- as ONE row matrix (prefill_many) on stream 1.  Prompts under 16 ids (and
         // configurations the segmented call does not compute) go one by one through prepare().
         const bool batched = batched_prompts();
         auto prepare_many = [&](int cap) -> bool {
-            const std::vector<int> fq = free_slots();
-            if (fq.empty()) return next < prompts.size();
-            const size_t room = std::min<size_t>({fq.size(), (size_t)kPreMax, cap > 0 ? (size_t)cap : (size_t)kPreMax});
+            if (pool.empty()) return next < prompts.size();
+            const size_t room = std::min<size_t>({pool.size(), (size_t)kPreMax, cap > 0 ? (size_t)cap : (size_t)kPreMax});
             std::vector<int> js, limits;
             int rows = 0;
             while (next < prompts.size() && js.size() < room) {
@@ -684,45 +710,56 @@ public:
                 if (next >= prompts.size()) return false;
                 const int P = (int)prompts[next].size();
                 if (batched && P >= 16 && P <= kPreRows) return true;        // (only prompts without room were taken: look again)
-                return prepare(fq[0]);
+                return prepare();
             }
             const auto t0 = clock::now();
-            std::vector<int> slots(fq.begin(), fq.begin() + (long)js.size()), first;
+            std::vector<int> sets(pool.end() - (long)js.size(), pool.end()), first;
+            std::reverse(sets.begin(), sets.end());                          // (the order they would be popped in)
             std::vector<const std::vector<int32_t>*> ps;
             for (int j : js) ps.push_back(&prompts[(size_t)j]);
-            prefill_many(slots, ps, &first);
+            prefill_many(sets, ps, &first);
             st.prefill_s += std::chrono::duration<double>(clock::now() - t0).count();
+            std::vector<int> unused;
             for (size_t k = 0; k < js.size(); k++) {
                 std::vector<int32_t>& row = (*out)[(size_t)js[k]];
                 st.admissions++;
-                if (first[k] == eos) continue;                               // ended at once: the slot stays free
-                row.push_back(first[k]);
-                st.new_tokens++;
-                if ((int)row.size() >= limits[k]) continue;
-                const int q = slots[k];
-                job[(size_t)q] = js[k]; cur[(size_t)q] = (int)row.size(); last[(size_t)q] = limits[k] - 1;
-                n_ready++;
+                bool taken = false;
+                if (first[k] != eos) {                                       // (eos: ended at once, the set stays free)
+                    row.push_back(first[k]);
+                    st.new_tokens++;
+                    if ((int)row.size() < limits[k]) { ready.push_back(Ready{js[k], sets[k], (int)row.size(), limits[k] - 1}); taken = true; }
+                }
+                if (!taken) unused.push_back(sets[k]);
             }
+            pool.resize(pool.size() - js.size());
+            for (size_t k = unused.size(); k-- > 0;) pool.push_back(unused[k]);
             return true;
         };
         int cnt = 0;                                                       // steps of the slice in flight (0: none)
         auto t_slice = clock::now();
         std::vector<int> ap_seq, ap_first, ap_last;                        // gten_hip_decoder_slots_apply's arguments
         std::vector<const int32_t*> ap_tok;
-        // ready slots join, then the next slice starts (stream 0, asynchronous)
+        // ready prompts take the free slots, then the next slice starts (stream 0, asynchronous)
         auto launch_slice = [&]() {
-            // (the caches of the joining slots were filled on stream 1: the host has waited for that, and the explicit
-            //  stream-to-stream dependency makes the next launch on stream 0 acquire what another queue has written)
-            if (n_ready > 0) GTEN_HIP_OK(gten_hip_stream_wait(0, 1));
-            // (all joining slots in one call: their ids, step words and cache-table rows go up behind each other, one wait)
             ap_seq.clear(); ap_first.clear(); ap_last.clear(); ap_tok.clear();
-            for (int q = 0; q < S && n_ready > 0; q++)
-                if (job[(size_t)q] >= 0 && !live[(size_t)q]) {
-                    const std::vector<int32_t>& row = (*out)[(size_t)job[(size_t)q]];
-                    GTEN_ASSERTM((int)row.size() == cur[(size_t)q], "serve: slot %d holds %zu ids at step %d", q, row.size(), cur[(size_t)q]);
-                    ap_seq.push_back(q); ap_first.push_back(cur[(size_t)q]); ap_last.push_back(last[(size_t)q]); ap_tok.push_back(row.data());
-                    live[(size_t)q] = 1; n_live++; n_ready--;
+            if (!ready.empty()) {
+                const std::vector<int> fq = free_slots();
+                // (the caches of the joining slots were filled on stream 1: the host has waited for that, and the explicit
+                //  stream-to-stream dependency makes the next launch on stream 0 acquire what another queue has written)
+                if (!fq.empty()) GTEN_HIP_OK(gten_hip_stream_wait(0, 1));
+                for (size_t i = 0; i < fq.size() && !ready.empty(); i++) {
+                    const int q = fq[i];
+                    const Ready r = ready.front();
+                    ready.pop_front();
+                    const std::vector<int32_t>& row = (*out)[(size_t)r.j];
+                    GTEN_ASSERTM((int)row.size() == r.cur, "serve: prompt %d holds %zu ids at step %d", r.j, row.size(), r.cur);
+                    GTEN_HIP_OK(gten_hip_decoder_slot_bind(dec_, q, set_kv(r.set)));
+                    set_of[(size_t)q] = r.set; job[(size_t)q] = r.j; cur[(size_t)q] = r.cur; last[(size_t)q] = r.last;
+                    // (all joining slots in one call below: their ids, step words and cache-table rows go up behind each other, one wait)
+                    ap_seq.push_back(q); ap_first.push_back(r.cur); ap_last.push_back(r.last); ap_tok.push_back(row.data());
+                    live[(size_t)q] = 1; n_live++;
                 }
+            }
             if (!ap_seq.empty())
                 GTEN_HIP_OK(gten_hip_decoder_slots_apply(dec_, (int)ap_seq.size(), ap_seq.data(), ap_first.data(), ap_last.data(), ap_tok.data()));
             if (n_live == 0) return;
@@ -739,7 +776,7 @@ public:
             GTEN_HIP_OK(gten_hip_decoder_lane_info(dec_, nullptr, nullptr, &ran));
             st.lane_steps += (int64_t)cnt * ran;
         };
-        // the ids of the finished slice; slots that ended are parked (their caches are free for the next prompt)
+        // the ids of the finished slice; slots that ended are parked (their cache sets are free for the next prompts)
         std::vector<int> from((size_t)S, 0);
         std::vector<int32_t> all_ids((size_t)S * (size_t)std::max(slice, 1));
         auto harvest = [&]() {
@@ -760,16 +797,17 @@ public:
                 cur[(size_t)q] += got;
                 if (stop || cur[(size_t)q] > last[(size_t)q]) {
                     ap_seq.push_back(q); ap_first.push_back(0); ap_last.push_back(0);                  // parked, all of them at once below
-                    job[(size_t)q] = -1; live[(size_t)q] = 0; n_live--;
+                    pool.push_back(set_of[(size_t)q]);
+                    set_of[(size_t)q] = -1; job[(size_t)q] = -1; live[(size_t)q] = 0; n_live--;
                 }
             }
             if (!ap_seq.empty()) GTEN_HIP_OK(gten_hip_decoder_slots_apply(dec_, (int)ap_seq.size(), ap_seq.data(), ap_first.data(), ap_last.data(), nullptr));
             st.decode_s += std::chrono::duration<double>(clock::now() - t_slice).count();
             cnt = 0;
-            GTEN_HIP_OK(gten_hip_stream_wait(1, 0));            // (... and the other way round for the caches the parked slots leave)
+            GTEN_HIP_OK(gten_hip_stream_wait(1, 0));            // (... and the other way round for the cache sets the parked slots leave)
         };
-        // One host thread: prompts are processed back to back on stream 1; between two prompts the slice on stream 0 is
-        // polled, and when it has finished its ids are read and the next slice (with the slots that became ready) starts.
+        // One host thread: prompts are processed back to back on stream 1; between two prompt calls the slice on stream 0 is
+        // polled, and when it has finished its ids are read and the next slice (with the prompts that became ready) starts.
         bool queue_left = true;
         int prepared_this_slice = 0;
         for (;;) {
@@ -777,15 +815,10 @@ public:
                 int idle = 0;
                 if (serve_schedule_ > 0) idle = prepared_this_slice >= serve_schedule_;   // fixed schedule (tests): k prompts per slice
                 else GTEN_HIP_OK(gten_hip_stream_idle(0, &idle));
-                int free_q = -1;
-                if (!idle && queue_left) {
-                    const std::vector<int> fq = free_slots();
-                    if (!fq.empty()) free_q = fq[0];
-                }
-                if (free_q >= 0) {                                          // slice still running: more prompts beside it
+                if (!idle && queue_left && !pool.empty()) {                 // slice still running: more prompts beside it
                     GTEN_HIP_OK(gten_hip_select_stream(1));
                     const int before = (int)st.admissions;
-                    queue_left = batched ? prepare_many(serve_schedule_ > 0 ? serve_schedule_ - prepared_this_slice : 0) : prepare(free_q);
+                    queue_left = batched ? prepare_many(serve_schedule_ > 0 ? serve_schedule_ - prepared_this_slice : 0) : prepare();
                     GTEN_HIP_OK(gten_hip_select_stream(0));
                     prepared_this_slice += batched ? std::max(1, (int)st.admissions - before) : 1;
                     continue;
@@ -793,22 +826,24 @@ public:
                 harvest();                                                  // (waits when nothing is left to prepare)
                 prepared_this_slice = 0;
             }
-            if (n_live == 0 && n_ready == 0) {                              // nothing to decode: a prompt first
-                int free_q = -1;
-                if (queue_left) {
-                    const std::vector<int> fq = free_slots();
-                    if (!fq.empty()) free_q = fq[0];
-                }
-                if (free_q < 0) break;                                      // queue empty, nothing in flight
+            if (n_live == 0 && ready.empty()) {                             // nothing to decode: a prompt first
+                if (!queue_left || pool.empty()) break;                     // queue empty, nothing in flight
                 GTEN_HIP_OK(gten_hip_select_stream(1));
-                queue_left = batched ? prepare_many(serve_schedule_) : prepare(free_q);
+                queue_left = batched ? prepare_many(serve_schedule_) : prepare();
                 GTEN_HIP_OK(gten_hip_select_stream(0));
-                if (n_ready == 0) { if (!queue_left) break; continue; }
+                if (ready.empty()) { if (!queue_left) break; continue; }
             }
             launch_slice();
         }
+        // every slot back on its own sequence's caches (all of them are parked now): what follows a serve() -- decode_step,
+        // generate -- addresses slot q as sequence q
+        for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_bind(dec_, q, set_kv(q)));
         return st;
     }
+
+    // Cache sets beyond the sequences' own that serve() fills ahead (-1: a quarter of the slots, at most 64, for wide batches; 0:
+    // a prompt is only processed once a slot is free, the behaviour before round 4)
+    void set_serve_spares(int n) { serve_spares_ = n; }
 
     // Tests: k > 0 fixes the admission schedule -- exactly k prompts are processed beside every slice (as far as slots and
     // queue allow) instead of "as many as fit while the slice runs", so that a run is repeatable slice by slice.
@@ -816,6 +851,8 @@ public:
 
 private:
     std::vector<std::unique_ptr<TinyLlama>> seqs_;
+    std::vector<std::unique_ptr<TinyLlama>> spares_;   // spare cache sets of serve()
+    std::vector<std::vector<gten_hip_kv_ptrs>> set_kv_;      // per cache set: its layers' cache pointers (gten_hip_decoder_slot_bind)
     std::unique_ptr<TinyLlama> pre_;         // the shared row matrix of batched prompt processing (prefill_many), made on first use
     std::unique_ptr<Tensor> first_ids_;      // [kPreMax] int32 on the device: the prompts' first ids (gten_hip_argmax_row)
     gten_hip_decoder* dec_ = nullptr;
@@ -823,6 +860,20 @@ private:
     ModuleDtype dtype_;
     TinyLLamaParams params_;
     int serve_schedule_ = 0;
+    int serve_spares_ = -1;
+
+    const gten_hip_kv_ptrs* set_kv(int c)
+    {
+        if ((int)set_kv_.size() < n_sets()) set_kv_.resize((size_t)n_sets());
+        std::vector<gten_hip_kv_ptrs>& kv = set_kv_[(size_t)c];
+        if (kv.empty()) {
+            gten_hip_decoder_desc di;
+            std::vector<gten_hip_layer_ptrs> Li;
+            cset(c).describe(&di, &Li);
+            for (auto& p : Li) kv.push_back(gten_hip_kv_ptrs{p.kcache, p.vcache});
+        }
+        return kv.data();
+    }
 
     void ensure_decoder()
     {
