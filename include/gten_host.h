@@ -120,6 +120,9 @@ int  gten_host_batch_set_serve_schedule(gten_host_batch* b, int k);
  * which ends joins the next slice with a prompt that is already processed (gten_hip_decoder_slot_bind): -1 = a quarter of the
  * slots, at most 64, for batches of 16 sequences and more (the default), 0 = a prompt is processed only once a slot is free */
 int  gten_host_batch_set_serve_spares(gten_host_batch* b, int n);
+/* percent of the slots that get a processed prompt before a queue's FIRST slice starts (wide batches): 100 (default) fills
+ * every slot first -- fewer, fuller shared steps, the first ids later; 0 starts decoding with the first batch of prompts */
+int  gten_host_batch_set_serve_ramp(gten_host_batch* b, int percent);
 int  gten_host_batch_decode_begin(gten_host_batch* b, int seq, const int32_t* tokens, int count);
 int  gten_host_batch_decode_step(gten_host_batch* b, int n, int use_graph);                 /* asynchronous, all sequences */
 int  gten_host_batch_decode_steps(gten_host_batch* b, int n_first, int count, int use_graph);   /* asynchronous: count consecutive steps, four per graph replay */

@@ -233,17 +233,18 @@ def test_prompts_processed_ahead_onto_spare_cache_sets_give_the_same_ids(hip):
         for spares in (0, 3, 16, -1):
             for k, slice_steps in ((0, 8), (2, 5)):
                 b.set_serve_spares(spares)
+                b.set_serve_ramp(100 if spares in (0, 16) else 0)            # (... and the first slice with every slot filled, or not)
                 b.set_serve_schedule(k)
                 got, st = b.serve(prompts, total, -1, slice_steps, max_new_each=budgets)
                 runs.append(([g.tolist() for g in got], spares, k, st["steps"]))
     finally:
         b.set_serve_schedule(0)
         b.set_serve_spares(-1)
+        b.set_serve_ramp(100)
     for got, spares, k, _ in runs[1:]:
         assert got == runs[0][0], (spares, k)
     for j, g in enumerate(runs[0][0]):
         assert len(g) == min(total, len(prompts[j]) + int(budgets[j])), (j, len(g))
-    assert min(r[3] for r in runs if r[1] != 0) <= min(r[3] for r in runs if r[1] == 0)      # (ahead: never more shared steps)
     fixed_after = b.generate(prompts[:16], cap)
     assert [x.tolist() for x in fixed_after] == [x.tolist() for x in fixed_before]
     b.close()

@@ -330,6 +330,13 @@ int gten_host_batch_set_serve_spares(gten_host_batch* b, int n)
     return 0;
 }
 
+int gten_host_batch_set_serve_ramp(gten_host_batch* b, int percent)
+{
+    if (!b || percent < 0 || percent > 100) return -4;
+    b->batch->set_serve_ramp(percent);
+    return 0;
+}
+
 int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
                           int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats)
 {

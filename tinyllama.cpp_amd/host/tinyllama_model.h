@@ -830,6 +830,12 @@ public:
                 if (!queue_left || pool.empty()) break;                     // queue empty, nothing in flight
                 GTEN_HIP_OK(gten_hip_select_stream(1));
                 queue_left = batched ? prepare_many(serve_schedule_) : prepare();
+                // (with nothing live there is nothing to run beside: prompts are processed -- at the prompt kernels' full rate --
+                //  until serve_ramp_ percent of the slots have one, and only then does the first slice start: 669 instead of 709
+                //  shared steps on the bench's queue, its first 256 prompts 31.3 k instead of 28.6 k new ids/s; the price is the
+                //  first ids' latency, ~0.4 s at full size.  0: the first slice starts with the first batch of prompts)
+                while (serve_schedule_ == 0 && batched && queue_left && !pool.empty() && (int)ready.size() * 100 < S * serve_ramp_)
+                    queue_left = prepare_many(0);
                 GTEN_HIP_OK(gten_hip_select_stream(0));
                 if (ready.empty()) { if (!queue_left) break; continue; }
             }
@@ -844,6 +850,8 @@ public:
     // Cache sets beyond the sequences' own that serve() fills ahead (-1: a quarter of the slots, at most 64, for wide batches; 0:
     // a prompt is only processed once a slot is free, the behaviour before round 4)
     void set_serve_spares(int n) { serve_spares_ = n; }
+    // Percent of the slots that get a processed prompt before a queue's first slice starts (wide batches; default 100)
+    void set_serve_ramp(int percent) { serve_ramp_ = std::min(std::max(percent, 0), 100); }
 
     // Tests: k > 0 fixes the admission schedule -- exactly k prompts are processed beside every slice (as far as slots and
     // queue allow) instead of "as many as fit while the slice runs", so that a run is repeatable slice by slice.
@@ -861,6 +869,7 @@ private:
     TinyLLamaParams params_;
     int serve_schedule_ = 0;
     int serve_spares_ = -1;
+    int serve_ramp_ = 100;
 
     const gten_hip_kv_ptrs* set_kv(int c)
     {

@@ -39,7 +39,7 @@ class GtenHost:
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step", "gten_host_model_decode_steps", "gten_host_batch_decode_steps",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
-        "gten_host_batch_prefill", "gten_host_batch_prefill_many", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_set_serve_schedule", "gten_host_batch_set_serve_spares", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
+        "gten_host_batch_prefill", "gten_host_batch_prefill_many", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_set_serve_schedule", "gten_host_batch_set_serve_spares", "gten_host_batch_set_serve_ramp", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
         "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
     ]
 
@@ -86,6 +86,7 @@ class GtenHost:
         self._bserve = _sig(L, "gten_host_batch_serve", ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp])
         self._bsched = _sig(L, "gten_host_batch_set_serve_schedule", ci, [vp, ci])
         self._bspares = _sig(L, "gten_host_batch_set_serve_spares", ci, [vp, ci])
+        self._bramp = _sig(L, "gten_host_batch_set_serve_ramp", ci, [vp, ci])
         self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
         self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
         self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
@@ -338,6 +339,10 @@ class HostBatch:
     def set_serve_spares(self, n):
         """cache sets that serve() fills ahead of the slots that will take them (-1: default, 0: none)"""
         self._ck(self.host._bspares(self.h, int(n)), "set_serve_spares")
+
+    def set_serve_ramp(self, percent):
+        """percent of the slots that get a processed prompt before a queue's first slice starts (default 100)"""
+        self._ck(self.host._bramp(self.h, int(percent)), "set_serve_ramp")
 
     def serve(self, prompts, max_tokens, eos=-1, slice_steps=16, max_new=0, max_new_each=None):
         """continuous batching: the queue `prompts` (any number) through this batch's slots; returns (list of id
