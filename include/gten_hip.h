@@ -299,6 +299,9 @@ int gten_hip_decoder_slot_bind(gten_hip_decoder* dec, int seq, const gten_hip_kv
 int gten_hip_decoder_slots_apply(gten_hip_decoder* dec, int count, const int* seqs, const int* n_first, const int* n_last,
                                  const int32_t* const* tokens);
 int gten_hip_decoder_run(gten_hip_decoder* dec, int steps);
+/* the same run with the lanes whose slots are ALL parked left out when skip_empty_lanes != 0, whatever gten_hip_set_lane_skip
+ * says: the tail of a queue, once the caller has moved its last sequences into as few lanes as they fit (slot_bind) */
+int gten_hip_decoder_run_lanes(gten_hip_decoder* dec, int steps, int skip_empty_lanes);
 /* lanes (round 4): with set_lane_skip(1) a run leaves out every lane whose slots are all parked (its launch chain costs a full
  * lane's time however few slots are live); off by default -- it measured slower on the bench's serving queue, DESIGN.md 3.6 --
  * and the ids never depend on it (tests/test_serving_gpu.py).  lane_info: sequences per lane, lanes, how many the last run took. */

@@ -323,6 +323,8 @@ int gten_hip_decoder_slot_park(gten_hip_decoder* dc, int seq)
     dc->slots[(size_t)seq] = Slot{1, 0, 0};
     return 0;
 }
+int gten_hip_decoder_run(gten_hip_decoder* dc, int steps);
+int gten_hip_decoder_run_lanes(gten_hip_decoder* dc, int steps, int) { return gten_hip_decoder_run(dc, steps); }
 int gten_hip_decoder_slot_bind(gten_hip_decoder* dc, int seq, const gten_hip_kv_ptrs* kv)
 {
     if (!dc || !kv || seq < 0 || seq >= dc->n_seq) return fail("slot_bind: sequence %d", seq);

@@ -131,7 +131,9 @@ def test_lanes_without_a_live_slot_sit_the_run_out(hip):
     """round 4: a shared run leaves out every lane whose slots are all parked, and admission fills the lanes that already run
     first.  The ids must not depend on it: a queue through 256 slots (two lanes of 128 rows) -- short enough that the second
     lane is empty at the start and again in the tail -- with and without lane skipping, and through 16 slots; the skipping run
-    must have computed fewer lane-steps than steps x lanes."""
+    must have computed fewer lane-steps than steps x lanes.  In the tail of a queue serve() also MOVES the last sequences into as
+    few lanes as they fit (parked, their cache sets bound to free slots of the lanes that stay, started again): covered by the
+    same comparison, the 16-slot run never moves anything."""
     pkg = load_package()
     host = pkg.load_host()
     cfg = host_cfg(tiny_config(Q4, Q8, n_heads=4, n_kv_heads=2, max_ctx=320, n_layers=2))
@@ -154,7 +156,9 @@ def test_lanes_without_a_live_slot_sit_the_run_out(hip):
         hip.set_lane_skip(False)
     for j in range(330):
         assert outs[0][j].tolist() == outs[1][j].tolist() == outs[2][j].tolist(), j
-    assert stats[0]["lane_rows"] == 128 and stats[1]["lane_steps"] == 2 * stats[1]["steps"]
+    # (without the switch only the TAIL leaves lanes out -- the queue is empty, the last sequences have been moved into as few
+    #  lanes as they fit; with it every run does, also while the slots fill)
+    assert stats[0]["lane_rows"] == 128 and stats[0]["lane_steps"] <= stats[1]["lane_steps"] < 2 * stats[1]["steps"]
     assert stats[0]["lane_steps"] < 2 * stats[0]["steps"], stats[0]
     print("lane-steps with / without skipping:", stats[0]["lane_steps"], stats[1]["lane_steps"], "steps", stats[0]["steps"], stats[1]["steps"])
 

@@ -1657,7 +1657,7 @@ int gten_hip_decoder_slot_bind(gten_hip_decoder* dc, int seq, const gten_hip_kv_
     return 0;
 }
 
-int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
+static int run_impl(gten_hip_decoder* dc, int steps, bool skip_lanes)
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(dc && steps >= 0, "decoder_run: bad arguments");
@@ -1672,8 +1672,8 @@ int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
     const int SL = dc->n_seq / dc->lanes;
     for (int q = 0; q < dc->n_seq; q++)
         if (dc->slots[(size_t)q].advance & 1) mask |= 1u << (q / SL);
-    dc->lane_mask = (dc->lanes > 1 && g_lane_skip) ? mask : 0;
-    dc->last_run_lanes = (dc->lanes > 1 && g_lane_skip && mask) ? __builtin_popcount(mask) : dc->lanes;
+    dc->lane_mask = (dc->lanes > 1 && skip_lanes) ? mask : 0;
+    dc->last_run_lanes = (dc->lanes > 1 && skip_lanes && mask) ? __builtin_popcount(mask) : dc->lanes;
     const int rc_run = run_steps_free(dc, steps);
     dc->lane_mask = 0;
     if (rc_run) return rc_run;
@@ -1681,6 +1681,11 @@ int gten_hip_decoder_run(gten_hip_decoder* dc, int steps)
         if (s.advance & 1) s.n = s.stop > 0 ? std::min(s.n + steps, s.stop) : s.n + steps;   // (a slot that reaches max_ctx + 1 has to be parked or restarted before the next run)
     return 0;
 }
+
+int gten_hip_decoder_run(gten_hip_decoder* dc, int steps) { return run_impl(dc, steps, g_lane_skip); }
+/* ... with the lanes whose slots are all parked left out of THIS run whatever gten_hip_set_lane_skip says (the tail of a queue,
+ * whose last sequences the caller has moved into as few lanes as they fit: TinyLlamaBatch::serve) */
+int gten_hip_decoder_run_lanes(gten_hip_decoder* dc, int steps, int skip_empty_lanes) { return run_impl(dc, steps, skip_empty_lanes != 0 || g_lane_skip); }
 
 /* rows (sequences) per lane, the number of lanes, and how many of them the last gten_hip_decoder_run took */
 int gten_hip_decoder_lane_info(gten_hip_decoder* dc, int* lane_rows, int* lanes, int* last_run_lanes)

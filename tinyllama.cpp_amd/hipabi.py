@@ -92,7 +92,7 @@ class GtenHip:
         "gten_hip_decoder_step", "gten_hip_decoder_steps", "gten_hip_decoder_generate", "gten_hip_decoder_generate_multi", "gten_hip_decoder_step_ragged", "gten_hip_decoder_result", "gten_hip_decoder_time_family",
         "gten_hip_decoder_create_multi", "gten_hip_decoder_set_tokens_seq", "gten_hip_decoder_result_seq",
         "gten_hip_decoder_logits_seq",
-        "gten_hip_decoder_lane_info", "gten_hip_set_lane_skip", "gten_hip_decoder_slot_start", "gten_hip_decoder_slot_start_until", "gten_hip_decoder_slot_park", "gten_hip_decoder_slot_bind", "gten_hip_decoder_slots_apply", "gten_hip_decoder_run", "gten_hip_decoder_slot_ids", "gten_hip_decoder_slot_ids_all",
+        "gten_hip_decoder_lane_info", "gten_hip_set_lane_skip", "gten_hip_decoder_slot_start", "gten_hip_decoder_slot_start_until", "gten_hip_decoder_slot_park", "gten_hip_decoder_slot_bind", "gten_hip_decoder_slots_apply", "gten_hip_decoder_run", "gten_hip_decoder_run_lanes", "gten_hip_decoder_slot_ids", "gten_hip_decoder_slot_ids_all",
     ]
 
     def __init__(self, path=None):

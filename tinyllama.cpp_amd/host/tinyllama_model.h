@@ -613,7 +613,7 @@ public:
     // generating it alone (bit for bit up to 8 slots; tests/test_serving_gpu.py).
     // (lane_steps: shared steps x the lanes each of them ran -- a lane whose slots are all parked is left out of a run; lane_rows:
     //  slots per lane; new ids / (lane_steps x lane_rows) is the share of COMPUTED slot-steps that produced an id)
-    struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0, lane_steps = 0; int lane_rows = 0; double prefill_s = 0.0, decode_s = 0.0; };
+    struct ServeStats { int64_t prompt_tokens = 0, new_tokens = 0, steps = 0, admissions = 0, lane_steps = 0, moved = 0; int lane_rows = 0; double prefill_s = 0.0, decode_s = 0.0; };
     // (max_new_each, when given, bounds the new ids of prompt j by max_new_each[j] instead of max_new)
     ServeStats serve(const std::vector<std::vector<int32_t>>& prompts, int max_tokens, int eos, int slice,
                      std::vector<std::vector<int32_t>>* out, int max_new = 0, const int32_t* max_new_each = nullptr)
@@ -736,11 +736,37 @@ public:
             return true;
         };
         int cnt = 0;                                                       // steps of the slice in flight (0: none)
+        bool queue_left = true;
+        bool tail = false;                                                 // the queue is empty: the last sequences are kept in as few lanes as they fit
         auto t_slice = clock::now();
         std::vector<int> ap_seq, ap_first, ap_last;                        // gten_hip_decoder_slots_apply's arguments
         std::vector<const int32_t*> ap_tok;
         // ready prompts take the free slots, then the next slice starts (stream 0, asynchronous)
         auto launch_slice = [&]() {
+            // THE TAIL.  Once the queue is empty and nothing waits, the live sequences thin out in every lane alike, and a lane
+            // costs a full lane's launches however few of its slots are live.  Whenever they would fit into fewer lanes than they
+            // occupy, the sequences of the emptiest lane move: parked here, handed over as ready prompts (their cache sets go
+            // with them), started again in the free slots of the lanes that stay -- and the runs of the tail leave empty lanes
+            // out (gten_hip_decoder_run_lanes).  Same rows, same ids: a sequence does not know its slot.
+            if (n_lanes > 1 && serve_schedule_ == 0 && !queue_left && ready.empty() && n_live > 0) {
+                std::vector<int> per((size_t)n_lanes, 0);
+                for (int q = 0; q < S; q++) per[(size_t)(q / lane_rows)] += live[(size_t)q] ? 1 : 0;
+                int occupied = 0, emptiest = -1;
+                for (int g = 0; g < n_lanes; g++)
+                    if (per[(size_t)g] > 0) { occupied++; if (emptiest < 0 || per[(size_t)g] < per[(size_t)emptiest]) emptiest = g; }
+                if (occupied > (n_live + lane_rows - 1) / lane_rows) {
+                    ap_seq.clear(); ap_first.clear(); ap_last.clear();
+                    for (int q = emptiest * lane_rows; q < (emptiest + 1) * lane_rows; q++) {
+                        if (!live[(size_t)q]) continue;
+                        ready.push_back(Ready{job[(size_t)q], set_of[(size_t)q], cur[(size_t)q], last[(size_t)q]});
+                        ap_seq.push_back(q); ap_first.push_back(0); ap_last.push_back(0);
+                        set_of[(size_t)q] = -1; job[(size_t)q] = -1; live[(size_t)q] = 0; n_live--;
+                    }
+                    GTEN_HIP_OK(gten_hip_decoder_slots_apply(dec_, (int)ap_seq.size(), ap_seq.data(), ap_first.data(), ap_last.data(), nullptr));
+                    st.moved += (int64_t)ap_seq.size();
+                }
+                tail = true;
+            }
             ap_seq.clear(); ap_first.clear(); ap_last.clear(); ap_tok.clear();
             if (!ready.empty()) {
                 const std::vector<int> fq = free_slots();
@@ -770,7 +796,7 @@ public:
                 if (live[(size_t)q]) longest = std::max(longest, last[(size_t)q] - cur[(size_t)q] + 1);
             cnt = std::min(std::max(slice, 1), longest);
             t_slice = clock::now();
-            GTEN_HIP_OK(gten_hip_decoder_run(dec_, cnt));
+            GTEN_HIP_OK(gten_hip_decoder_run_lanes(dec_, cnt, tail ? 1 : 0));
             st.steps += cnt;
             int ran = n_lanes;
             GTEN_HIP_OK(gten_hip_decoder_lane_info(dec_, nullptr, nullptr, &ran));
@@ -808,7 +834,6 @@ public:
         };
         // One host thread: prompts are processed back to back on stream 1; between two prompt calls the slice on stream 0 is
         // polled, and when it has finished its ids are read and the next slice (with the prompts that became ready) starts.
-        bool queue_left = true;
         int prepared_this_slice = 0;
         for (;;) {
             if (cnt > 0) {
