@@ -241,14 +241,15 @@ __device__ __forceinline__ unsigned mmvh_scale(unsigned biased_pair, float bias,
 template <int WT, int RT, int FT, bool SILU>
 // (round 4: the one-tile launches at 64 / 128 rows -- q|k|v, o, down -- keep to 128 registers, two workgroups per CU: half the
 //  activation fragments in flight per wave, but a second workgroup's requests fly while the first computes -- 180 / 162
-//  registers and one workgroup per CU before: 64 sequences 37.3 k -> 38.4 k tok/s, 256 sequences 71.0 k -> 73.8 k)
-__global__ __launch_bounds__(512, (FT == 1 && RT >= 4) ? 4 : 2) void k_dec_mmvh(const uint16_t* __restrict__ a_ah, const void* __restrict__ a_w0, float* __restrict__ a_out,
+//  registers and one workgroup per CU before: 64 sequences 37.3 k -> 38.4 k tok/s, 256 sequences 71.0 k -> 73.8 k; the two-tile
+//  launch (lm_head) at 64 rows likewise: 38.4 -> 38.7 k; at 128 rows it would spill 34 registers)
+__global__ __launch_bounds__(512, ((FT == 1 && RT >= 4) || (FT == 2 && RT == 4 && !SILU)) ? 4 : 2) void k_dec_mmvh(const uint16_t* __restrict__ a_ah, const void* __restrict__ a_w0, float* __restrict__ a_out,
                                                   const int a_d_in, const int a_d_out0, const int a_out_cols, const int a_S, const int a_n_mats,
                                                   const MmvRest rest)
 {
     // (more than four row tiles: activation fragments two blocks ahead instead of four -- registers; the one-tile launches from
     //  four row tiles up: one or two blocks ahead, see the launch bounds)
-    constexpr int SP = 16 * RT, FR = 16 * FT, CB = (FT == 1 && RT >= 4) ? ((RT > 4) ? 1 : 2) : ((RT > 4) ? ((FT > 2) ? 1 : 2) : 4);
+    constexpr int SP = 16 * RT, FR = 16 * FT, CB = (FT == 1 && RT >= 4) ? ((RT > 4) ? 1 : 2) : (FT == 2 && RT == 4 && !SILU) ? 2 : ((RT > 4) ? ((FT > 2) ? 1 : 2) : 4);
     constexpr int NPF = MMV_MAXP / FT;
     const int nb = a_d_in >> 5;
     const int nbs = nb / (int)gridDim.y, b_lo = (int)blockIdx.y * nbs;
