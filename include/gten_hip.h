@@ -128,6 +128,18 @@ int gten_hip_set_prefill_exact(int on);
  * of the probabilities, fp16 operand rounding in the wide W.x and p.V).  Up to 8 sequences and contexts <= 256 both forms
  * are the same bytes. */
 int gten_hip_set_decode_exact(int on);
+/* Decoders of 16+ sequences created AFTERWARDS (Q8 activations, fast forms) keep HEAD-MAJOR SHADOWS of their sequences' K / V
+ * caches (on != 0, the default; round 5, csrc/gten_decode_attn_hm.h) or read the cache rows as they lie (0: round 4's kernel).
+ * The caches themselves keep the reference's row layout [max_ctx][kv_dim] (gten/modules.cpp:188-201) for every reader and
+ * writer; a shadow holds the same bytes per (kv head, 256 positions) as ONE contiguous run in matrix-operand order, is filled
+ * from the rows when a sequence (re)starts, follows the decode appends, and is re-imported before the next step whenever ANY
+ * call of this library has written into one of the rows since (every writer announces its output range: a stale shadow is
+ * not possible through this interface; a caller that writes cache rows with its own kernels restarts the sequence --
+ * slot_start / step at another position / generate_multi -- to the same effect). */
+int gten_hip_set_kv_head_major(int on);
+/* host-only self-test of the registry behind that guarantee (which ranges are watched, which writes hit them, whose flag is
+ * set): needs no GPU and no gten_hip_init; returns 0 or the number of the first failing case */
+int gten_hip_kv_watch_selftest(void);
 /* single-sequence q4 decoders created AFTER this call run the step as ONE persistent launch (1) or as the chain of 113
  * launches (0, the default: it is the faster one on MI355X): the same bytes either way
  * (tests/test_persist_gpu.py); csrc/gten_decode_persist.h */
@@ -318,6 +330,9 @@ int gten_hip_decoder_step_ragged(gten_hip_decoder* dec, const int* n_per_seq, in
  * `reps` replays of a graph holding only that family's launches at context length n, bracketed by
  * two events on the library's stream; *avg_us = elapsed / (reps * launches per replay). */
 int gten_hip_decoder_time_family(gten_hip_decoder* dec, int family, int n, int reps, double* avg_us, int* launches_per_replay);
+/* head-major shadows of this decoder: *head_major = whether it keeps them; sequence imports (rows -> shadow) launched so far and
+ * the launches they took (tests watch a write into a cache row being followed by a re-import) */
+int gten_hip_decoder_kv_info(gten_hip_decoder* dec, int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches);
 /* waits for the stream and returns the argmax produced by step n */
 int gten_hip_decoder_result(gten_hip_decoder* dec, int n, int32_t* argmax_host);
 int gten_hip_decoder_result_seq(gten_hip_decoder* dec, int seq, int n, int32_t* argmax_host);

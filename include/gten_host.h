@@ -130,6 +130,11 @@ int  gten_host_batch_decode_step_ragged(gten_host_batch* b, const int32_t* n_per
 int  gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out); /* waits */
 int  gten_host_batch_logits(gten_host_batch* b, int seq, float* logits_out);                /* waits; f32[n_vocab] */
 int  gten_host_batch_time_family(gten_host_batch* b, int family, int n, int reps, double* avg_us, int* launches);
+/* steps n_first .. n_first + steps - 1 of ONE sequence on its own single-sequence decoder (the caches are the ones the shared
+ * decoder uses: whatever it appends there, the shared decoder must see -- tests/test_kv_head_major_gpu.py); asynchronous */
+int  gten_host_batch_seq_steps(gten_host_batch* b, int seq, const int32_t* tokens, int count, int n_first, int steps);
+/* the shared decoder's head-major K / V shadows (gten_hip_decoder_kv_info): kept at all, sequence imports so far, their launches */
+int  gten_host_batch_kv_info(gten_host_batch* b, int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches);
 
 /* HIP-event timing of one kernel family of the decode step (see gten_hip_decoder_time_family) */
 int gten_host_model_time_family(gten_host_model* m, int family, int n, int reps, double* avg_us, int* launches);

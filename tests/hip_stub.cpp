@@ -346,6 +346,17 @@ int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seq
     }
     return 0;
 }
+int gten_hip_set_kv_head_major(int) { return 0; }
+int gten_hip_kv_watch_selftest(void) { return 0; }
+int gten_hip_decoder_kv_info(gten_hip_decoder* dc, int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches)
+{
+    if (!dc) return fail("decoder_kv_info: arguments");
+    // (the stand-in reads the cache rows of its fixed next-id rule directly: no shadows)
+    if (head_major) *head_major = 0;
+    if (seq_imports) *seq_imports = 0;
+    if (import_launches) *import_launches = 0;
+    return 0;
+}
 int gten_hip_decoder_lane_info(gten_hip_decoder* dc, int* lane_rows, int* lanes, int* last_run_lanes)
 {
     if (!dc) return fail("decoder_lane_info: arguments");

@@ -48,3 +48,12 @@ def test_no_silent_cpu_fallback():
         api.init(0)
     with pytest.raises(pkg.GtenHipError):
         api.alloc(64)
+
+
+def test_watched_cache_registry_selftest():
+    """the registry behind "a head-major K / V shadow cannot be stale" (csrc/gten_rt.h kv_watch_*, include/gten_hip.h
+    gten_hip_set_kv_head_major): which writes hit which watched rows, whose flag they set, what slot_bind's re-registration
+    leaves -- host-only logic, exercised without a GPU"""
+    pkg = load_package()
+    api = pkg.hipabi.GtenHip()
+    assert api.kv_watch_selftest() == 0

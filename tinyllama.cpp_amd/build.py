@@ -44,6 +44,12 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", 
 CXX_FLAGS = ["-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I" + INCLUDE, "-I" + PKG]
 
 
+# A/B builds on the GPU box: extra hipcc flags (e.g. "-DHM_OCC=") from the environment; a change of the flags rebuilds everything
+_EXTRA = os.environ.get("GTEN_HIP_EXTRA_FLAGS", "").split()
+HIP_FLAGS += _EXTRA
+_FLAGS_STAMP = os.path.join(CSRC, "_obj", "flags.txt")
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return True
@@ -70,6 +76,11 @@ def build_hip(force=False):
     hdrs = _sources(CSRC, (".h",)) + _sources(INCLUDE, (".h",)) + [os.path.abspath(__file__)]
     os.makedirs(HIP_OBJ, exist_ok=True)
     compile_flags = [f for f in HIP_FLAGS if f != "-shared"]
+    stamp = " ".join(_EXTRA)
+    if (open(_FLAGS_STAMP).read() if os.path.exists(_FLAGS_STAMP) else "") != stamp:
+        force = True
+        with open(_FLAGS_STAMP, "w") as f:
+            f.write(stamp)
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(HIP_OBJ, os.path.basename(src) + ".o")

@@ -88,6 +88,7 @@ enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2, EPI_STAGE_FRAG = 3 };
 #include "gten_decode_attn.h"
 #include "gten_decode_attn_exact64.h"
 #include "gten_decode_attn_wide.h"
+#include "gten_decode_attn_hm.h"
 
 // --------------------------------------------------------------- host side
 
@@ -147,6 +148,17 @@ struct gten_hip_decoder {
     bool exact = false;               // gten_hip_set_decode_exact at creation
     bool persist_on = false;          // gten_hip_set_decode_persistent at creation: the step as ONE persistent launch (gten_decode_persist.h)
     struct PersistState* persist = nullptr;
+    // ---- head-major shadows of the K / V caches (gten_decode_attn_hm.h): decoders of 16+ sequences, Q8 activations, fast forms.
+    // [sequence][layer][K | V][kv head][chunk][HM_CHUNK_BYTES]; hm_dirty[q] != 0: sequence q's shadow must be re-imported from
+    // its cache rows before the next step (set at creation, by every (re)start of the sequence, and -- through the watch
+    // registry of gten_rt.h -- by every write of this library into one of its cache rows)
+    uint8_t* hm = nullptr;
+    size_t hm_seq_stride = 0, hm_cache_bytes = 0;
+    std::vector<char> hm_dirty;
+    unsigned long long hm_imports = 0, hm_import_launches = 0;
+    // every decoder: do the caches it appends to overlap a watch of ANOTHER decoder (cached per registry epoch)
+    unsigned long long watch_epoch = 0;
+    bool watch_foreign = false;
     int lanes = 1;
     hipStream_t lane_stream[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};    // capture / eager side streams of lanes 1..
     hipEvent_t lane_fork = nullptr, lane_join[DEC_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -193,6 +205,15 @@ static bool g_exact_now = false;
 // off by default: on the bench's serving queue (1024 prompts through two lanes of 128 slots) only 3 % of the lane-steps have an
 // empty lane, and the extra graphs cost more than that returns: 33.5 k against 37.0 k new ids/s, A/B on one box
 static bool g_lane_skip = false;         // gten_hip_decoder_run leaves lanes without a live slot out of the step (gten_hip_set_lane_skip)
+// decoders of 16+ sequences created AFTERWARDS keep head-major shadows of their K / V caches (gten_decode_attn_hm.h) or read
+// the cache rows as they lie (0: k_dec_attn_mm_g, round 4's kernel -- kept for the A/B and as the reference the tests hold
+// the new kernel to)
+static bool g_kv_head_major = true;
+extern "C" int gten_hip_set_kv_head_major(int on)
+{
+    g_kv_head_major = on != 0;
+    return 0;
+}
 extern "C" int gten_hip_set_decode_exact(int on)
 {
     g_decode_exact = on != 0;
@@ -243,6 +264,11 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
 {
     constexpr size_t NW = (ADT == GTEN_Q8) ? 17 : 32;
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
+    if constexpr (ADT == GTEN_Q8) if (grouped_mm(t, n_seq) && t.hm_k) {
+        // head-major shadows: one wave per (sequence, kv head, chunk)
+        DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_hm<GRP>), dim3(n_seq * t.n_chunks * t.n_kv), dim3(64), 1024, t, n_seq);
+        return 0;
+    }
     if constexpr (ADT == GTEN_Q8) if (grouped_mm(t, n_seq)) {
         const size_t smem = (size_t)DEC_CHUNK * 68 + 2 * 8 * 264 * 2 + 16 * 64 + 32 * 4 + 8 * 4 + (size_t)4 * (DEC_MAXGRP + 2) * 2 + 128 + 128 * 4 + 80 + 64;
         GTR_REQUIRE((n_seq * t.n_chunks) % 8 == 0, "decoder: %d sequences x %d chunks is not a multiple of 8", n_seq, t.n_chunks);
@@ -902,6 +928,10 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         t.qkv_stride = QW; t.scores_stride = d.n_heads * d.max_ctx; t.stats_stride = d.n_heads * dc->n_chunks * 2;
         t.part_stride = d.n_heads * dc->n_chunks * dh;
         t.qkv_plane = ks_qkv > 1 ? S * QW : 0;
+        if (dc->hm) {
+            t.hm_k = dc->hm + (size_t)lane * S * dc->hm_seq_stride + (size_t)l * 2 * dc->hm_cache_bytes;
+            t.hm_seq_stride = dc->hm_seq_stride; t.hm_cache_bytes = dc->hm_cache_bytes;
+        }
         const dim3 agrid(d.n_heads, dc->n_chunks, S);
         const size_t smem1 = (size_t)(16 + 3 * dh + 16) * 4 + 32 + (size_t)3 * dh + 64;
         if (!grouped_known) { grouped = attention_grouped_ok(t, S); grouped_known = true; }
@@ -1160,6 +1190,17 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
         const size_t cache_bytes = (size_t)d.max_ctx * gten_hip_row_bytes(d.adtype, KV);
         GTR_CHECK(hipMalloc(&dc->dummy_kv, 2 * cache_bytes));
         GTR_CHECK(hipMemset(dc->dummy_kv, 0, 2 * cache_bytes));
+        const int grp = d.n_heads / d.n_kv_heads;
+        if (wide && g_kv_head_major && !dc->exact && d.adtype == GTEN_Q8 && dh == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1)) {
+            dc->hm_cache_bytes = (size_t)d.n_kv_heads * dc->n_chunks * HM_CHUNK_BYTES;
+            dc->hm_seq_stride = (size_t)d.n_layers * 2 * dc->hm_cache_bytes;
+            GTR_CHECK(hipMalloc((void**)&dc->hm, S * dc->hm_seq_stride));
+            GTR_CHECK(hipMemset(dc->hm, 0, S * dc->hm_seq_stride));
+            dc->hm_dirty.assign(S, 1);
+            for (size_t q = 0; q < S; q++)
+                for (size_t i = 0; i < (size_t)d.n_layers * 2; i++)
+                    kv_watch_add(dc->kv_real[q * d.n_layers * 2 + i], cache_bytes, dc, &dc->hm_dirty[q]);
+        }
     }
     if (int rc = rope_table(dh, &dc->rope)) return rc;
     GTR_CHECK(hipMalloc((void**)&dc->rope_now, S * (size_t)(dh / 2) * sizeof(float2)));
@@ -1270,7 +1311,8 @@ int gten_hip_decoder_destroy(gten_hip_decoder* dc)
         if (dc->exec_km[m]) rel(hipGraphExecDestroy(dc->exec_km[m]));
         if (dc->graph_km[m]) rel(hipGraphDestroy(dc->graph_km[m]));
     }
-    void* bufs[] = {dc->ids_stage, dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
+    kv_watch_remove(dc, nullptr);
+    void* bufs[] = {dc->hm, dc->ids_stage, dc->step, dc->tokens, dc->result, dc->qkv_raw, dc->proj_raw, dc->down_raw,
                     dc->scores, dc->stats, dc->att_part, dc->xbuf, dc->hbuf, dc->best_val, dc->best_idx,
                     dc->act_q, dc->act_d, dc->act_sum, dc->act_f, dc->stg_q, dc->stg_d, dc->stg_sum, dc->stg_f,
                     dc->logits_m, (void*)dc->kv_tab, dc->gu_raw, dc->rope_now, dc->dummy_kv};
@@ -1313,6 +1355,60 @@ int gten_hip_decoder_set_tokens_seq(gten_hip_decoder* dc, int seq, const int32_t
 #define DEC_GRAPH_STEPS 4
 static int slots_leave(gten_hip_decoder* dc);     // continuous batching (below): back to every sequence's own caches
 static int run_step(gten_hip_decoder* dc, int use_graph);
+// ---- what has to happen before a decoder's steps are launched (never inside a stream capture):
+//   1. the cache rows this decoder is about to append to may be shadowed by ANOTHER decoder (a batch's wide decoder over the
+//      same sequences): tell the registry, that decoder re-imports them;
+//   2. this decoder's own head-major shadows: sequences whose rows were written since the last import (or that were
+//      (re)started) are imported now, rows [0, n - 1) with n read from the sequence's step word on the device -- on the
+//      stream the steps follow on, so whatever ordered the rows' writers ahead of the steps orders them ahead of this.
+static void hm_mark_all(gten_hip_decoder* dc)
+{
+    std::fill(dc->hm_dirty.begin(), dc->hm_dirty.end(), (char)1);
+}
+static int pre_run(gten_hip_decoder* dc)
+{
+    const gten_hip_decoder_desc& d = dc->d;
+    if (kv_watch_any()) {
+        const size_t cache_bytes = (size_t)d.max_ctx * gten_hip_row_bytes(d.adtype, (d.n_embd / d.n_heads) * d.n_kv_heads);
+        if (dc->watch_epoch != kv_watch_epoch()) {
+            dc->watch_epoch = kv_watch_epoch();
+            dc->watch_foreign = false;
+            if (dc->n_seq == 1) {
+                for (const gten_hip_layer_ptrs& L : dc->layers)
+                    if (kv_watch_overlaps(L.kcache, cache_bytes, dc) || kv_watch_overlaps(L.vcache, cache_bytes, dc)) { dc->watch_foreign = true; break; }
+            } else {
+                for (const void* c : dc->kv_real)
+                    if (kv_watch_overlaps(c, cache_bytes, dc)) { dc->watch_foreign = true; break; }
+            }
+        }
+        if (dc->watch_foreign) {
+            if (dc->n_seq == 1) for (const gten_hip_layer_ptrs& L : dc->layers) { kv_watch_touch(L.kcache, cache_bytes, dc); kv_watch_touch(L.vcache, cache_bytes, dc); }
+            else for (const void* c : dc->kv_real) kv_watch_touch(c, cache_bytes, dc);
+        }
+    }
+    if (!dc->hm) return 0;
+    HmImportList items{};
+    const size_t kv_pitch = gten_hip_row_bytes(d.adtype, (d.n_embd / d.n_heads) * d.n_kv_heads);
+    auto flush = [&]() -> int {
+        if (items.n == 0) return 0;
+        GTR_LAUNCH(KT_PACK, k_kv_import_hm, dim3(d.n_kv_heads * dc->n_chunks, d.n_layers * 2, items.n), dim3(256), (size_t)DEC_CHUNK * 68, items,
+                   (const DecStep*)dc->step, (const void* const*)dc->kv_tab, dc->hm, dc->hm_seq_stride, dc->hm_cache_bytes, d.n_layers, d.n_kv_heads, dc->n_chunks,
+                   d.max_ctx, kv_pitch);
+        dc->hm_import_launches++;
+        dc->hm_imports += (unsigned long long)items.n;
+        items.n = 0;
+        return 0;
+    };
+    for (int q = 0; q < dc->n_seq; q++) {
+        if (!dc->hm_dirty[(size_t)q]) continue;
+        dc->hm_dirty[(size_t)q] = 0;
+        items.seq[items.n++] = q;
+        if (items.n == (int)(sizeof(items.seq) / sizeof(items.seq[0])))
+            if (int rc = flush()) return rc;
+    }
+    return flush();
+}
+
 // (the graphs of the lane subset dc->lane_mask selects: slot 0 = every lane)
 static unsigned graph_slot(const gten_hip_decoder* dc)
 {
@@ -1321,6 +1417,7 @@ static unsigned graph_slot(const gten_hip_decoder* dc)
 }
 static int run_steps_free(gten_hip_decoder* dc, int count)
 {
+    if (int rc = pre_run(dc)) return rc;
     if (prof_on()) { for (int i = 0; i < count; i++) if (int rc = run_step(dc, 0)) return rc; return 0; }
     const unsigned gs = graph_slot(dc);
     hipGraph_t& graph_k = gs ? dc->graph_km[gs] : dc->graph_k;
@@ -1346,6 +1443,7 @@ static int run_steps_free(gten_hip_decoder* dc, int count)
 
 static int run_step(gten_hip_decoder* dc, int use_graph)
 {
+    if (int rc = pre_run(dc)) return rc;
     if (!use_graph || prof_on()) return enqueue(dc);    // event pairs cannot be recorded into a capture
     const unsigned gs = graph_slot(dc);
     hipGraph_t& graph = gs ? dc->graph_m[gs] : dc->graph;
@@ -1372,6 +1470,7 @@ int gten_hip_decoder_step(gten_hip_decoder* dc, int n, int use_graph)
     // so consecutive steps need no host-side update at all.  (All sequences of a
     // multi-sequence decoder are at the same position.)
     if (dc->dev_n != n || !dc->dev_ns.empty()) {
+        hm_mark_all(dc);                              // not the continuation of this decoder's own steps: the rows are the caller's
         std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n, 1});
         GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
         GTR_CHECK(hipStreamSynchronize(stream()));    // `st` lives on this stack frame
@@ -1391,6 +1490,7 @@ int gten_hip_decoder_steps(gten_hip_decoder* dc, int n_first, int count, int use
                 n_first, n_first + count, dc ? dc->d.max_ctx : 0);
     if (count == 0) return 0;
     if (dc->dev_n != n_first || !dc->dev_ns.empty()) {
+        hm_mark_all(dc);
         std::vector<DecStep> st((size_t)dc->n_seq, DecStep{n_first, 1});
         GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
         GTR_CHECK(hipStreamSynchronize(stream()));
@@ -1414,6 +1514,7 @@ int gten_hip_decoder_step_ragged(gten_hip_decoder* dc, const int* n_per_seq, int
     bool same = (int)dc->dev_ns.size() == dc->n_seq;
     for (int q = 0; same && q < dc->n_seq; q++) same = dc->dev_ns[q] == n_per_seq[q];
     if (!same) {
+        hm_mark_all(dc);
         std::vector<DecStep> st((size_t)dc->n_seq);
         for (int q = 0; q < dc->n_seq; q++) st[q] = DecStep{n_per_seq[q], 1};
         GTR_CHECK(hipMemcpyAsync(dc->step, st.data(), st.size() * sizeof(DecStep), hipMemcpyHostToDevice, stream()));
@@ -1489,6 +1590,7 @@ int gten_hip_decoder_generate_multi(gten_hip_decoder* dc, const int* n_first, co
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     dc->dev_ns.clear();
+    hm_mark_all(dc);
     if (int rc_ = slots_leave(dc)) return rc_;
     std::vector<int32_t> ids((size_t)GEN_SLICE);
     while (n_live > 0) {
@@ -1544,6 +1646,7 @@ static int slots_view(gten_hip_decoder* dc)
         GTR_CHECK(hipStreamSynchronize(stream()));
         for (int q = 0; q < dc->n_seq; q++)
             if (int rc = slot_caches(dc, q, true)) return rc;
+        hm_mark_all(dc);
     }
     dc->dev_n = -1;
     dc->dev_ns.clear();
@@ -1555,6 +1658,7 @@ static int slots_leave(gten_hip_decoder* dc)
 {
     for (int q = 0; q < dc->n_seq && !dc->kv_parked.empty(); q++)
         if (int rc = slot_caches(dc, q, false)) return rc;
+    if (!dc->slots.empty()) hm_mark_all(dc);           // (leaving the slot view: positions and cache bindings are the caller's again)
     dc->slots.clear();
     return 0;
 }
@@ -1573,6 +1677,7 @@ int gten_hip_decoder_slot_start_until(gten_hip_decoder* dc, int seq, int n_first
     if (int rc = slots_view(dc)) return rc;
     if (int rc = slot_caches(dc, seq, false)) return rc;
     dc->slots[(size_t)seq] = DecStep{n_first, 3, n_last};
+    if (dc->hm) dc->hm_dirty[(size_t)seq] = 1;         // a (re)started sequence: its rows [0, n_first - 1) are the caller's
     GTR_CHECK(hipMemcpyAsync(dc->step + seq, &dc->slots[(size_t)seq], sizeof(DecStep), hipMemcpyHostToDevice, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
     return 0;
@@ -1607,6 +1712,7 @@ int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seq
         const int q = seqs[i];
         const bool park = n_first[i] == 0;
         dc->slots[(size_t)q] = park ? DecStep{1, 0, 0} : DecStep{n_first[i], 3, n_last[i]};
+        if (dc->hm && !park) dc->hm_dirty[(size_t)q] = 1;
         if (!dc->kv_parked.empty() && (bool)dc->kv_parked[(size_t)q] != park) {
             const void** row = rows.data() + (size_t)i * L * 2;            // (alive until the wait below)
             for (size_t l = 0; l < L; l++) {
@@ -1649,10 +1755,19 @@ int gten_hip_decoder_slot_bind(gten_hip_decoder* dc, int seq, const gten_hip_kv_
     GTR_REQUIRE(dc && kv && seq >= 0 && seq < dc->n_seq, "decoder_slot_bind: sequence %d outside [0, %d)", seq, dc ? dc->n_seq : 0);
     GTR_REQUIRE(!dc->kv_parked.empty() && dc->kv_parked[(size_t)seq], "decoder_slot_bind: slot %d is not parked", seq);
     const size_t off = (size_t)seq * dc->d.n_layers * 2;
-    for (int l = 0; l < dc->d.n_layers; l++) {
+    for (int l = 0; l < dc->d.n_layers; l++)
         GTR_REQUIRE(kv[l].kcache && kv[l].vcache, "decoder_slot_bind: null cache pointer (layer %d)", l);
+    for (int l = 0; l < dc->d.n_layers; l++) {
         dc->kv_real[off + 2 * (size_t)l] = kv[l].kcache;
         dc->kv_real[off + 2 * (size_t)l + 1] = kv[l].vcache;
+    }
+    if (dc->hm) {
+        // the slot's shadow follows the set it is bound to: watch the new rows instead of the old ones
+        const size_t cache_bytes = (size_t)dc->d.max_ctx * gten_hip_row_bytes(dc->d.adtype, (dc->d.n_embd / dc->d.n_heads) * dc->d.n_kv_heads);
+        char* flag = &dc->hm_dirty[(size_t)seq];
+        kv_watch_remove(dc, flag);
+        for (size_t i = 0; i < (size_t)dc->d.n_layers * 2; i++) kv_watch_add(dc->kv_real[off + i], cache_bytes, dc, flag);
+        *flag = 1;
     }
     return 0;
 }
@@ -1754,6 +1869,8 @@ int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int re
     GTR_CHECK(hipStreamSynchronize(stream()));
     dc->dev_n = -1;
     dc->dev_ns.clear();
+    hm_mark_all(dc);
+    if (int rc_ = pre_run(dc)) return rc_;
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     g_only_family = family;
@@ -1813,6 +1930,19 @@ int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsig
                 break;
             }
     }
+    return 0;
+}
+
+/* head-major K / V shadows of a decoder (gten_decode_attn_hm.h): whether it keeps them, how many sequence imports (rows ->
+ * shadow) it has launched so far and in how many launches -- tests watch these to see that a write into a cache row is
+ * followed by a re-import */
+int gten_hip_decoder_kv_info(gten_hip_decoder* dc, int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches)
+{
+    GTR_NEED_INIT();
+    GTR_REQUIRE(dc, "decoder_kv_info: null decoder");
+    if (head_major) *head_major = dc->hm ? 1 : 0;
+    if (seq_imports) *seq_imports = dc->hm_imports;
+    if (import_launches) *import_launches = dc->hm_import_launches;
     return 0;
 }
 

@@ -20,6 +20,9 @@ struct AttnArgs {
     const void* const* kv_tab; int layer, n_layers;
     int qkv_stride, scores_stride, stats_stride, part_stride;
     int qkv_plane;                // grouped kernels: floats to the second K-split plane of qkv_raw (0: a single plane)
+    // head-major shadows of the caches (gten_decode_attn_hm.h; decoders of 16+ sequences): this layer's K shadow of the lane's
+    // first sequence, bytes from one sequence's shadows to the next, bytes of one shadow (the V shadow follows the K shadow)
+    uint8_t* hm_k; size_t hm_seq_stride, hm_cache_bytes;
 };
 
 // The cache pointers may come out of the device table (multi-sequence), so hipcc only knows them as generic pointers
@@ -38,6 +41,7 @@ __device__ __forceinline__ AttnArgs attn_for_seq(const AttnArgs& a, int seq)
     t.stats = a.stats + (size_t)seq * a.stats_stride;
     t.att_part = a.att_part + (size_t)seq * a.part_stride;
     t.rope_now = a.rope_now + (size_t)seq * (a.d_head >> 1);
+    t.hm_k = a.hm_k + (size_t)seq * a.hm_seq_stride;
     if (a.kv_tab) {
         t.kcache = (uint8_t*)a.kv_tab[((size_t)seq * a.n_layers + a.layer) * 2];
         t.vcache = (uint8_t*)a.kv_tab[((size_t)seq * a.n_layers + a.layer) * 2 + 1];

@@ -1,0 +1,366 @@
+// gten_decode_attn_hm.h: decode attention of 16+ sequences on HEAD-MAJOR K / V shadows (round 5) -- part of the single-token
+// decode translation unit: included by gten_decode.hip (which owns the includes, the LDS symbol, the launch macros and the
+// host side).
+//
+// The reference keeps a K / V cache as rows [max_ctx][n_kv x 68 bytes] (gten/modules.cpp:188-201; a kv head's slice of a
+// Q8 row = two 34-byte blocks, gten/quants.h:17-23), and so do the module tensors and every operator of this library.  A
+// decode step of many sequences reads each cache once per step and little else: 92 % of the bytes of a 256-sequence step at
+// ctx 2048.  A (kv head, 256-position chunk) workgroup reading 68-byte slices of 272-byte rows uses half of every
+// 128-byte line it touches (round 4: 3.4-3.7 TB/s for the requests alone, against 5.1-5.5 TB/s for one contiguous run), and
+// the slices then have to be re-laid in LDS before the matrix cores can take them.  A decoder of 16+ sequences (Q8
+// activations, fast forms) therefore keeps a SHADOW of every sequence's caches, laid out for exactly this kernel:
+//
+//   shadow of one (sequence, layer, K | V):  [kv head][chunk of 256 positions][HM_CHUNK_BYTES = 17 408 = 256 x 68]
+//   a K chunk   bytes [0, 16384)  the quants in MATRIX-OPERAND order: 16 tiles of 16 positions x 1 KiB; inside a tile lane
+//               l = 16 lq + lc of a wave owns bytes [16 l, 16 l + 16) = elements 16 lq .. 16 lq + 15 of position 16 T + lc --
+//               a tile is ONE coalesced 16-byte-per-lane load straight into the A operand of v_mfma_i32_16x16x64_i8
+//               bytes [16384, 17408)  the block deltas (f16) as [block][lq][tile][4 positions]: a lane's 64 deltas are one
+//               contiguous 128-byte run
+//   a V chunk   bytes [0, 16384)  the quants TRANSPOSED and biased (q ^ 0x80), 8 steps of 32 positions x 2 KiB; lane l owns
+//               16 bytes = two element tiles x 8 positions in the order the score tiles leave their probabilities in the
+//               registers (slot j < 4: position 32 s + 4 lq + j, j >= 4: 32 s + 16 + 4 lq + j - 4): the A operand of
+//               v_mfma_f32_16x16x32_f16 after a byte -> f16 expansion, no transpose through LDS
+//               bytes [16384, 17408)  the block deltas as [lq][position pair][step][tile][position][half]: again one
+//               128-byte run per lane
+// The same 17 408 bytes per chunk as the cache rows hold, as ONE contiguous run per matrix.
+//
+// The row caches stay the truth: the shadows are filled from them (k_kv_import_hm) whenever a sequence (re)starts or
+// anything wrote into its rows (gten_rt.h, kv_watch_*), the decode appends go to both, and every other path -- operators,
+// the prompt kernels, decoders of up to 8 sequences, the exact forms, f16 activations -- reads the rows as before.
+//
+// k_dec_attn_hm: ONE WAVE per (sequence, kv head, chunk), no barrier against another wave, LDS only for the 8 head
+// vectors of the group.  Scores as K . Q^T (positions on the rows): one v_mfma_i32_16x16x64_i8 per 16 positions gives, for
+// the group's 8 heads, the exact integer dots of BOTH quant blocks at once -- columns 0..7 hold head j's block 0 (the B
+// operand's lanes lq >= 2 are zero there), columns 8..15 head j's block 1 -- scaled (isum dq dk) and added across the
+// column pair by one DPP rotate, exactly the two terms k_dec_attn_mm_g adds.  A lane then owns 2 of its tile's 4
+// positions under one head: 32 scores per lane, every lane busy; maxima, sums of exponentials and the Q8 block maxima of
+// the probabilities (32 positions along the context, gten/ops.h:996-997) are in-lane loops plus three cross-lane steps.
+// The probabilities, rounded to Q8 and with the V row's block delta folded in (one fp16 rounding: k_dec_attn_mm_g's A
+// operand), ARE the B operand of p.V as they stand (V^T x P^T, v_mfma_f32_16x16x32_f16): no LDS, no transpose.
+// The new position never touches the chunk's registers: its score, probability and p.V term are formed from the chip's
+// own K / V row beside the matrix instructions (its probability joins its Q8 block's maximum).
+// Same chunk-local statistics and partials as k_dec_attn_mm_g (the consumer joins the chunks, PRO_ATTW); per (head,
+// position) the same operations -- what differs is the order of the f32 additions in a chunk's sum of exponentials and in
+// p.V (the matrix core's order over another assignment of positions to its steps).
+// three waves per SIMD: the kernel fits 160 registers without a spill (hipcc takes 176 when left alone)
+#ifndef HM_OCC
+#define HM_OCC __attribute__((amdgpu_waves_per_eu(3)))
+#endif
+#define HM_CHUNK_BYTES 17408
+#define HM_Q_BYTES 16384
+
+// byte offsets inside a chunk: position p in [0, 256), element e in [0, 64), quant block / half in {0, 1}
+__host__ __device__ __forceinline__ unsigned hm_k_q_off(unsigned p, unsigned e) { return (p >> 4) * 1024u + (((e >> 4) * 16u + (p & 15u)) * 16u) + (e & 15u); }
+__host__ __device__ __forceinline__ unsigned hm_k_d_off(unsigned p, unsigned blk) { return HM_Q_BYTES + blk * 512u + ((p & 15u) >> 2) * 128u + (p >> 4) * 8u + (p & 3u) * 2u; }
+__host__ __device__ __forceinline__ unsigned hm_v_q_off(unsigned p, unsigned e)
+{
+    const unsigned s = p >> 5, tp = (p >> 4) & 1u, r = p & 15u, et = e >> 4;
+    return s * 2048u + (et >> 1) * 1024u + (((r >> 2) * 16u + (e & 15u)) * 16u) + (et & 1u) * 8u + 4u * tp + (r & 3u);
+}
+__host__ __device__ __forceinline__ unsigned hm_v_d_off(unsigned p, unsigned half)
+{
+    const unsigned s = p >> 5, tp = (p >> 4) & 1u, r = p & 15u;
+    return HM_Q_BYTES + ((r >> 2) * 2u + ((r >> 1) & 1u)) * 128u + s * 16u + (tp * 4u + (r & 1u) * 2u + half) * 2u;
+}
+
+// ---- row caches -> shadows: one workgroup per (kv head, chunk) x (layer, K | V) x listed sequence.  Rows [0, n - 1) of a
+// sequence at step n are its context (the step itself appends row n - 1); chunks without such a row return at once.
+struct HmImportList { int n; int seq[512]; };
+
+__global__ __launch_bounds__(256) void k_kv_import_hm(const HmImportList items, const DecStep* __restrict__ step, const void* const* __restrict__ kv_tab,
+                                                      uint8_t* __restrict__ hm_base, size_t hm_seq_stride, size_t hm_cache_bytes, int n_layers, int n_kv,
+                                                      int n_chunks, int max_ctx, size_t kv_pitch)
+{
+    const int seq = items.seq[blockIdx.z], layer = blockIdx.y >> 1, kv = blockIdx.y & 1;
+    const int g = blockIdx.x % n_kv, chunk = blockIdx.x / n_kv, c0 = chunk * DEC_CHUNK;
+    const int rows = step[seq].n - 1;                             // cached positions of the sequence
+    if (c0 >= rows) return;
+    const uint8_t* src = (const uint8_t*)kv_tab[((size_t)seq * n_layers + layer) * 2 + kv] + (size_t)g * 68;
+    uint8_t* dst = hm_base + (size_t)seq * hm_seq_stride + (size_t)(layer * 2 + kv) * hm_cache_bytes + (size_t)(g * n_chunks + chunk) * HM_CHUNK_BYTES;
+    unsigned* raw = (unsigned*)g_smem;                            // [256][17]: the slices as they lie in the cache
+    {
+        const int p = threadIdx.x, row = min(c0 + p, max_ctx - 1);
+        const gmem_u32 s = as_global(src + (size_t)row * kv_pitch);
+#pragma unroll
+        for (int j = 0; j < 17; j++) raw[p * 17 + j] = s[j];
+    }
+    __syncthreads();
+    const uint8_t* rb = (const uint8_t*)raw;
+    // element e of a slice sits at byte 2 + e (block 0) or 4 + e (block 1: behind the second delta)
+    auto elem = [&](unsigned p, unsigned e) -> unsigned { return rb[p * 68u + e + (e < 32u ? 2u : 4u)]; };
+    for (unsigned q = threadIdx.x; q < 1024u; q += 256u) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (kv == 0) {
+            // K piece q = 64 T + 16 lq + lc: elements 16 lq .. 16 lq + 15 of position 16 T + lc
+            const unsigned T = q >> 6, lq = (q >> 4) & 3u, lc = q & 15u, p = 16u * T + lc;
+#pragma unroll
+            for (unsigned j = 0; j < 16; j++) w[j >> 2] |= elem(p, 16u * lq + j) << (8u * (j & 3u));
+        } else {
+            // V piece q = 128 s + 64 ep + 16 lq + lc: element tiles 2 ep, 2 ep + 1 at column lc, 8 positions each
+            const unsigned s = q >> 7, ep = (q >> 6) & 1u, lq = (q >> 4) & 3u, lc = q & 15u;
+#pragma unroll
+            for (unsigned j = 0; j < 16; j++) {
+                const unsigned et = 2u * ep + (j >> 3), slot = j & 7u, p = 32u * s + 16u * (slot >> 2) + 4u * lq + (slot & 3u);
+                w[j >> 2] |= (elem(p, 16u * et + lc) ^ 0x80u) << (8u * (j & 3u));
+            }
+        }
+        *(uint4*)(dst + (size_t)q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    {
+        const unsigned p = threadIdx.x;
+        const uint16_t d0 = *(const uint16_t*)(rb + p * 68u), d1 = *(const uint16_t*)(rb + p * 68u + 34u);
+        if (kv == 0) { *(uint16_t*)(dst + hm_k_d_off(p, 0)) = d0; *(uint16_t*)(dst + hm_k_d_off(p, 1)) = d1; }
+        else { *(uint16_t*)(dst + hm_v_d_off(p, 0)) = d0; *(uint16_t*)(dst + hm_v_d_off(p, 1)) = d1; }
+    }
+}
+
+// ---- cross-lane steps of the one-wave kernel
+__device__ __forceinline__ float hm_ror8(float v)               // the lane 8 columns away in its row of 16 (row_ror:8)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
+}
+__device__ __forceinline__ unsigned hm_ror8_u(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float hm_rows_max(float v)           // over the four rows of 16 lanes (same column); every lane gets it
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float hm_rows_sum(float v)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// four biased bytes (q ^ 0x80) -> four exact f16 integers: 0x6400 | b is 1024 + (q + 128); minus 1152
+typedef _Float16 hm_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hm_bytes_to_h4(unsigned b4, unsigned& lo, unsigned& hi)
+{
+    const unsigned x0 = __builtin_amdgcn_perm(0x64646464u, b4, 0x04010400u);      // [b0, 0x64, b1, 0x64]
+    const unsigned x1 = __builtin_amdgcn_perm(0x64646464u, b4, 0x04030402u);      // [b2, 0x64, b3, 0x64]
+    const hm_h2 k = {(_Float16)1152.0f, (_Float16)1152.0f};
+    lo = __builtin_bit_cast(unsigned, __builtin_bit_cast(hm_h2, x0) - k);
+    hi = __builtin_bit_cast(unsigned, __builtin_bit_cast(hm_h2, x1) - k);
+}
+
+template <int GRP>
+__global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, const int n_seq)
+{
+    constexpr int dh = 64;
+    // id -> (kv head, sequence, chunk): the live workgroups of short contexts (chunk 0) are the first ids, spread over all XCDs
+    const int g = blockIdx.x % a0.n_kv, sci = blockIdx.x / a0.n_kv, seq = sci % n_seq, chunk = sci / n_seq, c0 = chunk * DEC_CHUNK;
+    const AttnArgs a = attn_for_seq(a0, seq);
+    const int n = a.step->n, pos = n - 1;
+    if (c0 >= n) return;
+    // cached positions of this chunk: [c0, c0 + len); position `pos` itself comes from the chip when it lies in this chunk
+    const int len = min(DEC_CHUNK, pos - c0);
+    const bool has_new = pos < c0 + DEC_CHUNK;                    // (uniform per wave)
+    const int t = threadIdx.x, lc = t & 15, lq = t >> 4, hd = lc & 7, hi = lc >> 3;
+    const int kv_dim = a.n_kv * dh;
+
+    int8_t* qi8 = (int8_t*)g_smem;                                // [8][64] head vectors
+    int8_t* ki8 = qi8 + 8 * dh;                                   // 64: the new K row
+    int8_t* vi8 = ki8 + dh;                                       // 64: the new V row
+    float* qd = (float*)(vi8 + dh);                               // [8][2]
+    float* kd = qd + 16;                                          // 8: new k deltas, new v deltas
+    uint16_t* d16 = (uint16_t*)(kd + 8);                          // [8 + 2][4] halves
+
+    // ---- requests: the raw projections, the rotation, then the chunk's K tiles and deltas (tiles past the context
+    //      re-read the last live tile: no traffic, no branch around a request)
+    float qraw[GRP];
+#pragma unroll
+    for (int j = 0; j < GRP; j++) qraw[j] = a.qkv_raw[(g * GRP + j) * dh + t];
+    float kraw = a.qkv_raw[a.n_embd + g * dh + t], vraw = a.qkv_raw[a.n_embd + kv_dim + g * dh + t];
+    if (a.qkv_plane) {                                            // second K-split plane of the projections (uniform)
+#pragma unroll
+        for (int j = 0; j < GRP; j++) qraw[j] += a.qkv_raw[a.qkv_plane + (g * GRP + j) * dh + t];
+        kraw += a.qkv_raw[a.qkv_plane + a.n_embd + g * dh + t];
+        vraw += a.qkv_raw[a.qkv_plane + a.n_embd + kv_dim + g * dh + t];
+    }
+    const float2 rot = a.rope_now[t & 31];
+    const uint8_t* kc = a.hm_k + (size_t)(g * a.n_chunks + chunk) * HM_CHUNK_BYTES;
+    const uint8_t* vc = kc + a.hm_cache_bytes;
+    const int Tl = max(len - 1, 0) >> 4, Sl = Tl >> 1;
+    typedef int hm_v4i __attribute__((ext_vector_type(4)));
+    typedef const hm_v4i __attribute__((address_space(1)))* gmem_v4i;
+    hm_v4i ka[16], kdw[8];
+    {
+        const gmem_v4i kq = (gmem_v4i)(uintptr_t)(kc + t * 16);
+#pragma unroll
+        for (int T = 0; T < 16; T++) ka[T] = kq[min(T, Tl) * 64];
+        const gmem_v4i kdp = (gmem_v4i)(uintptr_t)(kc + HM_Q_BYTES + hi * 512 + lq * 128);
+#pragma unroll
+        for (int j = 0; j < 8; j++) kdw[j] = kdp[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- head vectors of the group (write -> rope -> write, gten/modules.cpp:196-201), the new K / V rows
+#pragma unroll
+    for (int j = 0; j < GRP; j++) head_prep_cs(qraw[j], true, true, rot, dh, GTEN_Q8, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
+    if (has_new) {
+        head_prep_cs(kraw, true, true, rot, dh, GTEN_Q8, ki8, kd, d16 + 4 * GRP);
+        head_prep_cs(vraw, true, false, rot, dh, GTEN_Q8, vi8, kd + 4, d16 + 4 * (GRP + 1));
+    }
+    __syncthreads();                                              // (one wave: orders its own LDS traffic)
+    // B operand: column lc = head hd's block hi -- its 16 bytes where the lane's K bytes belong to that block, else zero
+    const bool bsel = ((hi == 0) == (lq < 2)) && hd < GRP;
+    hm_v4i qb = *(const hm_v4i*)(qi8 + hd * dh + 16 * lq);
+    {
+        const hm_v4i z = {0, 0, 0, 0};
+        qb = bsel ? qb : z;
+    }
+    const float dq = qd[2 * hd + hi];
+    const unsigned pn = (unsigned)(pos - c0);                     // the new position inside the chunk (has_new)
+    float scn = -INFINITY;                                        // its score under head hd
+    if (has_new) {
+        // appends: the cache rows (as every decode path leaves them) and the shadows
+        {
+            uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * 68, *vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * 68;
+            const unsigned kb = (uint8_t)ki8[t], vb = (uint8_t)vi8[t];
+            store_global<uint8_t>(krow + (t >> 5) * GTEN_Q8_BYTES + 2 + (t & 31), (uint8_t)kb);
+            store_global<uint8_t>(vrow + (t >> 5) * GTEN_Q8_BYTES + 2 + (t & 31), (uint8_t)vb);
+            uint8_t* kcw = a.hm_k + (size_t)(g * a.n_chunks + chunk) * HM_CHUNK_BYTES;
+            uint8_t* vcw = kcw + a.hm_cache_bytes;
+            store_global<uint8_t>(kcw + hm_k_q_off(pn, (unsigned)t), (uint8_t)kb);
+            store_global<uint8_t>(vcw + hm_v_q_off(pn, (unsigned)t), (uint8_t)(vb ^ 0x80u));
+            if ((t & 31) == 0) {
+                const unsigned b = (unsigned)t >> 5;
+                const uint16_t kdl = d16[4 * GRP + b], vdl = d16[4 * (GRP + 1) + b];
+                store_global<uint16_t>(krow + b * GTEN_Q8_BYTES, kdl);
+                store_global<uint16_t>(vrow + b * GTEN_Q8_BYTES, vdl);
+                store_global<uint16_t>(kcw + hm_k_d_off(pn, b), kdl);
+                store_global<uint16_t>(vcw + hm_v_d_off(pn, b), vdl);
+            }
+        }
+        // its score: every row of the A operand is the new K row, so every lane gets its column's block dot in place
+        const hm_v4i kn = *(const hm_v4i*)(ki8 + 16 * lq);
+        const hm_v4i z = {0, 0, 0, 0};
+        const hm_v4i cn = __builtin_amdgcn_mfma_i32_16x16x64_i8(kn, qb, z, 0, 0, 0);
+        const float tn = (float)cn[0] * (dq * kd[hi]);
+        scn = (tn + hm_ror8(tn)) * 0.125f;                        // 1 / sqrt(64)
+    }
+
+    // ---- scores: lane (lc, lq) keeps positions 16 T + 4 lq + 2 hi + u (u = 0, 1) under head hd
+    float sc[16][2];
+#pragma unroll
+    for (int T = 0; T < 16; T++) {
+        const hm_v4i z = {0, 0, 0, 0};
+        const hm_v4i c = __builtin_amdgcn_mfma_i32_16x16x64_i8(ka[T], qb, z, 0, 0, 0);
+        // this lane's block deltas of positions 16 T + 4 lq + i
+        const unsigned w0 = (unsigned)kdw[T >> 1][(T & 1) * 2], w1 = (unsigned)kdw[T >> 1][(T & 1) * 2 + 1];
+        float term[4];
+        term[0] = (float)c[0] * (dq * h2f((uint16_t)(w0 & 0xffffu)));
+        term[1] = (float)c[1] * (dq * h2f((uint16_t)(w0 >> 16)));
+        term[2] = (float)c[2] * (dq * h2f((uint16_t)(w1 & 0xffffu)));
+        term[3] = (float)c[3] * (dq * h2f((uint16_t)(w1 >> 16)));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            // the column 8 away holds the other block's term of the same (head, position): it needs mine of ITS positions
+            const float mine = hi ? term[2 + u] : term[u], send = hi ? term[u] : term[2 + u];
+            const float both = mine + hm_ror8(send);
+            const bool live = 16 * T + 4 * lq + 2 * hi + u < len;
+            sc[T][u] = live ? both * 0.125f : -INFINITY;
+        }
+    }
+    // ---- the V chunk and its deltas are requested now (the K registers are free; their flight hides behind the softmax)
+    hm_v4i va[8][2], vdw[8];
+    {
+        const gmem_v4i vq = (gmem_v4i)(uintptr_t)(vc + t * 16);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { va[s][0] = vq[min(s, Sl) * 128]; va[s][1] = vq[min(s, Sl) * 128 + 64]; }
+        const gmem_v4i vdp = (gmem_v4i)(uintptr_t)(vc + HM_Q_BYTES + (lq * 2 + hi) * 128);
+#pragma unroll
+        for (int s = 0; s < 8; s++) vdw[s] = vdp[s];
+    }
+    // ---- chunk maximum and sum of exponentials per head (hardware exponential, as k_dec_attn_mm_g)
+    float M = scn;
+#pragma unroll
+    for (int T = 0; T < 16; T++) M = fmaxf(M, fmaxf(sc[T][0], sc[T][1]));
+    M = fmaxf(M, hm_ror8(M));
+    M = hm_rows_max(M);
+    float L = 0.f;
+#pragma unroll
+    for (int T = 0; T < 16; T++) {
+        sc[T][0] = __expf(sc[T][0] - M);                          // exp(-inf) = 0 for masked positions
+        sc[T][1] = __expf(sc[T][1] - M);
+        L += sc[T][0] + sc[T][1];
+    }
+    L += hm_ror8(L);
+    L = hm_rows_sum(L);
+    float en = 0.f;
+    if (has_new) { en = __expf(scn - M); L += en; }
+    if (lq == 0 && hi == 0 && hd < GRP)
+        *(float2*)(a.stats + ((size_t)(g * GRP + hd) * a.n_chunks + chunk) * 2) = make_float2(M, L);
+    const float rL = recip_rn(L);
+
+    // ---- per block of 32 positions (tiles 2 s, 2 s + 1): Q8 rounding of the probabilities, the V deltas folded in, p.V
+    const int sn = (int)(pn >> 5);
+    const float pnew = en * rL;
+    float pnq = 0.f;                                              // the new position's probability as stored (Q8)
+    att_f4 acc[4];
+#pragma unroll
+    for (int et = 0; et < 4; et++) acc[et] = att_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        float p[4] = {sc[2 * s][0] * rL, sc[2 * s][1] * rL, sc[2 * s + 1][0] * rL, sc[2 * s + 1][1] * rL};
+        float am = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+        am = fmaxf(am, hm_ror8(am));
+        am = hm_rows_max(am);
+        const bool mine_new = has_new && s == sn;                 // (uniform)
+        if (mine_new) am = fmaxf(am, pnew);
+        const Q8Scale qs = q8_scale_from_absmax(am);
+        if (mine_new) pnq = (float)q8_round(pnew, qs.scale) * qs.ddeq;
+        unsigned own[2][2];                                       // [tile][half]: f16 pairs (u = 0, 1)
+#pragma unroll
+        for (int tp = 0; tp < 2; tp++) {
+            const unsigned d0 = (unsigned)vdw[s][2 * tp], d1 = (unsigned)vdw[s][2 * tp + 1];   // u = 0 | u = 1: (half 0, half 1)
+            const bool l0 = 32 * s + 16 * tp + 4 * lq + 2 * hi < len, l1 = 32 * s + 16 * tp + 4 * lq + 2 * hi + 1 < len;
+            const float q0 = (float)q8_round(p[2 * tp], qs.scale) * qs.ddeq, q1 = (float)q8_round(p[2 * tp + 1], qs.scale) * qs.ddeq;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float dv0 = h2f((uint16_t)(h ? d0 >> 16 : d0 & 0xffffu)), dv1 = h2f((uint16_t)(h ? d1 >> 16 : d1 & 0xffffu));
+                const _Float16 a0h = f2hv(l0 ? q0 * dv0 : 0.f), a1h = f2hv(l1 ? q1 * dv1 : 0.f);
+                const hm_h2 pr = {a0h, a1h};
+                own[tp][h] = __builtin_bit_cast(unsigned, pr);
+            }
+        }
+        // B operand of half h for the head columns (hi = 0): slots {own, the column 8 away} per tile
+        att_h8 bp[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned w[4] = {own[0][h], hm_ror8_u(own[0][h]), own[1][h], hm_ror8_u(own[1][h])};
+            __builtin_memcpy(&bp[h], w, 16);
+        }
+#pragma unroll
+        for (int et = 0; et < 4; et++) {
+            const unsigned b0 = (unsigned)va[s][et >> 1][(et & 1) * 2], b1 = (unsigned)va[s][et >> 1][(et & 1) * 2 + 1];
+            unsigned w[4];
+            hm_bytes_to_h4(b0, w[0], w[1]);
+            hm_bytes_to_h4(b1, w[2], w[3]);
+            att_h8 av;
+            __builtin_memcpy(&av, w, 16);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bp[et >> 1], acc[et], 0, 0, 0);
+        }
+    }
+    // ---- the new position's term from the chip: out[head][e] += f16(p dv[half]) v[e]
+    if (has_new) {
+#pragma unroll
+        for (int et = 0; et < 4; et++) {
+            const float pv = (float)f2hv(pnq * h2f(d16[4 * (GRP + 1) + (et >> 1)]));
+            const unsigned vb = *(const unsigned*)(vi8 + 16 * et + 4 * lq);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[et][i] += pv * (float)(int8_t)((vb >> (8 * i)) & 0xffu);
+        }
+    }
+    // C layout: column lc = head, rows e = 16 et + 4 lq + i
+    if (hi == 0 && hd < GRP) {
+        float* o = a.att_part + ((size_t)(g * GRP + hd) * a.n_chunks + chunk) * dh + 4 * lq;
+#pragma unroll
+        for (int et = 0; et < 4; et++) *(float4*)(o + 16 * et) = make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
+    }
+}

@@ -778,6 +778,7 @@ int gten_hip_pack_weight(const void* src_blocks, int dtype, int rows, int cols, 
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(src_blocks && dst_packed && rows > 0 && cols > 0, "pack_weight: bad arguments");
+    kv_watch_touch(dst_packed, (size_t)rows * gten_hip_row_bytes(dtype, cols));      // (every writer of device memory: gten_rt.h, watched K / V caches)
     if (dtype == GTEN_F16) {
         GTR_CHECK(hipMemcpyAsync(dst_packed, src_blocks, (size_t)rows * cols * 2, hipMemcpyDeviceToDevice, stream()));
         return 0;
@@ -802,6 +803,7 @@ int gten_hip_token_embed(const void* w, int w_dtype, int n_vocab, const int32_t*
     GTR_REQUIRE(d > 0 && d % 32 == 0 && d <= 8192, "token_embed: unsupported width %d", d);
     GTR_REQUIRE(act_dtype_ok(out_dtype), "token_embed: bad output dtype %d", out_dtype);
     GTR_REQUIRE(out_pitch >= gten_hip_row_bytes(out_dtype, d), "token_embed: output pitch too small");
+    kv_watch_touch(out, (size_t)n * out_pitch);
     const dim3 grid(n - start_pos), block(256);
     if (w_dtype == GTEN_F16) {
         GTR_REQUIRE(out_dtype == GTEN_F16, "token_embed: f16 table needs f16 output (row copy, gten/ops.h:529)");
@@ -833,6 +835,7 @@ int gten_hip_matmul_2d(const void* x, int x_dtype, size_t x_pitch, const void* w
     GTR_REQUIRE(x_pitch >= gten_hip_row_bytes(x_dtype, d_in), "matmul_2d: input pitch too small");
     GTR_REQUIRE(out_pitch >= gten_hip_row_bytes(out_dtype, d_out), "matmul_2d: output pitch too small");
     GTR_REQUIRE(n - start_pos <= 65535, "matmul_2d: too many new rows");
+    kv_watch_touch(out, (size_t)n * out_pitch);       // (the key / value projections write the K / V caches: gten/modules.cpp:188-201)
     // prefill-sized calls go to the matrix cores (gten_mfma.hip); the row-per-workgroup
     // kernel below streams the weights once per row and is meant for a handful of rows
     if (n - start_pos >= GTEN_MFMA_MIN_ROWS && d_in % 128 == 0)   // the MFMA kernel stages 4 quant blocks at a time
@@ -865,6 +868,7 @@ int gten_hip_rms_norm(const void* x, int dtype, size_t x_pitch, const void* w_f1
     GTR_NEED_INIT();
     if (int rc = check_rowwise("rms_norm", x, out, dtype, x_pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(w_f16 && out_pitch >= gten_hip_row_bytes(dtype, d), "rms_norm: bad weight/output");
+    kv_watch_touch(out, (size_t)n * out_pitch);
     if (n - start_pos >= 4 && rms_norm_q8w_ok(x, x_pitch, w_f16, out, out_pitch, dtype, d)) {
         GTR_LAUNCH(KT_RMSNORM, k_rms_norm_q8w, dim3(n - start_pos), dim3(64), 0, (const uint8_t*)x, x_pitch, (const uint16_t*)w_f16, (uint8_t*)out, out_pitch,
                    start_pos, (uint4*)nullptr);
@@ -882,6 +886,7 @@ int gten_hip_rotary_emb(void* x, int dtype, size_t pitch, int n, int d, int d_he
     if (int rc = check_rowwise("rotary_emb", x, x, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(d_head > 0 && d_head % 2 == 0 && d % d_head == 0, "rotary_emb: bad d_head %d for width %d", d_head, d);
     GTR_REQUIRE(n <= GTEN_ROPE_MAX_POS, "rotary_emb: position %d beyond the table (%d)", n, GTEN_ROPE_MAX_POS);
+    kv_watch_touch(x, (size_t)n * pitch);             // (K is rotated in place in its cache: gten/modules.cpp:199)
     const float2* table = nullptr;
     if (int rc = rope_table(d_head, &table)) return rc;
     if (n - start_pos >= 4 && rope_q8w_ok(x, pitch, dtype, d, d_head)) {
@@ -896,6 +901,7 @@ int gten_hip_silu(const void* x, void* out, int dtype, size_t pitch, int n, int 
 {
     GTR_NEED_INIT();
     if (int rc = check_rowwise("silu", x, out, dtype, pitch, n, d, start_pos)) return rc;
+    kv_watch_touch(out, (size_t)n * pitch);
     if (elementwise_q8x2_ok(x, nullptr, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_SILU>(x, nullptr, out, pitch, n, d, start_pos);
     if (elementwise_f16x8_ok(x, nullptr, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_f16x8<EW_SILU>(x, nullptr, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_SILU>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
@@ -908,6 +914,7 @@ int gten_hip_mul(const void* a, const void* b, void* out, int dtype, size_t pitc
     GTR_NEED_INIT();
     if (int rc = check_rowwise("mul", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "mul: null pointer");
+    kv_watch_touch(out, (size_t)n * pitch);
     if (elementwise_q8x2_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_MUL>(a, b, out, pitch, n, d, start_pos);
     if (elementwise_f16x8_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_f16x8<EW_MUL>(a, b, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_MUL>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
@@ -920,6 +927,7 @@ int gten_hip_add(const void* a, const void* b, void* out, int dtype, size_t pitc
     GTR_NEED_INIT();
     if (int rc = check_rowwise("add", a, out, dtype, pitch, n, d, start_pos)) return rc;
     GTR_REQUIRE(b, "add: null pointer");
+    kv_watch_touch(out, (size_t)n * pitch);
     if (elementwise_q8x2_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_q8x2<EW_ADD>(a, b, out, pitch, n, d, start_pos);
     if (elementwise_f16x8_ok(a, b, out, dtype, pitch, n - start_pos, d)) return launch_elementwise_f16x8<EW_ADD>(a, b, out, pitch, n, d, start_pos);
     GTR_LAUNCH(KT_ELEMWISE, (k_elementwise<EW_ADD>), dim3(n - start_pos), dim3(256), (size_t)d * 4,
@@ -958,6 +966,7 @@ int gten_hip_argmax_row(const float* logits, int n, int32_t* out)
 {
     GTR_NEED_INIT();
     GTR_REQUIRE(logits && out && n > 0, "argmax_row: bad arguments");
+    kv_watch_touch(out, 4);
     GTR_LAUNCH(KT_ELEMWISE, k_argmax_row, dim3(1), dim3(1024), 0, logits, n, out);
     return 0;
 }
@@ -976,6 +985,7 @@ int gten_hip_qkv_attn(const void* q, const void* k, const void* v, void* out, in
     GTR_REQUIRE(q_pitch >= gten_hip_row_bytes(dtype, n_heads * d_head) && out_pitch >= gten_hip_row_bytes(dtype, n_heads * d_head) &&
                 kv_pitch >= gten_hip_row_bytes(dtype, n_kv_heads * d_head), "qkv_attn: pitch too small");
     GTR_REQUIRE(n - start_pos <= 65535 && n <= 12288, "qkv_attn: context %d too long for this kernel", n);
+    kv_watch_touch(out, (size_t)n * out_pitch);
     if (dtype == GTEN_Q8 && d_head == 64 && n - start_pos >= GTEN_ATTN_TILED_MIN_ROWS) {
         // prompt processing: 32 rows of a head per workgroup, int8 MFMA scores (same bytes as k_attn below)
         // (fewer than 16 new rows take the row kernel: tests reach it for long inputs by calling in 15-row pieces)
@@ -1029,6 +1039,13 @@ int gten_hip_block_rows(const gten_hip_block_desc* b, int n, int start_pos)
     const void* ptrs[] = {b->attn_norm_w, b->wq, b->wk, b->wv, b->wo, b->ffn_norm_w, b->wgate, b->wup, b->wdown, b->inp, b->attn_norm_out,
                           b->q, b->k, b->v, b->attn_out, b->o, b->h, b->ffn_norm_out, b->gate, b->up, b->down, b->out};
     for (const void* p : ptrs) GTR_REQUIRE(p && ((uintptr_t)p & 15) == 0, "block_rows: null or unaligned pointer");
+    if (kv_watch_any()) {
+        // every buffer this call writes (k and v are the K / V caches); the operators it is composed of touch only their own outputs
+        const size_t rE = gten_hip_row_bytes(b->adtype, E), rKV = gten_hip_row_bytes(b->adtype, KV), rF = gten_hip_row_bytes(b->adtype, F);
+        const std::pair<const void*, size_t> outs[] = {{b->attn_norm_out, rE}, {b->q, rE}, {b->k, rKV}, {b->v, rKV}, {b->attn_out, rE}, {b->o, rE}, {b->h, rE},
+                                                       {b->ffn_norm_out, rE}, {b->gate, rF}, {b->up, rF}, {b->down, rE}, {b->out, rE}};
+        for (const auto& o : outs) kv_watch_touch(o.first, (size_t)n * o.second);
+    }
     if (f16cfg) {
         // the f16 configuration: no f16 copies to make (the rows are the operands), otherwise the same composition
         const size_t hE = (size_t)E * 2, hKV = (size_t)KV * 2, hF = (size_t)F * 2;
@@ -1210,6 +1227,7 @@ int gten_hip_copy_ranges(const gten_hip_copy_range* ranges, int n)
     size_t longest = 0;
     for (int i = 0; i < n; i++) {
         GTR_REQUIRE(ranges[i].dst && ranges[i].src, "copy_ranges: range %d is null", i);
+        kv_watch_touch(ranges[i].dst, ranges[i].bytes);
         t.r[i] = ranges[i];
         longest = std::max(longest, ranges[i].bytes);
     }

@@ -17,6 +17,19 @@ void stream_override(hipStream_t s);   // launches go to `s` until it is reset w
 bool inited();
 int rope_table(int d_head, const float2** out);
 
+// ---- watched K / V caches (round 5).  A decoder of 16+ sequences keeps HEAD-MAJOR shadows of its sequences' K / V caches
+// (gten_decode_attn_hm.h) and registers every row-layout cache it shadows here, one flag per sequence.  EVERY entry point of
+// the C-ABI that writes device memory calls kv_watch_touch on its output range: a write that overlaps a watched cache sets
+// the owner's flag, and the owner re-imports that sequence's rows before its next step -- a stale shadow is impossible for
+// writes that go through this library (all of its kernels and copies do).  `except`: the owner whose own decode appends keep
+// its shadow current.  The registry is host-only state (one calling thread, like the rest of the library).
+void kv_watch_add(const void* p, size_t bytes, const void* owner, char* dirty_flag);
+void kv_watch_remove(const void* owner, const char* dirty_flag);     // the entries of one flag (dirty_flag null: all of the owner's)
+void kv_watch_touch(const void* p, size_t bytes, const void* except = nullptr);
+bool kv_watch_any();                   // false: nothing is watched, touches are free
+unsigned long long kv_watch_epoch();   // bumped by every add / remove: callers cache "do my caches overlap a foreign watch"
+bool kv_watch_overlaps(const void* p, size_t bytes, const void* except);
+
 } // namespace gtr
 
 #define GTR_CHECK(expr)                                                                        \

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -65,6 +66,61 @@ int rope_table(int d_head, const float2** out)
     *out = dev;
     return 0;
 }
+
+// ---- watched K / V caches (gten_rt.h) -------------------------------------
+// Sorted by start address; the caches of one decoder are equally long and disjoint, those of different decoders may
+// coincide (two decoders over the same sequences), so a lookup scans every entry that starts inside
+// (p - longest entry, p + bytes).
+struct KvWatch { uintptr_t lo, hi; const void* owner; char* flag; };
+static std::multimap<uintptr_t, KvWatch> g_watch;
+static size_t g_watch_longest = 0;
+static unsigned long long g_watch_epoch = 1;
+
+void kv_watch_add(const void* p, size_t bytes, const void* owner, char* dirty_flag)
+{
+    if (!p || !bytes) return;
+    const uintptr_t lo = (uintptr_t)p;
+    g_watch.emplace(lo, KvWatch{lo, lo + bytes, owner, dirty_flag});
+    if (bytes > g_watch_longest) g_watch_longest = bytes;
+    g_watch_epoch++;
+}
+
+void kv_watch_remove(const void* owner, const char* dirty_flag)
+{
+    for (auto it = g_watch.begin(); it != g_watch.end();) {
+        if (it->second.owner == owner && (!dirty_flag || it->second.flag == dirty_flag)) it = g_watch.erase(it);
+        else ++it;
+    }
+    if (g_watch.empty()) g_watch_longest = 0;
+    g_watch_epoch++;
+}
+
+template <typename F>
+static void kv_watch_scan(const void* p, size_t bytes, const void* except, F&& hit)
+{
+    if (g_watch.empty() || !p || !bytes) return;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    const uintptr_t from = lo > g_watch_longest ? lo - g_watch_longest : 0;
+    for (auto it = g_watch.lower_bound(from); it != g_watch.end() && it->first < hi; ++it) {
+        const KvWatch& w = it->second;
+        if (w.hi > lo && w.owner != except) hit(w);
+    }
+}
+
+void kv_watch_touch(const void* p, size_t bytes, const void* except)
+{
+    kv_watch_scan(p, bytes, except, [](const KvWatch& w) { *w.flag = 1; });
+}
+
+bool kv_watch_overlaps(const void* p, size_t bytes, const void* except)
+{
+    bool any = false;
+    kv_watch_scan(p, bytes, except, [&](const KvWatch&) { any = true; });
+    return any;
+}
+
+bool kv_watch_any() { return !g_watch.empty(); }
+unsigned long long kv_watch_epoch() { return g_watch_epoch; }
 
 // ---- HIP-event profiler -------------------------------------------------
 static bool g_prof_on = false;
@@ -190,6 +246,7 @@ int gten_hip_stream_idle(int idx, int* idle)
 int gten_hip_memset(void* dptr, int byte, size_t nbytes)
 {
     GTR_NEED_INIT();
+    kv_watch_touch(dptr, nbytes);
     GTR_CHECK(hipMemsetAsync(dptr, byte, nbytes, g_stream));
     return 0;
 }
@@ -199,6 +256,7 @@ int gten_hip_memcpy_h2d(void* dst, const void* src_host, size_t nbytes)
     GTR_NEED_INIT();
     // pageable source: the runtime stages it before returning, so the caller
     // may reuse src_host immediately (the loader reuses one read buffer).
+    kv_watch_touch(dst, nbytes);
     GTR_CHECK(hipMemcpyAsync(dst, src_host, nbytes, hipMemcpyHostToDevice, g_stream));
     GTR_CHECK(hipStreamSynchronize(g_stream));
     return 0;
@@ -215,6 +273,7 @@ int gten_hip_memcpy_d2h(void* dst_host, const void* src, size_t nbytes)
 int gten_hip_memcpy_d2d(void* dst, const void* src, size_t nbytes)
 {
     GTR_NEED_INIT();
+    kv_watch_touch(dst, nbytes);
     GTR_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, g_stream));
     return 0;
 }
@@ -253,6 +312,49 @@ const char* gten_hip_prof_family_name(int family)
         "decode_gemv_qkv", "decode_attn_score", "decode_attn_pv", "decode_gemv_o", "decode_gemv_gateup",
         "decode_gemv_down", "decode_gemv_head", "decode_argmax", "matmul_2d_mfma", "decode_stage", "qkv_attn_tiled", "decode_persistent"};
     return (family >= 0 && family < KT_COUNT) ? names[family] : nullptr;
+}
+
+// The watched-cache registry on made-up addresses (nothing is dereferenced): every case of "does this write hit that
+// watch" the decoders rely on.  Leaves the registry as it found it.
+int gten_hip_kv_watch_selftest(void)
+{
+    const uintptr_t base = (uintptr_t)1 << 40;
+    auto at = [&](uintptr_t off) { return (const void*)(base + off); };
+    char fa = 0, fb = 0, fc = 0;
+    int owner_a = 0, owner_b = 0;
+    const unsigned long long e0 = kv_watch_epoch();
+    kv_watch_add(at(0x1000), 0x1000, &owner_a, &fa);        // [0x1000, 0x2000)
+    kv_watch_add(at(0x3000), 0x1000, &owner_a, &fb);        // [0x3000, 0x4000)
+    kv_watch_add(at(0x1000), 0x1000, &owner_b, &fc);        // the same rows watched by a second owner
+    int bad = 0;
+    auto expect = [&](int no, bool a, bool b, bool c) {
+        if (!bad && ((fa != 0) != a || (fb != 0) != b || (fc != 0) != c)) bad = no;
+        fa = fb = fc = 0;
+    };
+    if (kv_watch_epoch() == e0 || !kv_watch_any()) bad = 100;
+    kv_watch_touch(at(0x0), 0x1000);                    expect(1, false, false, false);   // ends where the first watch begins
+    kv_watch_touch(at(0x0), 0x1001);                    expect(2, true, false, true);     // one byte into it
+    kv_watch_touch(at(0x1fff), 1);                      expect(3, true, false, true);     // its last byte
+    kv_watch_touch(at(0x2000), 0x1000);                 expect(4, false, false, false);   // the gap between the two
+    kv_watch_touch(at(0x2fff), 2);                      expect(5, false, true, false);    // into the second
+    kv_watch_touch(at(0x0), 0x10000);                   expect(6, true, true, true);      // a range that covers everything
+    kv_watch_touch(at(0x1800), 8, &owner_a);            expect(7, false, false, true);    // the owner's own appends spare its flags
+    kv_watch_touch(at(0x1800), 8, &owner_b);            expect(8, true, false, false);
+    kv_watch_touch(at(0x4000), 0x100);                  expect(9, false, false, false);   // just past the end
+    kv_watch_touch(nullptr, 16);                        expect(10, false, false, false);
+    kv_watch_touch(at(0x1800), 0);                      expect(11, false, false, false);
+    if (!bad && (!kv_watch_overlaps(at(0x1800), 8, &owner_a) || kv_watch_overlaps(at(0x3800), 8, &owner_a))) bad = 12;   // only b's watch is foreign to a
+    kv_watch_remove(&owner_a, &fb);                                                      // one flag's entries (a slot bound to other rows)
+    kv_watch_touch(at(0x3000), 0x1000);                 expect(13, false, false, false);
+    kv_watch_touch(at(0x1000), 4);                      expect(14, true, false, true);
+    kv_watch_add(at(0x8000), 0x4000, &owner_a, &fb);                                     // ... and its new, longer rows
+    kv_watch_touch(at(0xbfff), 1);                      expect(15, false, true, false);
+    kv_watch_touch(at(0x1000), 4);                      expect(16, true, false, true);    // the shorter entries are still found
+    kv_watch_remove(&owner_a, nullptr);
+    kv_watch_touch(at(0x0), 0x10000);                   expect(17, false, false, true);
+    kv_watch_remove(&owner_b, nullptr);
+    kv_watch_touch(at(0x0), 0x10000);                   expect(18, false, false, false);
+    return bad;
 }
 
 size_t gten_hip_row_bytes(int dtype, int cols)

@@ -381,6 +381,23 @@ int gten_host_batch_time_family(gten_host_batch* b, int family, int n, int reps,
     return *avg_us < 0.0 ? -4 : 0;
 }
 
+int gten_host_batch_seq_steps(gten_host_batch* b, int seq, const int32_t* tokens, int count, int n_first, int steps)
+{
+    if (seq < 0 || seq >= b->batch->n_seq() || !tokens || count <= 0 || count > b->cfg.max_ctx || n_first < 1 || steps < 0 ||
+        n_first + steps - 1 > count)
+        return -1;
+    TinyLlama& m = b->batch->seq(seq);                 // the sequence's own model object: its single-sequence decoder on the SAME caches
+    m.decode_set_tokens(tokens, 0, count);
+    m.decode_steps(n_first, steps, true);
+    return 0;
+}
+
+int gten_host_batch_kv_info(gten_host_batch* b, int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches)
+{
+    b->batch->kv_info(head_major, seq_imports, import_launches);
+    return 0;
+}
+
 int gten_host_synth_weight(const gten_host_config* cfg, uint64_t seed, int idx, void* out, size_t nbytes)
 {
     std::vector<float> scratch;

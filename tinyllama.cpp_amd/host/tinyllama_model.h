@@ -586,6 +586,12 @@ public:
         ensure_decoder();
         GTEN_HIP_OK(gten_hip_decoder_logits_seq(dec_, seq_i, out));
     }
+    // head-major K / V shadows of the shared decoder (gten_hip_decoder_kv_info)
+    void kv_info(int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches)
+    {
+        ensure_decoder();
+        GTEN_HIP_OK(gten_hip_decoder_kv_info(dec_, head_major, seq_imports, import_launches));
+    }
     double decode_time_family(int family, int n, int reps, int* launches)
     {
         ensure_decoder();

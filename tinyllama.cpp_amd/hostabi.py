@@ -40,7 +40,7 @@ class GtenHost:
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
         "gten_host_batch_prefill", "gten_host_batch_prefill_many", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_set_serve_schedule", "gten_host_batch_set_serve_spares", "gten_host_batch_set_serve_ramp", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
-        "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family",
+        "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family", "gten_host_batch_kv_info", "gten_host_batch_seq_steps",
     ]
 
     def __init__(self, path=None):
@@ -90,6 +90,8 @@ class GtenHost:
         self._bresult = _sig(L, "gten_host_batch_decode_result", ci, [vp, ci, ci, C.POINTER(C.c_int32)])
         self._blogits = _sig(L, "gten_host_batch_logits", ci, [vp, ci, vp])
         self._btime = _sig(L, "gten_host_batch_time_family", ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci)])
+        self._bseqsteps = _sig(L, "gten_host_batch_seq_steps", ci, [vp, ci, vp, ci, ci, ci])
+        self._bkvinfo = _sig(L, "gten_host_batch_kv_info", ci, [vp, C.POINTER(ci), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
         self._synthw = _sig(L, "gten_host_synth_weight", ci, [cfgp, C.c_uint64, ci, vp, sz])
         self._writeg = _sig(L, "gten_host_write_gten", ci, [cfgp, C.c_uint64, C.c_char_p])
         self._stoks = _sig(L, "gten_host_synthetic_tokens", None, [vp, ci, C.c_uint32, ci])
@@ -374,6 +376,17 @@ class HostBatch:
         out = np.zeros(self.cfg.n_vocab, np.float32)
         self._ck(self.host._blogits(self.h, seq, out.ctypes.data_as(C.c_void_p)), "batch_logits")
         return out
+
+    def seq_steps(self, seq, tokens, n_first, steps):
+        """steps n_first .. n_first + steps - 1 of ONE sequence on its own single-sequence decoder (same caches as the shared one)"""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        self._ck(self.host._bseqsteps(self.h, seq, tokens.ctypes.data_as(C.c_void_p), len(tokens), n_first, steps), "batch_seq_steps")
+
+    def kv_info(self):
+        """(head-major K / V shadows kept, sequence imports launched so far, import launches) of the shared decoder"""
+        hm, imp, lau = C.c_int(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        self._ck(self.host._bkvinfo(self.h, C.byref(hm), C.byref(imp), C.byref(lau)), "batch_kv_info")
+        return bool(hm.value), imp.value, lau.value
 
     def time_family(self, family, n, reps=20):
         us, cnt = C.c_double(0.0), C.c_int(0)
