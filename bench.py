@@ -366,8 +366,60 @@ class StubBatch:
         return got, {"prompt_tokens": float(sum(len(p) for p in prompts)), "new_tokens": float(sum(new)), "steps": float(max(new, default=0)),
                      "admissions": float(len(prompts)), "prefill_s": 0.0, "decode_s": 0.0}
 
+    # (the batched-decode leg of N > 1: a step of S sequences sleeps like a wide step, higher ranks slower)
+    step_s = 0.004
+
+    def load_synthetic(self, seed):
+        pass
+
+    def prefill(self, seq, tokens, want=True):
+        return None
+
+    def decode_begin(self, seq, tokens):
+        pass
+
+    def decode_steps(self, n_first, count, use_graph=True):
+        time.sleep(self.step_s * count * (1.0 + 0.25 * int(os.environ.get("RANK", "0"))))
+
     def close(self):
         pass
+
+
+def batched_decode(batch, S, K, make_tokens, rep, rank, world, dist, device, sync):
+    """N > 1, the batched counterpart of `value`: EVERY replica steps its own decoder of S sequences (lanes of 128 rows) K times,
+    the steps ending at n = N_CTX -- the same barrier-bracketed region as the batch-1 steps (MAX elapsed over ranks, tokens
+    summed), and rank 0's rate over the same steps with the other GPUs idle at a barrier as the denominator of the efficiency.
+    One GPU does ~40 x the tokens per second here that it does at batch 1, which is why this, not `value`, is the number a
+    deployment of the 8 GPUs would quote; `value` stays BASELINE.json's metric."""
+    n0 = N_CTX - K + 1
+    for q in range(S):
+        toks = make_tokens(N_CTX, 1000 + q + S * rank)
+        if n0 > 1:
+            batch.prefill(q, toks[:n0 - 1], want=False)          # every sequence's context by ONE prompt call (batched row matrix)
+        batch.decode_begin(q, toks)
+    batch.decode_steps(n0, min(4, K), True)                      # untimed: captures the four-step graph
+    sync()
+
+    def run():
+        batch.decode_steps(n0, K, True)
+        return S * K
+
+    solo = None
+    if dist is not None:
+        dist.barrier()
+        if rank == 0:
+            dt0, k0 = rep.timed_region(run, sync)
+            solo = k0 / dt0
+        dist.barrier()
+    elapsed, total, per_rank = rep.timed_region(run, sync, dist=dist, device=device, per_rank=True)
+    out = {"streams_per_gpu": S, "steps": K, "tok_s": round(total / elapsed, 1), "ms_per_step": round(elapsed / K * 1e3, 4),
+           "per_rank": [{"rank": r, "tok_s": round(k / e, 1), "ms_per_step": round(e / K * 1e3, 4)} for r, (e, k) in enumerate(per_rank)],
+           "note": "every replica steps its own %d sequences (one decoder, lanes of 128 rows) %d times, steps ending at n = %d; "
+                   "tok_s = tokens of all ranks / the slowest rank's time" % (S, K, N_CTX)}
+    if solo is not None:
+        out["solo_rank0_tok_s"] = round(solo, 1)
+        out["efficiency"] = round(total / elapsed / (world * solo), 4)
+    return out
 
 
 def serving_queue(n_prompts, make_tokens, seed=2024):
@@ -397,6 +449,14 @@ def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist,
         box["got"], box["st"] = batch.serve(my_prompts, N_CTX, -1, slice_steps, max_new_each=my_budgets)
         return int(box["st"]["new_tokens"])
 
+    # rank 0's rate on its own shard while the other GPUs idle at a barrier: the denominator of the serving efficiency
+    solo = None
+    if dist is not None:
+        dist.barrier()
+        if rank == 0:
+            dt0, k0 = rep.timed_region(run, sync)
+            solo = k0 / dt0
+        dist.barrier()
     elapsed, new_total, per_rank = rep.timed_region(run, sync, dist=dist, device=device, per_rank=True)
     served = torch.zeros(n_global, dtype=torch.int32, device=device)
     for j, ids in zip(mine, box["got"]):
@@ -417,6 +477,8 @@ def sharded_serving(batch, slots, n_global, make_tokens, rep, rank, world, dist,
             "per_rank": [{"rank": r, "new_tokens": k, "wall_s": round(e, 3), "new_tok_s": round(k / e, 1), "shared_steps": steps[r],
                           "slot_utilisation": round(k / max(steps[r] * slots, 1), 3)} for r, (e, k) in enumerate(per_rank)],
             "every_prompt_served_exactly_once": bool((served == 1).all()),
+            "solo_rank0_new_tok_s": round(solo, 1) if solo else None,
+            "efficiency": round(new_total / elapsed / (world * solo), 4) if solo else None,
             "note": "ONE global queue (prompts of 64..512 ids, 32..224 new ids each; %d per GPU: weak scaling) sharded round-robin "
                     "over the replicas, each rank its shard through its own %d slots (continuous batching, prompts on the library's "
                     "second stream beside slices of %d shared steps); new_tok_s = new ids of all ranks / the slowest rank's wall "
@@ -438,6 +500,21 @@ class Leg:
             self.out[self.name] = {"error": "%s: %s" % (et.__name__, ev)}
             return True
         return False
+
+
+def remove_synth_cache():
+    """the per-node synthetic-weight cache in GTEN_SYNTH_CACHE_DIR (host/tinyllama_model.h load_synthetic_cached): removed by the
+    node's first local rank once its replicas have loaded -- and again on the way out of main(), so that a run that failed
+    half way leaves nothing in /dev/shm (which is memory)"""
+    d = os.environ.get("GTEN_SYNTH_CACHE_DIR")
+    if not d:
+        return
+    import glob
+    for f in glob.glob(os.path.join(d, "gten_synth_*")):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
 
 
 def load_replicas():
@@ -534,6 +611,8 @@ def main(argv=None):
     finally:
         if dist is not None and dist.is_initialized():
             dist.destroy_process_group()
+        if local_rank == 0:
+            remove_synth_cache()            # (a run that failed before the replicas were done with the shared weights: nothing stays behind)
 
 
 def worker(args, rank, local_rank, world, dist):
@@ -673,19 +752,43 @@ def worker(args, rank, local_rank, world, dist):
                 sbatch.close()
             except Exception:                        # noqa: BLE001
                 pass
+    # N > 1: the batched decode step on every replica (one decoder of 256 sequences per GPU), same bracketing as `value`
+    batched = None
+    if dist is not None and world > 1 and fused and (args.serve_slots or args.wide_streams) > 1 and not args.brief:
+        S = 256 if not stub else 8
+        bbatch, err = None, None
+        try:
+            if stub:
+                bbatch = StubBatch()
+                make_tokens_b = lambda n, j: np.random.default_rng(rep_seed(555, j)).integers(3, 31993, n).astype(np.int32)
+            else:
+                bbatch = host.batch(cfg, S)
+                bbatch.load_synthetic(args.seed)
+                make_tokens_b = lambda n, j: host.synthetic_tokens(n, seed=rep_seed(12345, j))
+        except Exception as e:                       # noqa: BLE001 -- recorded below
+            err = "%s: %s" % (type(e).__name__, e)
+        okf = torch.tensor([0.0 if err else 1.0], device=ddev) if ddev else torch.tensor([0.0 if err else 1.0])
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if float(okf.item()) < 0.5:
+            batched = {"error": err or "another rank could not set the leg up"}
+        else:
+            try:
+                batched = batched_decode(bbatch, S, min(K, 32), make_tokens_b, rep, rank, world, dist, ddev, sync)
+            except Exception as e:                   # noqa: BLE001
+                batched = {"error": "%s: %s" % (type(e).__name__, e)}
+        if bbatch is not None:
+            try:
+                bbatch.close()
+            except Exception:                        # noqa: BLE001
+                pass
     # the replicas are done with each other: every rank leaves the process group here (rank 0 goes on alone with the
     # roofline / CPU-baseline legs, the others exit and free their host cores)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-        if rank == 0 and os.environ.get("GTEN_SYNTH_CACHE_DIR"):          # every replica has read the shared weights by now
-            import glob
-            for f in glob.glob(os.path.join(os.environ["GTEN_SYNTH_CACHE_DIR"], "gten_synth_s*")):
-                try:
-                    os.remove(f)
-                except OSError:
-                    pass
-            os.environ.pop("GTEN_SYNTH_CACHE_DIR", None)                  # rank 0's later models generate their own
+        if local_rank == 0:                                               # every replica of this node has read the shared weights by now
+            remove_synth_cache()
+        os.environ.pop("GTEN_SYNTH_CACHE_DIR", None)                      # rank 0's later models generate their own
     if rank != 0:
         model.close()
         return 0
@@ -776,6 +879,15 @@ def worker(args, rank, local_rank, world, dist):
                                   "barrier, same run); value = tokens of all ranks / the slowest rank's time")
     if sharded is not None:
         out["sharded_serving"] = sharded
+    if batched is not None:
+        out["batched_decode"] = batched
+    if world > 1:
+        # what N GPUs are FOR in this design, at the top level beside `value` (which stays BASELINE.json's batch-1 metric): the
+        # aggregate of the batched step and of the sharded serving queue, each with its own efficiency against rank 0 alone
+        out["batched_tok_s"] = (batched or {}).get("tok_s")
+        out["batched_efficiency"] = (batched or {}).get("efficiency")
+        out["serving_new_tok_s"] = (sharded or {}).get("new_tok_s")
+        out["serving_efficiency"] = (sharded or {}).get("efficiency")
     if args.rehearse_one_gpu and world > 1:
         out["metric"] = "REHEARSAL (all %d replicas share GPU 0): " % world + out["metric"]
     if stub:
@@ -802,7 +914,15 @@ def worker(args, rank, local_rank, world, dist):
     # secondary: the same K steps as ONE persistent launch per step (csrc/gten_decode_persist.h: granule hand-offs instead of 113
     # launch boundaries; the same bytes, tests/test_persist_gpu.py) -- measured slower than the launch chain on MI355X, reported
     # beside `value`, never in it
+    persist_built = False
     if secondary and fused and args.mode == "q4" and use_graph:
+        try:
+            hip.set_decode_persistent(True)          # (refused by a library built without -DGTEN_WITH_PERSIST=1: the product build)
+            hip.set_decode_persistent(False)
+            persist_built = True
+        except Exception:
+            pass
+    if persist_built:
       with Leg(out, "persistent_step"):
             hip.set_decode_persistent(True)
             try:

@@ -108,11 +108,17 @@ int  gten_host_batch_generate(gten_host_batch* b, const int32_t* prompts, const 
  * next prompt at once while the other slots go on decoding (TinyLlamaBatch::serve, host/tinyllama_model.h; device side:
  * gten_hip_decoder_slot_start / _run / _slot_ids).  `slice` = shared steps between two looks at the results; max_new > 0
  * additionally bounds the ids generated per prompt (max_new_each, when not NULL: prompt j's own bound).
- * out is [n_prompts][max(max_tokens, max_prompt)] (prompt + new ids), n_total [n_prompts]; stats (may be NULL) receives
- * EIGHT doubles: {prompt tokens, new tokens, shared steps, admissions, seconds in prompt processing, seconds in shared steps,
- * lane-steps (shared steps x the lanes each of them ran: a lane without a live slot sits a run out), slots per lane}. */
+ * out is [n_prompts][max(max_tokens, max_prompt)] (prompt + new ids), n_total [n_prompts]; stats (may be NULL) receives SIX
+ * doubles: {prompt tokens, new tokens, shared steps, admissions, seconds in prompt processing, seconds in shared steps} -- the
+ * list this entry point was first published with, and it stays six. */
 int  gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
                            int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats);
+/* ... the same with the caller saying how many doubles `stats` holds: exactly n_stats are written (zeros past the list), so the
+ * list can grow without overrunning an older caller.  In order: the six above, lane-steps (shared steps x the lanes each of them
+ * ran: a lane without a live slot sits a run out), slots per lane, sequences moved between lanes in the tail of the queue. */
+int  gten_host_batch_serve2(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
+                            int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats,
+                            int n_stats);
 /* tests: k > 0 fixes the admission schedule of gten_host_batch_serve -- exactly k prompts are processed beside every slice
  * (as far as free slots and the queue allow) instead of as many as fit while it runs; 0 restores the default */
 int  gten_host_batch_set_serve_schedule(gten_host_batch* b, int k);

@@ -106,6 +106,29 @@ def test_one_global_prompt_queue_is_sharded_over_the_replicas(n):
     assert r["value"] > 0 and r["config"]["parallelism"] == f"replicas x{n}"        # the batch-1 rate is still the headline
 
 
+@pytest.mark.parametrize("n", [2, 8])
+def test_batched_aggregates_sit_at_the_top_level_with_their_own_efficiency(n):
+    """round-4 verdict: at N GPUs `value` is N x batch-1 (BASELINE.json's metric) while one GPU does ~40 x that batched -- the N > 1
+    line carries the aggregate of the batched step (every replica its own 256 sequences) and of the sharded serving queue at the
+    top level, each with an efficiency against rank 0 alone, measured in the same run.  World 8 is the driver's SCALE run."""
+    p = run_bench("--gpus", str(n), "--serve", "16", timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = result_line(p)
+    assert r["n_gpus"] == n and len(r["per_rank"]) == n
+    bd, sv = r["batched_decode"], r["sharded_serving"]
+    assert [x["rank"] for x in bd["per_rank"]] == list(range(n)) and bd["steps"] == 12
+    assert r["batched_tok_s"] == bd["tok_s"] > 0 and r["batched_efficiency"] == bd["efficiency"]
+    assert r["serving_new_tok_s"] == sv["new_tok_s"] > 0 and r["serving_efficiency"] == sv["efficiency"]
+    # tokens of all ranks / the slowest rank's time; the stub's higher ranks are slower, so the efficiency is below 1 and above
+    # the slowest rank's share
+    rates = [x["tok_s"] for x in bd["per_rank"]]
+    assert min(rates) * n <= bd["tok_s"] * 1.03 and bd["tok_s"] <= sum(rates) * 1.03
+    assert abs(bd["efficiency"] - bd["tok_s"] / (n * bd["solo_rank0_tok_s"])) < 2e-3 and 0.2 < bd["efficiency"] <= 1.1
+    assert abs(sv["efficiency"] - sv["new_tok_s"] / (n * sv["solo_rank0_new_tok_s"])) < 2e-3 and 0.05 < sv["efficiency"] <= 1.2
+    assert sv["every_prompt_served_exactly_once"] is True and sv["prompts_per_rank"] == [16] * n
+    assert r["value"] > 0 and r["efficiency"] > 0                                      # the batch-1 headline and its efficiency stay
+
+
 def test_a_lost_request_is_reported():
     p = run_bench("--gpus", "2", "--serve", "24", env={"GTEN_BENCH_STUB_DROP_RANK": "1"})
     assert p.returncode == 0, p.stderr[-2000:]
@@ -115,7 +138,8 @@ def test_a_lost_request_is_reported():
 def test_brief_runs_skip_the_sharded_queue():
     p = run_bench("--gpus", "2", "--brief")
     assert p.returncode == 0, p.stderr[-2000:]
-    assert "sharded_serving" not in result_line(p)
+    r = result_line(p)
+    assert "sharded_serving" not in r and "batched_decode" not in r
 
 
 def test_shards_partition_the_queue():

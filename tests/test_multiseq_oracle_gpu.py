@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from gpu_common import hip  # noqa: F401
+from gpu_common import hip, record_margin  # noqa: F401
 from __graft_entry__ import load_package
 from helpers import MODES, Q4, Q8, tiny_config
 from test_golden_gpu import band
@@ -206,6 +206,8 @@ def test_wide_path_long_context_probe(hip, full_golden, extra_golden, name, wd, 
             rms, mx = float(np.sqrt((d * d).mean())), float(np.abs(d).max())
             print(f"{name} S={S} slot {q} n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} "
                   f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} scalar {int(g[f'long.{name}.n{n}.top_ids.scalar'][0])} (gap {gap:.3f})")
+            if q == 0:
+                record_margin(f"{name} wide S={S} n={n}", rms, own_rms, mx)
             if name == "f16":
                 assert mx <= 0.03 * max(std / 0.91, 1.0), (q, n, mx)
                 assert int(np.argmax(lg)) == int(ids[0]) or gap < 0.03, (q, n, gap)

@@ -14,6 +14,19 @@ from test_model_gpu import check_logits, host_cfg
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_persistent_step(hip):
+    """round 5: the persistent step (0.90 x the launch chain, HISTORY.md) is compiled only with -DGTEN_WITH_PERSIST=1
+    (GTEN_HIP_EXTRA_FLAGS="-DGTEN_WITH_PERSIST=1" python -m pytest tests/test_persist_gpu.py); the product library refuses
+    gten_hip_set_decode_persistent(1)"""
+    pkg = load_package()
+    try:
+        hip.set_decode_persistent(True)
+    except pkg.GtenHipError:
+        pytest.skip("libgten_hip.so was built without the persistent step (-DGTEN_WITH_PERSIST=1)")
+    hip.set_decode_persistent(False)
+
+
 def _pair(hip, host, cfg, weights=None, seed=1234):
     """(persistent, chain) models on the same weights; the launch choice is made when the decoder is created"""
     out = []

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from gpu_common import hip  # noqa: F401
+from gpu_common import hip, record_margin  # noqa: F401
 from __graft_entry__ import load_package
 from helpers import MODES
 from test_golden_gpu import band
@@ -103,6 +103,7 @@ def test_long_context_probe_f16_q8(hip, extra, name, wd, ad):
         gap = float(g[f"long.{name}.n{n}.top_logits"][0] - g[f"long.{name}.n{n}.top_logits"][1])
         print(f"{name} n={n}: rms {rms:.4f} (reference's own spread {own_rms:.4f}) max {mx:.4f} (std {std:.3f}) "
               f"top1 {int(np.argmax(lg))} ref avx {int(ids[0])} (gap {gap:.3f})")
+        record_margin(f"{name} fused step n={n}", rms, own_rms, mx)
         if name == "f16":
             assert mx <= 0.03 * max(std / 0.91, 1.0), (n, mx)
             assert int(np.argmax(lg)) == int(ids[0]) or gap < 0.03, (n, gap)

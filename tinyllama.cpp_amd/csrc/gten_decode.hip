@@ -265,8 +265,10 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     constexpr size_t NW = (ADT == GTEN_Q8) ? 17 : 32;
     const dim3 grid(n_seq, t.n_chunks, t.n_kv);
     if constexpr (ADT == GTEN_Q8) if (grouped_mm(t, n_seq) && t.hm_k) {
-        // head-major shadows: one wave per (sequence, kv head, chunk)
-        DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_hm<GRP>), dim3(n_seq * t.n_chunks * t.n_kv), dim3(64), 1024, t, n_seq);
+        // head-major shadows: one wave per (sequence, kv head, chunk), HM_WAVES consecutive chunks per workgroup
+        const int n_cq = (t.n_chunks + HM_WAVES - 1) / HM_WAVES;
+        if (n_seq >= 128) DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_hm<GRP, true>), dim3(n_seq * n_cq * t.n_kv), dim3(64 * HM_WAVES), 2048, t, n_seq, n_cq);
+        else DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_hm<GRP, false>), dim3(n_seq * n_cq * t.n_kv), dim3(64 * HM_WAVES), 2048, t, n_seq, n_cq);
         return 0;
     }
     if constexpr (ADT == GTEN_Q8) if (grouped_mm(t, n_seq)) {
@@ -990,7 +992,23 @@ static int enqueue_multi(gten_hip_decoder* dc, int lane)
 }
 
 // one step of one lane (a decoder of up to 64 sequences has the single lane 0)
+// The batch-1 step as ONE persistent launch (round 4: built, bit-identical to the launch chain, 0.90 x its speed -- HISTORY.md):
+// compiled only with -DGTEN_WITH_PERSIST=1 (GTEN_HIP_EXTRA_FLAGS for tinyllama.cpp_amd/build.py); the product library
+// answers gten_hip_set_decode_persistent(1) with an error and runs the launch chain.
+#ifndef GTEN_WITH_PERSIST
+#define GTEN_WITH_PERSIST 0
+#endif
+#if GTEN_WITH_PERSIST
 #include "gten_decode_persist.h"
+#else
+struct PersistState {};
+static bool g_persist_on = false;
+extern "C" int gten_hip_set_decode_persistent(int on)
+{
+    if (on) return fail(-4, "set_decode_persistent: this library was built without the persistent step (-DGTEN_WITH_PERSIST=1, HISTORY.md)");
+    return 0;
+}
+#endif
 
 static int persist_prepare(gten_hip_decoder* dc);
 
@@ -999,10 +1017,12 @@ static int enqueue_lane(gten_hip_decoder* dc, int lane)
     g_exact_now = dc->exact;
     // single sequence, Q8 activations: the whole step as one persistent launch (a family-restricted timing replay wants
     // the launch chain's kernels)
+#if GTEN_WITH_PERSIST
     if (dc->persist_on && dc->n_seq == 1 && !dc->exact && (g_only_family < 0 || g_only_family == KT_DEC_PERSIST)) {
         if (int rc = persist_prepare(dc)) return rc;
         if (dc->persist) return persist_launch<GTEN_Q4>(dc->persist);
     }
+#endif
     if (dc->n_seq > 1) {
         switch (dc->d.wdtype) {
         case GTEN_F16: return enqueue_multi<GTEN_F16>(dc, lane);
@@ -1212,10 +1232,16 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
 }
 
 // ---- the persistent step's state (gten_decode_persist.h): per-layer pointer table, granule buffers, control words
+#if GTEN_WITH_PERSIST
 static int g_cu_count = -1;
 static int persist_prepare(gten_hip_decoder* dc)
 {
     if (dc->persist) return 0;
+    // ONE live persistent decoder per device: the kernel holds 89 728 bytes of LDS and 512 threads, so only one of its workgroups
+    // fits a CU and its grid takes every CU -- two such grids on two streams would each hold part of the chip and poll for
+    // workgroups that can never be scheduled (every poll then runs into its spin limit and aborts the step).  A second decoder
+    // keeps the launch chain.
+    if (!g_persist_all.empty()) { dc->persist_on = false; return 0; }
     if (g_cu_count < 0) {
         int dev = 0;
         GTR_CHECK(hipGetDevice(&dev));
@@ -1279,6 +1305,10 @@ static hipError_t persist_free(gten_hip_decoder* dc)
     dc->persist = nullptr;
     return first;
 }
+#else
+static int persist_prepare(gten_hip_decoder* dc) { dc->persist_on = false; return 0; }
+static hipError_t persist_free(gten_hip_decoder*) { return hipSuccess; }
+#endif
 
 extern "C" {
 
@@ -1901,6 +1931,21 @@ int gten_hip_decoder_time_family(gten_hip_decoder* dc, int family, int n, int re
     return 0;
 }
 
+// a persistent step that gave up (a poll ran into its spin limit) leaves stale ids and logits behind: every read of a result says so
+static int persist_aborted(gten_hip_decoder* dc)
+{
+#if GTEN_WITH_PERSIST
+    if (dc->persist) {
+        unsigned code = 0;
+        GTR_CHECK(hipMemcpy(&code, dc->persist->ctl + 1, 4, hipMemcpyDeviceToHost));
+        if (code) return fail(-5, "decoder: the persistent step aborted (code %u): results are invalid; gten_hip_persist_status clears the state", code);
+    }
+#else
+    (void)dc;
+#endif
+    return 0;
+}
+
 /* the persistent step (gten_decode_persist.h), over every live decoder of the process: how many run it, how many of its
  * launches were enqueued so far, the abort code of a poll that gave up (0 = none; cleared by the call -- the step's results
  * are invalid), and workgroup 0's phase stamps of the newest such decoder (10 ns ticks; GTEN_HIP_PERSIST_STAMPS=1 at its
@@ -1910,26 +1955,33 @@ int gten_hip_persist_status(int* n_decoders, unsigned long long* launches, unsig
     GTR_NEED_INIT();
     GTR_REQUIRE(n_decoders && launches && abort_code, "persist_status: null argument");
     GTR_CHECK(hipStreamSynchronize(stream()));
+    *n_decoders = 0;
+    *launches = 0;
+    *abort_code = 0;
+    if (stamps_host && n_stamps > 0)
+        for (int i = 0; i < n_stamps; i++) stamps_host[i] = 0;
+#if GTEN_WITH_PERSIST
     *n_decoders = (int)g_persist_all.size();
     *launches = g_persist_launches;
-    *abort_code = 0;
     for (PersistState* ps : g_persist_all) {
         unsigned ctl[2];
         GTR_CHECK(hipMemcpy(ctl, ps->ctl, 8, hipMemcpyDeviceToHost));
         if (ctl[1]) {
             *abort_code = ctl[1];
-            const unsigned z = 0;
-            GTR_CHECK(hipMemcpy(ps->ctl + 1, &z, 4, hipMemcpyHostToDevice));
+            // the aborted step never bumped the epoch, and the granules it did publish carry exactly the tags the next launch
+            // would wait for: clear the abort word AND move to the next epoch, so nothing of the partial step can be accepted
+            const unsigned next[2] = {ctl[0] + 1u, 0u};
+            GTR_CHECK(hipMemcpy(ps->ctl, next, 8, hipMemcpyHostToDevice));
         }
     }
     if (stamps_host && n_stamps > 0) {
-        for (int i = 0; i < n_stamps; i++) stamps_host[i] = 0;
         for (auto it = g_persist_all.rbegin(); it != g_persist_all.rend(); ++it)
             if ((*it)->stamps) {
                 GTR_CHECK(hipMemcpy(stamps_host, (*it)->stamps, (size_t)std::min((*it)->n_stamps, n_stamps) * 4, hipMemcpyDeviceToHost));
                 break;
             }
     }
+#endif
     return 0;
 }
 
@@ -1958,7 +2010,7 @@ int gten_hip_decoder_result_seq(gten_hip_decoder* dc, int seq, int n, int32_t* a
     GTR_REQUIRE(seq >= 0 && seq < dc->n_seq, "decoder_result: sequence %d outside [0, %d)", seq, dc->n_seq);
     GTR_CHECK(hipMemcpyAsync(argmax_host, dc->result + (size_t)seq * (dc->d.max_ctx + 2) + n, 4, hipMemcpyDeviceToHost, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
-    return 0;
+    return persist_aborted(dc);
 }
 
 int gten_hip_decoder_logits_seq(gten_hip_decoder* dc, int seq, float* logits_host)
@@ -1968,7 +2020,7 @@ int gten_hip_decoder_logits_seq(gten_hip_decoder* dc, int seq, float* logits_hos
     const float* src = dc->n_seq > 1 ? dc->logits_m + (size_t)seq * dc->d.n_vocab : dc->d.logits;
     GTR_CHECK(hipMemcpyAsync(logits_host, src, (size_t)dc->d.n_vocab * 4, hipMemcpyDeviceToHost, stream()));
     GTR_CHECK(hipStreamSynchronize(stream()));
-    return 0;
+    return persist_aborted(dc);
 }
 
 } // extern "C"

@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void k_kv_import_hm(const HmImportList items, 
     }
     {
         const unsigned p = threadIdx.x;
-        const uint16_t d0 = *(const uint16_t*)(rb + p * 68u), d1 = *(const uint16_t*)(rb + p * 68u + 34u);
+        // (rows the sequence does not have yet hold whatever the cache holds: their deltas become 0, so that the attention kernel
+        //  may multiply a zero probability by them without a select -- the appends of later steps write real, finite deltas)
+        const bool known = c0 + (int)p < rows;
+        const uint16_t d0 = known ? *(const uint16_t*)(rb + p * 68u) : (uint16_t)0, d1 = known ? *(const uint16_t*)(rb + p * 68u + 34u) : (uint16_t)0;
         if (kv == 0) { *(uint16_t*)(dst + hm_k_d_off(p, 0)) = d0; *(uint16_t*)(dst + hm_k_d_off(p, 1)) = d1; }
         else { *(uint16_t*)(dst + hm_v_d_off(p, 0)) = d0; *(uint16_t*)(dst + hm_v_d_off(p, 1)) = d1; }
     }
@@ -148,65 +151,86 @@ __device__ __forceinline__ void hm_bytes_to_h4(unsigned b4, unsigned& lo, unsign
     hi = __builtin_bit_cast(unsigned, __builtin_bit_cast(hm_h2, x1) - k);
 }
 
-template <int GRP>
-__global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, const int n_seq)
+// Measured on the 256- / 64-sequence step (ms per step, two runs each, one box): waves per workgroup 4 | 2 and the
+// K / V requests nontemporal or not -- 4: 3.145 3.155 / 1.506 1.514; 2: 3.201 3.192 / 1.501 1.497; 4 + nt: 3.136 3.106 / 1.539 1.538;
+// 2 + nt: 3.105 3.110 / 1.516 1.511; one wave per workgroup (every wave prepares all eight head vectors) 3.153 / 1.515, two waves
+// per SIMD instead of three 3.161 / 1.517.  So: pairs of chunks per workgroup, and the K / V stream -- read once per step, 6 GB
+// at 256 sequences, far beyond the memory-side cache -- nontemporal from 128 rows per lane up (it then stops displacing the
+// weights the other lane is about to read), default policy below.
+#ifndef HM_WAVES
+#define HM_WAVES 2            // waves per workgroup = consecutive chunks of one (sequence, kv head) that share the head vectors
+#endif
+#define HM_LD(p) (NT ? __builtin_nontemporal_load(p) : *(p))
+
+template <int GRP, bool NT>
+__global__ __launch_bounds__(64 * HM_WAVES) HM_OCC void k_dec_attn_hm(const AttnArgs a0, const int n_seq, const int n_cq)
 {
-    constexpr int dh = 64;
-    // id -> (kv head, sequence, chunk): the live workgroups of short contexts (chunk 0) are the first ids, spread over all XCDs
-    const int g = blockIdx.x % a0.n_kv, sci = blockIdx.x / a0.n_kv, seq = sci % n_seq, chunk = sci / n_seq, c0 = chunk * DEC_CHUNK;
+    constexpr int dh = 64, NWV = HM_WAVES;
+    // id -> (kv head, sequence, chunk quad): the live workgroups of short contexts (quad 0) are the first ids, spread over all XCDs.
+    // Wave w of the workgroup owns chunk NWV cq + w; the group's head vectors are prepared ONCE per workgroup (wave w: heads w,
+    // w + NWV, ...) and shared through LDS -- one barrier at the start, none afterwards.
+    const int g = blockIdx.x % a0.n_kv, sci = blockIdx.x / a0.n_kv, seq = sci % n_seq, cq = sci / n_seq;
+    const int w = threadIdx.x >> 6, t = threadIdx.x & 63, lc = t & 15, lq = t >> 4, hd = lc & 7, hi = lc >> 3;
+    const int chunk = NWV * cq + w, c0 = chunk * DEC_CHUNK;
     const AttnArgs a = attn_for_seq(a0, seq);
     const int n = a.step->n, pos = n - 1;
-    if (c0 >= n) return;
+    if (NWV * cq * DEC_CHUNK >= n) return;                        // (the whole workgroup)
+    const bool alive = c0 < n;                                    // (uniform per wave)
     // cached positions of this chunk: [c0, c0 + len); position `pos` itself comes from the chip when it lies in this chunk
     const int len = min(DEC_CHUNK, pos - c0);
-    const bool has_new = pos < c0 + DEC_CHUNK;                    // (uniform per wave)
-    const int t = threadIdx.x, lc = t & 15, lq = t >> 4, hd = lc & 7, hi = lc >> 3;
+    const bool has_new = alive && pos < c0 + DEC_CHUNK;
     const int kv_dim = a.n_kv * dh;
 
-    int8_t* qi8 = (int8_t*)g_smem;                                // [8][64] head vectors
-    int8_t* ki8 = qi8 + 8 * dh;                                   // 64: the new K row
-    int8_t* vi8 = ki8 + dh;                                       // 64: the new V row
-    float* qd = (float*)(vi8 + dh);                               // [8][2]
-    float* kd = qd + 16;                                          // 8: new k deltas, new v deltas
-    uint16_t* d16 = (uint16_t*)(kd + 8);                          // [8 + 2][4] halves
+    int8_t* qi8 = (int8_t*)g_smem;                                // [8][64] head vectors (shared)
+    float* qd = (float*)(qi8 + 8 * dh);                           // [8][2]
+    uint16_t* d16 = (uint16_t*)(qd + 16);                         // [8][4] halves
+    int8_t* ki8 = (int8_t*)(d16 + 32) + w * 192;                  // per wave: the new K row [64], the new V row [64],
+    int8_t* vi8 = ki8 + dh;                                       //           their deltas as floats [8] and halves [2][4]
+    float* kd = (float*)(vi8 + dh);
+    uint16_t* kvd16 = (uint16_t*)(kd + 8);
 
-    // ---- requests: the raw projections, the rotation, then the chunk's K tiles and deltas (tiles past the context
-    //      re-read the last live tile: no traffic, no branch around a request)
-    float qraw[GRP];
+    // ---- requests: this wave's share of the raw projections, the rotation, then the chunk's K tiles and deltas (tiles
+    //      past the context re-read the last live tile: no traffic, no branch around a request)
+    constexpr int NJ = (GRP + NWV - 1) / NWV;
+    float qraw[NJ];
 #pragma unroll
-    for (int j = 0; j < GRP; j++) qraw[j] = a.qkv_raw[(g * GRP + j) * dh + t];
+    for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(w + NWV * jj, GRP - 1)) * dh + t];
     float kraw = a.qkv_raw[a.n_embd + g * dh + t], vraw = a.qkv_raw[a.n_embd + kv_dim + g * dh + t];
     if (a.qkv_plane) {                                            // second K-split plane of the projections (uniform)
 #pragma unroll
-        for (int j = 0; j < GRP; j++) qraw[j] += a.qkv_raw[a.qkv_plane + (g * GRP + j) * dh + t];
+        for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_raw[a.qkv_plane + (g * GRP + min(w + NWV * jj, GRP - 1)) * dh + t];
         kraw += a.qkv_raw[a.qkv_plane + a.n_embd + g * dh + t];
         vraw += a.qkv_raw[a.qkv_plane + a.n_embd + kv_dim + g * dh + t];
     }
     const float2 rot = a.rope_now[t & 31];
-    const uint8_t* kc = a.hm_k + (size_t)(g * a.n_chunks + chunk) * HM_CHUNK_BYTES;
+    const uint8_t* kc = a.hm_k + (size_t)(g * a.n_chunks + (alive ? chunk : 0)) * HM_CHUNK_BYTES;
     const uint8_t* vc = kc + a.hm_cache_bytes;
     const int Tl = max(len - 1, 0) >> 4, Sl = Tl >> 1;
     typedef int hm_v4i __attribute__((ext_vector_type(4)));
     typedef const hm_v4i __attribute__((address_space(1)))* gmem_v4i;
     hm_v4i ka[16], kdw[8];
-    {
+    if (alive) {
         const gmem_v4i kq = (gmem_v4i)(uintptr_t)(kc + t * 16);
 #pragma unroll
-        for (int T = 0; T < 16; T++) ka[T] = kq[min(T, Tl) * 64];
+        for (int T = 0; T < 16; T++) ka[T] = HM_LD(kq + min(T, Tl) * 64);
         const gmem_v4i kdp = (gmem_v4i)(uintptr_t)(kc + HM_Q_BYTES + hi * 512 + lq * 128);
 #pragma unroll
-        for (int j = 0; j < 8; j++) kdw[j] = kdp[j];
+        for (int j = 0; j < 8; j++) kdw[j] = HM_LD(kdp + j);
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- head vectors of the group (write -> rope -> write, gten/modules.cpp:196-201), the new K / V rows
+    // ---- head vectors of the group (write -> rope -> write, gten/modules.cpp:196-201): this wave's share
 #pragma unroll
-    for (int j = 0; j < GRP; j++) head_prep_cs(qraw[j], true, true, rot, dh, GTEN_Q8, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
-    if (has_new) {
-        head_prep_cs(kraw, true, true, rot, dh, GTEN_Q8, ki8, kd, d16 + 4 * GRP);
-        head_prep_cs(vraw, true, false, rot, dh, GTEN_Q8, vi8, kd + 4, d16 + 4 * (GRP + 1));
+    for (int jj = 0; jj < NJ; jj++) {
+        const int j = w + NWV * jj;
+        if (j < GRP) head_prep_cs(qraw[jj], true, true, rot, dh, GTEN_Q8, qi8 + j * dh, qd + 2 * j, d16 + 4 * j);
     }
-    __syncthreads();                                              // (one wave: orders its own LDS traffic)
+    if (has_new) {
+        head_prep_cs(kraw, true, true, rot, dh, GTEN_Q8, ki8, kd, kvd16);
+        head_prep_cs(vraw, true, false, rot, dh, GTEN_Q8, vi8, kd + 4, kvd16 + 4);
+    }
+    __syncthreads();
+    if (!alive) return;
     // B operand: column lc = head hd's block hi -- its 16 bytes where the lane's K bytes belong to that block, else zero
     const bool bsel = ((hi == 0) == (lq < 2)) && hd < GRP;
     hm_v4i qb = *(const hm_v4i*)(qi8 + hd * dh + 16 * lq);
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, co
             store_global<uint8_t>(vcw + hm_v_q_off(pn, (unsigned)t), (uint8_t)(vb ^ 0x80u));
             if ((t & 31) == 0) {
                 const unsigned b = (unsigned)t >> 5;
-                const uint16_t kdl = d16[4 * GRP + b], vdl = d16[4 * (GRP + 1) + b];
+                const uint16_t kdl = kvd16[b], vdl = kvd16[4 + b];
                 store_global<uint16_t>(krow + b * GTEN_Q8_BYTES, kdl);
                 store_global<uint16_t>(vrow + b * GTEN_Q8_BYTES, vdl);
                 store_global<uint16_t>(kcw + hm_k_d_off(pn, b), kdl);
@@ -272,10 +296,10 @@ __global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, co
     {
         const gmem_v4i vq = (gmem_v4i)(uintptr_t)(vc + t * 16);
 #pragma unroll
-        for (int s = 0; s < 8; s++) { va[s][0] = vq[min(s, Sl) * 128]; va[s][1] = vq[min(s, Sl) * 128 + 64]; }
+        for (int s = 0; s < 8; s++) { va[s][0] = HM_LD(vq + min(s, Sl) * 128); va[s][1] = HM_LD(vq + min(s, Sl) * 128 + 64); }
         const gmem_v4i vdp = (gmem_v4i)(uintptr_t)(vc + HM_Q_BYTES + (lq * 2 + hi) * 128);
 #pragma unroll
-        for (int s = 0; s < 8; s++) vdw[s] = vdp[s];
+        for (int s = 0; s < 8; s++) vdw[s] = HM_LD(vdp + s);
     }
     // ---- chunk maximum and sum of exponentials per head (hardware exponential, as k_dec_attn_mm_g)
     float M = scn;
@@ -298,34 +322,49 @@ __global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, co
         *(float2*)(a.stats + ((size_t)(g * GRP + hd) * a.n_chunks + chunk) * 2) = make_float2(M, L);
     const float rL = recip_rn(L);
 
-    // ---- per block of 32 positions (tiles 2 s, 2 s + 1): Q8 rounding of the probabilities, the V deltas folded in, p.V
+    // ---- the probabilities and the Q8 scale of every block of 32 positions (tiles 2 s, 2 s + 1): the cross-lane steps of
+    //      the eight blocks side by side (each is a chain of dependent moves with wait states between them)
     const int sn = (int)(pn >> 5);
     const float pnew = en * rL;
+    float am[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        sc[2 * s][0] *= rL; sc[2 * s][1] *= rL; sc[2 * s + 1][0] *= rL; sc[2 * s + 1][1] *= rL;
+        am[s] = fmaxf(fmaxf(sc[2 * s][0], sc[2 * s][1]), fmaxf(sc[2 * s + 1][0], sc[2 * s + 1][1]));
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) am[s] = fmaxf(am[s], hm_ror8(am[s]));
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(am[s]), __float_as_uint(am[s]), false, false);
+        am[s] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(am[s]), __float_as_uint(am[s]), false, false);
+        am[s] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        if (has_new && s == sn) am[s] = fmaxf(am[s], pnew);      // (uniform) the new position's probability joins its block
+    }
     float pnq = 0.f;                                              // the new position's probability as stored (Q8)
     att_f4 acc[4];
 #pragma unroll
     for (int et = 0; et < 4; et++) acc[et] = att_f4{0.f, 0.f, 0.f, 0.f};
+    // ---- per block: Q8 rounding, the V deltas folded in (one fp16 rounding), p.V.  A position past the context has
+    //      probability exactly 0 and a FINITE delta (the import zeroes the deltas of rows it does not know, appends write real
+    //      ones), so its operand is 0 without a select.
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-        float p[4] = {sc[2 * s][0] * rL, sc[2 * s][1] * rL, sc[2 * s + 1][0] * rL, sc[2 * s + 1][1] * rL};
-        float am = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
-        am = fmaxf(am, hm_ror8(am));
-        am = hm_rows_max(am);
-        const bool mine_new = has_new && s == sn;                 // (uniform)
-        if (mine_new) am = fmaxf(am, pnew);
-        const Q8Scale qs = q8_scale_from_absmax(am);
-        if (mine_new) pnq = (float)q8_round(pnew, qs.scale) * qs.ddeq;
+        const Q8Scale qs = q8_scale_from_absmax(am[s]);
+        if (has_new && s == sn) pnq = (float)q8_round(pnew, qs.scale) * qs.ddeq;
         unsigned own[2][2];                                       // [tile][half]: f16 pairs (u = 0, 1)
 #pragma unroll
         for (int tp = 0; tp < 2; tp++) {
             const unsigned d0 = (unsigned)vdw[s][2 * tp], d1 = (unsigned)vdw[s][2 * tp + 1];   // u = 0 | u = 1: (half 0, half 1)
-            const bool l0 = 32 * s + 16 * tp + 4 * lq + 2 * hi < len, l1 = 32 * s + 16 * tp + 4 * lq + 2 * hi + 1 < len;
-            const float q0 = (float)q8_round(p[2 * tp], qs.scale) * qs.ddeq, q1 = (float)q8_round(p[2 * tp + 1], qs.scale) * qs.ddeq;
+            const float q0 = (float)q8_round(sc[2 * s + tp][0], qs.scale) * qs.ddeq, q1 = (float)q8_round(sc[2 * s + tp][1], qs.scale) * qs.ddeq;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const float dv0 = h2f((uint16_t)(h ? d0 >> 16 : d0 & 0xffffu)), dv1 = h2f((uint16_t)(h ? d1 >> 16 : d1 & 0xffffu));
-                const _Float16 a0h = f2hv(l0 ? q0 * dv0 : 0.f), a1h = f2hv(l1 ? q1 * dv1 : 0.f);
-                const hm_h2 pr = {a0h, a1h};
+                const hm_h2 pr = {f2hv(q0 * dv0), f2hv(q1 * dv1)};
                 own[tp][h] = __builtin_bit_cast(unsigned, pr);
             }
         }
@@ -333,17 +372,17 @@ __global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, co
         att_h8 bp[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const unsigned w[4] = {own[0][h], hm_ror8_u(own[0][h]), own[1][h], hm_ror8_u(own[1][h])};
-            __builtin_memcpy(&bp[h], w, 16);
+            const unsigned wv[4] = {own[0][h], hm_ror8_u(own[0][h]), own[1][h], hm_ror8_u(own[1][h])};
+            __builtin_memcpy(&bp[h], wv, 16);
         }
 #pragma unroll
         for (int et = 0; et < 4; et++) {
             const unsigned b0 = (unsigned)va[s][et >> 1][(et & 1) * 2], b1 = (unsigned)va[s][et >> 1][(et & 1) * 2 + 1];
-            unsigned w[4];
-            hm_bytes_to_h4(b0, w[0], w[1]);
-            hm_bytes_to_h4(b1, w[2], w[3]);
+            unsigned wv[4];
+            hm_bytes_to_h4(b0, wv[0], wv[1]);
+            hm_bytes_to_h4(b1, wv[2], wv[3]);
             att_h8 av;
-            __builtin_memcpy(&av, w, 16);
+            __builtin_memcpy(&av, wv, 16);
             acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bp[et >> 1], acc[et], 0, 0, 0);
         }
     }
@@ -351,7 +390,7 @@ __global__ __launch_bounds__(64) HM_OCC void k_dec_attn_hm(const AttnArgs a0, co
     if (has_new) {
 #pragma unroll
         for (int et = 0; et < 4; et++) {
-            const float pv = (float)f2hv(pnq * h2f(d16[4 * (GRP + 1) + (et >> 1)]));
+            const float pv = (float)f2hv(pnq * h2f(kvd16[4 + (et >> 1)]));
             const unsigned vb = *(const unsigned*)(vi8 + 16 * et + 4 * lq);
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[et][i] += pv * (float)(int8_t)((vb >> (8 * i)) & 0xffu);

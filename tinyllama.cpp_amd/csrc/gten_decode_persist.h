@@ -34,8 +34,10 @@
 // Arithmetic, rounding points and reduction trees are those of k_dec_gemv8 / k_dec_attn_one64 / k_dec_argmax, so the
 // step's bytes (K / V rows, logits, ids) are those of the launch chain (tests/test_decode_gpu.py).
 //
-// Residency: the grid (one workgroup per CU) must be co-resident; the kernel uses < 64 KB of LDS and 512 threads, so two
-// fit a CU and a busy neighbour stream only delays it.  gten_hip_set_decode_persistent(0) keeps the launch chain.
+// Residency: the grid (one workgroup per CU) must be co-resident.  The kernel holds 89 728 bytes of LDS (persist_smem()) and
+// 512 threads, so ONE of its workgroups fits a CU and its grid takes every CU: a second persistent decoder on another stream
+// could never be scheduled beside it, so the library keeps one per device (persist_prepare: the next decoder runs the launch
+// chain) and other kernels only delay it.  gten_hip_set_decode_persistent(0) keeps the launch chain.
 
 typedef unsigned long long pu64;
 typedef __attribute__((address_space(1))) pu64 pgu64;

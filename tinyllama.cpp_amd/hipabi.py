@@ -201,7 +201,8 @@ class GtenHip:
         self._check(self._decode_persistent(1 if on else 0))
 
     def set_lane_skip(self, on):
-        """gten_hip_decoder_run leaves lanes without a live slot out of the step (default) or always takes every lane"""
+        """1: gten_hip_decoder_run leaves lanes without a live slot out of the step; 0 (the library's default: skipping measured
+        slower on the bench's queue): every run takes every lane"""
         self._check(self._lane_skip(1 if on else 0))
 
     def persist_status(self, n_stamps=0):

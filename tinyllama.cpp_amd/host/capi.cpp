@@ -337,10 +337,11 @@ int gten_host_batch_set_serve_ramp(gten_host_batch* b, int percent)
     return 0;
 }
 
-int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
-                          int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats)
+int gten_host_batch_serve2(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
+                           int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats,
+                           int n_stats)
 {
-    if (!prompts || !n_prompt || !out || !n_total || n_prompts <= 0 || max_tokens <= 0 || slice <= 0) return -1;
+    if (!prompts || !n_prompt || !out || !n_total || n_prompts <= 0 || max_tokens <= 0 || slice <= 0 || n_stats < 0) return -1;
     std::vector<std::vector<int32_t>> ps((size_t)n_prompts), res;
     for (int j = 0; j < n_prompts; j++) {
         if (n_prompt[j] <= 0 || n_prompt[j] > max_prompt || n_prompt[j] > b->cfg.max_ctx) return -1;
@@ -353,11 +354,20 @@ int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int3
         n_total[j] = take;
     }
     if (stats) {
-        stats[0] = (double)st.prompt_tokens; stats[1] = (double)st.new_tokens; stats[2] = (double)st.steps;
-        stats[3] = (double)st.admissions; stats[4] = st.prefill_s; stats[5] = st.decode_s;
-        stats[6] = (double)st.lane_steps; stats[7] = (double)st.lane_rows;
+        // (exactly n_stats doubles are written: a caller sized for an older, shorter list stays inside its array)
+        const double all[] = {(double)st.prompt_tokens, (double)st.new_tokens, (double)st.steps, (double)st.admissions, st.prefill_s, st.decode_s,
+                              (double)st.lane_steps, (double)st.lane_rows, (double)st.moved};
+        const int have = (int)(sizeof(all) / sizeof(all[0]));
+        for (int i = 0; i < n_stats; i++) stats[i] = i < have ? all[i] : 0.0;
     }
     return 0;
+}
+
+/* the entry point as first published: SIX doubles (a caller compiled against that header holds double[6]) */
+int gten_host_batch_serve(gten_host_batch* b, const int32_t* prompts, const int32_t* n_prompt, int n_prompts, int max_prompt,
+                          int max_tokens, int eos, int slice, int max_new, const int32_t* max_new_each, int32_t* out, int32_t* n_total, double* stats)
+{
+    return gten_host_batch_serve2(b, prompts, n_prompt, n_prompts, max_prompt, max_tokens, eos, slice, max_new, max_new_each, out, n_total, stats, stats ? 6 : 0);
 }
 
 int gten_host_batch_decode_result(gten_host_batch* b, int seq, int n, int32_t* argmax_out)

@@ -27,6 +27,11 @@
 namespace gten {
 namespace synth {
 
+// Version of everything below that decides a synthetic weight's bytes (generator, quantizers, tensor order): part of the name of
+// the per-node weight cache (TinyLlama::load_synthetic_cached), so that a cache written by another generator is never read.
+// BUMP IT with any such change.
+constexpr int kFormat = 2;
+
 inline uint64_t mix64(uint64_t z)
 {
     z += 0x9e3779b97f4a7c15ull;

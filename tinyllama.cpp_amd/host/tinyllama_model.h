@@ -280,7 +280,7 @@ public:
         size_t total = 0;
         for (int i = 0; i < n_weights(); i++) total += weight(i).nbytes();
         char base[512];
-        std::snprintf(base, sizeof(base), "%s/gten_synth_s%llu_w%d_a%d_e%d_f%d_l%d_v%d_h%d_g%d.bin", dir, (unsigned long long)seed,
+        std::snprintf(base, sizeof(base), "%s/gten_synth_v%d_s%llu_w%d_a%d_e%d_f%d_l%d_v%d_h%d_g%d.bin", dir, synth::kFormat, (unsigned long long)seed,
                       (int)dtype_.wdtype, (int)dtype_.adtype, params.n_embd, params.n_ffn, params.n_layers, params.n_vocab, params.n_heads,
                       params.n_query_groups);
         const std::string path = base, lock = path + ".lock", tmp = path + ".tmp";
@@ -292,6 +292,7 @@ public:
             if (fd < 0) return false;
             if (::flock(fd, LOCK_EX | LOCK_NB) == 0) {
                 if (!ready()) {                                  // (it may have been finished between the check and the lock)
+                    const int omp_before = omp_get_max_threads();
                     if (const char* nt = std::getenv("GTEN_SYNTH_GEN_THREADS")) {
                         const int n = std::atoi(nt);
                         if (n > 0) omp_set_num_threads(n);       // the other replicas only wait: every core for this one
@@ -308,6 +309,7 @@ public:
                     if (f) ok = (std::fclose(f) == 0) && ok;
                     if (ok) std::rename(tmp.c_str(), path.c_str());
                     else std::remove(tmp.c_str());
+                    omp_set_num_threads(omp_before);             // (the generation is over: this replica's share of the cores again)
                     ::flock(fd, LOCK_UN);
                     ::close(fd);
                     return true;
@@ -451,6 +453,9 @@ public:
         for (size_t i = 1; i < seqs_.size(); i++)
             for (int w = 0; w < seqs_[0]->n_weights(); w++) seqs_[i]->weight(w) = seqs_[0]->weight(w);
         pre_.reset();                                        // (the shared prompt matrix aliases the weights too: rebuilt on next use)
+        // the shared decoder holds device pointers to the weights and to every cache set it was ever bound to (the spares among
+        // them): it goes before they do and is rebuilt on next use
+        if (dec_) { GTEN_HIP_OK(gten_hip_decoder_destroy(dec_)); dec_ = nullptr; }
         spares_.clear();                                     // (... and so do the spare cache sets)
         set_kv_.clear();
     }
@@ -662,6 +667,23 @@ public:
         };
         GTEN_HIP_OK(gten_hip_select_stream(0));
         for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_park(dec_, q));
+        // Whatever way this function is left (a failed check ends the process, but an allocation may throw), every slot goes back
+        // to its own sequence's caches: a decoder left bound to spare or foreign sets would read and write the wrong rows in the
+        // decode_step / generate that follows -- and dangle once share_weights() drops the spares.
+        struct Rebind {
+            TinyLlamaBatch* b; int S; bool done = false;
+            void run()
+            {
+                if (done) return;
+                done = true;
+                gten_hip_select_stream(0);
+                for (int q = 0; q < S; q++) {
+                    gten_hip_decoder_slot_park(b->dec_, q);
+                    gten_hip_decoder_slot_bind(b->dec_, q, b->set_kv(q));
+                }
+            }
+            ~Rebind() { run(); }
+        } rebind{this, S};
         // the next prompt of the queue onto a free cache set (stream 1); false when the queue is empty
         auto prepare = [&]() {
             while (next < prompts.size() && !pool.empty()) {
@@ -875,6 +897,7 @@ public:
         // every slot back on its own sequence's caches (all of them are parked now): what follows a serve() -- decode_step,
         // generate -- addresses slot q as sequence q
         for (int q = 0; q < S; q++) GTEN_HIP_OK(gten_hip_decoder_slot_bind(dec_, q, set_kv(q)));
+        rebind.done = true;
         return st;
     }
 

@@ -39,7 +39,7 @@ class GtenHost:
         "gten_host_model_set_fast_decode", "gten_host_model_decode_begin", "gten_host_model_decode_step", "gten_host_model_decode_steps", "gten_host_batch_decode_steps",
         "gten_host_model_decode_result", "gten_host_model_time_family",
         "gten_host_batch_create", "gten_host_batch_free", "gten_host_batch_load_synthetic", "gten_host_batch_set_weight",
-        "gten_host_batch_prefill", "gten_host_batch_prefill_many", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_set_serve_schedule", "gten_host_batch_set_serve_spares", "gten_host_batch_set_serve_ramp", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
+        "gten_host_batch_prefill", "gten_host_batch_prefill_many", "gten_host_batch_generate", "gten_host_batch_serve", "gten_host_batch_serve2", "gten_host_batch_set_serve_schedule", "gten_host_batch_set_serve_spares", "gten_host_batch_set_serve_ramp", "gten_host_batch_decode_begin", "gten_host_batch_decode_step", "gten_host_batch_decode_step_ragged",
         "gten_host_batch_decode_result", "gten_host_batch_logits", "gten_host_batch_time_family", "gten_host_batch_kv_info", "gten_host_batch_seq_steps",
     ]
 
@@ -83,7 +83,7 @@ class GtenHost:
         self._bstep = _sig(L, "gten_host_batch_decode_step", ci, [vp, ci, ci])
         self._bstepr = _sig(L, "gten_host_batch_decode_step_ragged", ci, [vp, vp, ci])
         self._bgen = _sig(L, "gten_host_batch_generate", ci, [vp, vp, vp, ci, ci, ci, vp, vp])
-        self._bserve = _sig(L, "gten_host_batch_serve", ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp])
+        self._bserve = _sig(L, "gten_host_batch_serve2", ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci])
         self._bsched = _sig(L, "gten_host_batch_set_serve_schedule", ci, [vp, ci])
         self._bspares = _sig(L, "gten_host_batch_set_serve_spares", ci, [vp, ci])
         self._bramp = _sig(L, "gten_host_batch_set_serve_ramp", ci, [vp, ci])
@@ -358,13 +358,13 @@ class HostBatch:
             npr[j] = len(p)
         out = np.zeros((len(prompts), width), np.int32)
         tot = np.zeros(len(prompts), np.int32)
-        st = np.zeros(8, np.float64)
+        st = np.zeros(9, np.float64)
         each = None if max_new_each is None else np.ascontiguousarray(max_new_each, dtype=np.int32)
         assert each is None or len(each) == len(prompts)
         self._ck(self.host._bserve(self.h, pr.ctypes.data_as(C.c_void_p), npr.ctypes.data_as(C.c_void_p), len(prompts), mp, max_tokens, eos,
-                                   slice_steps, max_new, None if each is None else each.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)),
+                                   slice_steps, max_new, None if each is None else each.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), tot.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), len(st)),
                  "batch_serve")
-        keys = ("prompt_tokens", "new_tokens", "steps", "admissions", "prefill_s", "decode_s", "lane_steps", "lane_rows")
+        keys = ("prompt_tokens", "new_tokens", "steps", "admissions", "prefill_s", "decode_s", "lane_steps", "lane_rows", "moved")
         return [out[j, : tot[j]].copy() for j in range(len(prompts))], dict(zip(keys, st.tolist()))
 
     def decode_result(self, seq, n):
