@@ -156,7 +156,7 @@ def usable_cpus():
 def csrc_fingerprint():
     """sha256 (16 hex digits) over what the in-tree libgten_hip.so is built from -- the kernel sources (comments and white
     space aside: code_only) AND the compiler flags (build.HIP_FLAGS, HIP_FILE_FLAGS: round 2 changed code generation of every
-    kernel by a flag change alone): what ties profiles/traffic.json (PMC counters collected by tools/collect_profiles.sh) to
+    kernel by a flag change alone): what ties profiles/traffic.json (PMC counters collected by tools/collect_all.sh) to
     the kernels being benched -- the GPU box has no .git, so a hash rather than a commit id"""
     import hashlib
     from __graft_entry__ import load_package
@@ -190,7 +190,7 @@ def measured_traffic(mode, family):
 
 
 def measured_counters(section):
-    """profiles/counters.json (tools/collect_counters.sh: PMC passes of the secondary legs' kernels), or (None, why) when it
+    """profiles/counters.json (tools/collect_all.sh: PMC passes of the secondary legs' kernels), or (None, why) when it
     is absent or was collected on other kernel sources"""
     cpath = os.path.join(ROOT, "profiles", "counters.json")
     if not os.path.exists(cpath):

@@ -733,8 +733,20 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
     const size_t nbs = (size_t)a.d_in / 32 / ks, fr = 16 * (size_t)ft;
     const size_t smem = std::max(fr * nbs * (WT == GTEN_Q4 ? 16 : 32), (size_t)8 * 16 * RT * 64) + fr * nbs * 2;
     GTR_REQUIRE(smem <= 150 * 1024, "decoder: the weight slab of d_in %d does not fit LDS", a.d_in);
-    const dim3 grid((cols + 16 * ft - 1) / (16 * ft), ks);
     const MmvRest rest{a.w[1], a.w[2], a.d_out[1], a.d_out[2], a.plane};
+    // lm_head at eight row tiles (round 5): FOUR feature tiles per workgroup.  Its 1001 two-tile workgroups each pulled the lane's
+    // 512 KB of staged activations through L2 -- 512 MB per launch, which is what its 53 us were; 501 workgroups of 64 features
+    // halve that (the same sums per row: a row's K slices and their order do not depend on the feature tiles beside it).
+    if constexpr (RT == 8 && WT == GTEN_Q4) {
+        if (a.n_mats == 1 && ks == 1 && cols >= 16384 && ppr <= 32 * (MMV_MAXP / 4)) {
+            const size_t smem4 = std::max((size_t)64 * nbs * 16, (size_t)8 * 16 * RT * 64) + 64 * nbs * 2;
+            GTR_REQUIRE(smem4 <= 150 * 1024, "decoder: the weight slab of d_in %d does not fit LDS", a.d_in);
+            DEC_LAUNCH(tag, (k_dec_mmvh<WT, 8, 4, false>), dim3((cols + 63) / 64, 1), dim3(512), smem4, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S,
+                       a.n_mats, rest);
+            return 0;
+        }
+    }
+    const dim3 grid((cols + 16 * ft - 1) / (16 * ft), ks);
     if (ft > 1)
         DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, FTW, false>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
     else
@@ -792,6 +804,7 @@ static int mmvh_prepare()
     MMVH_ATTR(1, 1); MMVH_ATTR(2, 1); MMVH_ATTR(3, 1); MMVH_ATTR(4, 1);
     MMVH_ATTR(1, FTA); MMVH_ATTR(2, FTA); MMVH_ATTR(3, 2); MMVH_ATTR(4, 2);
     MMVH_ATTR(8, 1); MMVH_ATTR(8, 2);
+    if (WT == GTEN_Q4) MMVH_ATTR(8, 4);
 #define MMVH_ATTR_S(RT_) GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_mmvh<WT, RT_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
     MMVH_ATTR_S(1); MMVH_ATTR_S(2); MMVH_ATTR_S(3); MMVH_ATTR_S(4); MMVH_ATTR_S(8);
 #undef MMVH_ATTR_S

@@ -28,41 +28,45 @@ def rows_of(d, counter):
 
 
 def main():
-    d, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r04")
+    d, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r05")
     sys.path.insert(0, ROOT)
     import bench
     out = {"csrc_sha256_16": bench.csrc_fingerprint(),
-           "source": f"tools/collect_counters.sh {tag} (rocprofv3 --pmc, one counter per pass, eager launches), profiles/{tag}_counters.txt"}
-    lines = [f"# tools/collect_counters.sh {tag}; kernel sources sha256/16 = {out['csrc_sha256_16']}"]
-    # ---- the 256-sequence step
-    try:
-        fetch, write = rows_of(os.path.join(d, "lanes_FETCH_SIZE"), "FETCH_SIZE"), rows_of(os.path.join(d, "lanes_WRITE_SIZE"), "WRITE_SIZE")
-        # the WIDE decoder's kernels only (the bench's own batch-1 timed region is in the trace too): the matrix-core W.x, the
-        # grouped attention, and k_dec_gemv8's staging launches (EPI_STAGE_FRAG = 3, its fifth template argument)
-        def wide(name):
-            if "k_dec_mmvh<" in name or "k_dec_attn_mm_g<" in name:
-                return True
-            if "k_dec_gemv8<" in name:
-                args = name.split("k_dec_gemv8<")[1].split(">")[0].split(",")
-                return len(args) >= 5 and args[4].strip() == "3"
-            return False
-        dec = lambda rows: [r for r in rows if wide(r[1])]
-        # 22 blocks x 2 lanes of attention launches per 256-sequence step
-        steps = sum(1 for r in dec(fetch) if "k_dec_attn_mm_g<" in r[1]) / 44.0
-        fkb, wkb = sum(r[2] for r in dec(fetch)), sum(r[2] for r in dec(write))
-        per_kernel = defaultdict(lambda: [0.0, 0])
-        for _, name, v in dec(fetch):
-            k = name.split("(")[0][:70]
-            per_kernel[k][0] += v; per_kernel[k][1] += 1
-        if steps > 0:
-            b = (2 * fkb + wkb) * 1024 / steps
-            out["lanes256"] = {"hbm_bytes_per_step": int(b), "steps_in_trace": steps, "fetch_kb": fkb, "write_kb": wkb}
-            lines.append(f"lanes256: {steps:.0f} steps in the trace, FETCH_SIZE {fkb:.0f} KB, WRITE_SIZE {wkb:.0f} KB over the wide decoder's dispatches -> "
-                         f"(2 F + W) * 1024 / steps = {int(b)} B per step")
-            for k, (v, n) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])[:12]:
-                lines.append(f"    {k:70s} dispatches {n:6d}  FETCH_SIZE {v / n:10.1f} KB per dispatch")
-    except Exception as e:                          # noqa: BLE001
-        lines.append(f"lanes256: not collected ({e!r})")
+           "source": f"tools/collect_all.sh {tag} (rocprofv3 --pmc, one counter per pass, eager launches), profiles/{tag}_counters.txt"}
+    lines = [f"# tools/collect_all.sh {tag}; kernel sources sha256/16 = {out['csrc_sha256_16']}"]
+    # ---- the multi-sequence legs: 8 sequences (GEMV kernels, grouped one-launch attention), 64 (one lane), 256 (two lanes of 128)
+    ATTN = ("k_dec_attn_hm<", "k_dec_attn_mm_g<", "k_dec_attn_one_g<", "k_dec_attn_score_g<")       # one per (block, lane) and step
+    def wide(name):
+        # the multi-sequence decoder's kernels only (the bench's own batch-1 timed region is in the trace too): its W.x kernels, its
+        # attention, and k_dec_gemv8's staging launches (EPI_STAGE = 2 / EPI_STAGE_FRAG = 3, the fifth template argument)
+        if any(k in name for k in ("k_dec_mmvh<", "k_dec_mmv<", "k_dec_gemvm<", "k_dec_silumul_rows", "k_dec_attn_pv_g<") + ATTN):
+            return True
+        if "k_dec_gemv8<" in name:
+            args = name.split("k_dec_gemv8<")[1].split(">")[0].split(",")
+            return len(args) >= 5 and args[4].strip() in ("2", "3")
+        return False
+    for S, lanes in ((8, 1), (64, 1), (256, 2)):
+        key = f"lanes{S}"
+        try:
+            fetch, write = rows_of(os.path.join(d, f"{key}_FETCH_SIZE"), "FETCH_SIZE"), rows_of(os.path.join(d, f"{key}_WRITE_SIZE"), "WRITE_SIZE")
+            dec = lambda rows: [r for r in rows if wide(r[1])]
+            steps = sum(1 for r in dec(fetch) if any(k in r[1] for k in ATTN)) / (22.0 * lanes)
+            fkb, wkb = sum(r[2] for r in dec(fetch)), sum(r[2] for r in dec(write))
+            per_kernel = defaultdict(lambda: [0.0, 0.0, 0])
+            for _, name, v in dec(fetch):
+                k = name.split("(")[0][:70]
+                per_kernel[k][0] += v; per_kernel[k][2] += 1
+            for _, name, v in dec(write):
+                per_kernel[name.split("(")[0][:70]][1] += v
+            if steps > 0:
+                b = (2 * fkb + wkb) * 1024 / steps
+                out[key] = {"hbm_bytes_per_step": int(b), "steps_in_trace": steps, "fetch_kb": fkb, "write_kb": wkb}
+                lines.append(f"{key}: {steps:.0f} steps in the trace, FETCH_SIZE {fkb:.0f} KB, WRITE_SIZE {wkb:.0f} KB over the decoder's dispatches -> "
+                             f"(2 F + W) * 1024 / steps = {int(b)} B per step")
+                for k, (v, w, n) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])[:12]:
+                    lines.append(f"    {k:70s} dispatches {n:6d}  FETCH_SIZE {v / n:10.1f} KB  WRITE_SIZE {w / n:9.1f} KB per dispatch  (2 F + W) = {(2 * v + w) / n / 1024:8.2f} MB")
+        except Exception as e:                          # noqa: BLE001
+            lines.append(f"{key}: not collected ({e!r})")
     # ---- the prompt GEMM
     try:
         busy, act = rows_of(os.path.join(d, "prefill_SQ_VALU_MFMA_BUSY_CYCLES"), "SQ_VALU_MFMA_BUSY_CYCLES"), rows_of(os.path.join(d, "prefill_GRBM_GUI_ACTIVE"), "GRBM_GUI_ACTIVE")

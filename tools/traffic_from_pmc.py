@@ -48,10 +48,13 @@ def csrc_fingerprint():
     return bench.csrc_fingerprint()
 
 
-def read_counter(dirname, counter, last_steps=8):
-    files = glob.glob(os.path.join(dirname, "pmc_" + counter, "**", "*_counter_collection.csv"), recursive=True)
+def read_counter(dirname, mode, counter, last_steps=8):
+    sub = os.path.join(dirname, f"pmc_{mode}_{counter}")
+    if not os.path.isdir(sub):
+        sub = os.path.join(dirname, "pmc_" + counter)            # (round-2 layout: q4 only)
+    files = glob.glob(os.path.join(sub, "**", "*_counter_collection.csv"), recursive=True)
     if not files:
-        raise SystemExit(f"no counter_collection.csv under {dirname}/pmc_{counter}")
+        raise SystemExit(f"no counter_collection.csv under {sub}")
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -71,25 +74,27 @@ def read_counter(dirname, counter, last_steps=8):
 
 
 def main():
-    d, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
-    fetch = read_counter(d, "FETCH_SIZE")
-    write = read_counter(d, "WRITE_SIZE")
-    out = {"csrc_sha256_16": csrc_fingerprint(), "q4": {},
-           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh, profiles/{tag}_pmc_q4.txt): "
+    d, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r05")
+    modes = sys.argv[3:] or ["q4"]
+    out = {"csrc_sha256_16": csrc_fingerprint(),
+           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_all.sh, profiles/{tag}_pmc_<mode>.txt): "
                      "eager decode steps at n = 2041..2048, bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: a 16 B/lane "
                      "streaming read is counted at half its bytes)"}
-    lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --brief --fill prefill --no-graph --steps 8 --warmup 2,",
-             "# q4, decode launches of the last 8 steps (n = 2041..2048); per-launch means; gfx950 correction: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM)",
-             f"# kernel sources sha256/16 = {out['csrc_sha256_16']}"]
-    for fam in sorted(fetch):
-        f_kb, n = fetch[fam]
-        w_kb = write.get(fam, (0.0, 0))[0]
-        b = int((2 * f_kb + w_kb) * 1024)
-        out["q4"][fam] = b
-        lines.append(f"{fam:22s} launches {n:5d}  FETCH_SIZE {f_kb:10.1f} KB  WRITE_SIZE {w_kb:8.1f} KB  HBM bytes (2*F+W)*1024 = {b}")
+    for mode in modes:
+        fetch, write = read_counter(d, mode, "FETCH_SIZE"), read_counter(d, mode, "WRITE_SIZE")
+        out[mode] = {}
+        lines = [f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --brief --mode {mode} --fill prefill --no-graph --steps 8 --warmup 2,",
+                 "# decode launches of the last 8 steps (n = 2041..2048); per-launch means; gfx950 correction: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM)",
+                 f"# kernel sources sha256/16 = {out['csrc_sha256_16']}"]
+        for fam in sorted(fetch):
+            f_kb, n = fetch[fam]
+            w_kb = write.get(fam, (0.0, 0))[0]
+            b = int((2 * f_kb + w_kb) * 1024)
+            out[mode][fam] = b
+            lines.append(f"{fam:22s} launches {n:5d}  FETCH_SIZE {f_kb:10.1f} KB  WRITE_SIZE {w_kb:8.1f} KB  HBM bytes (2*F+W)*1024 = {b}")
+        open(os.path.join(d, f"{tag}_pmc_{mode}.txt"), "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
-    open(os.path.join(d, f"{tag}_pmc_q4.txt"), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines))
 
 
 if __name__ == "__main__":
