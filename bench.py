@@ -1034,9 +1034,17 @@ def worker(args, rank, local_rank, world, dist):
                 out["multi_stream_lanes"] = multi_stream(256, "one decoder, two lanes of 128 sequences (q8 / q4; f16: four lanes of 64): the lanes' launch "
                                                               "chains are parallel branches of one graph and fill each other's gaps, a lane's W.x workgroups "
                                                               "run eight row tiles per expanded weight fragment; per sequence the bits of a 64-sequence "
-                                                              "decoder (tests/test_multiseq_gpu.py); 384 / 512 sequences measured 69.5 k / 71.2 k tok/s")
+                                                              "decoder (tests/test_multiseq_gpu.py); wide attention on head-major K / V shadows (round 5: "
+                                                              "csrc/gten_decode_attn_hm.h); 128 / 384 sequences measured 60.4 k / 90.3 k tok/s")
             except Exception as e:
                 out["multi_stream_lanes"] = {"tok_s": None, "note": "lanes leg unavailable: %r" % (e,)}
+            # ... and 512 sequences (four lanes of 128; q8 / q4): 12.5 GB of K / V per step, the weights' share of the bytes below 5 %
+            if args.mode != "f16":
+                try:
+                    out["multi_stream_lanes512"] = multi_stream(512, "one decoder, four lanes of 128 sequences: the step is 95 % K / V bytes, read once per step as "
+                                                                     "contiguous runs from head-major shadows (k_dec_attn_hm)")
+                except Exception as e:
+                    out["multi_stream_lanes512"] = {"tok_s": None, "note": "512-sequence leg unavailable: %r" % (e,)}
         model = host.model(cfg)
         model.load_synthetic(args.seed)
     # secondary: real greedy generation of a whole batch (sampler on the device, every sequence its own prompt)

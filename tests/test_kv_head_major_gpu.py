@@ -16,7 +16,7 @@ from test_model_gpu import host_cfg
 
 pytestmark = pytest.mark.gpu
 
-QMODES = [m for m in MODES() if m[0] != "f16"]
+QMODES = MODES()          # f16 too: its wide decoders keep f16 shadows (k_dec_attn_hm_f16) in place of the two-launch pair on the rows
 
 
 def make_batch(hip, host, cfg, n_seq, head_major, seed=777):

@@ -153,7 +153,7 @@ struct gten_hip_decoder {
     // its cache rows before the next step (set at creation, by every (re)start of the sequence, and -- through the watch
     // registry of gten_rt.h -- by every write of this library into one of its cache rows)
     uint8_t* hm = nullptr;
-    size_t hm_seq_stride = 0, hm_cache_bytes = 0;
+    size_t hm_seq_stride = 0, hm_cache_bytes = 0, hm_chunk_bytes = 0;
     std::vector<char> hm_dirty;
     unsigned long long hm_imports = 0, hm_import_launches = 0;
     // every decoder: do the caches it appends to overlap a watch of ANOTHER decoder (cached per registry epoch)
@@ -249,9 +249,15 @@ static bool grouped_mm(const AttnArgs& t, int n_seq)
     return n_seq >= 16 && t.adtype == GTEN_Q8 && t.d_head == 64 && !g_exact_now;
 }
 
+// f16 activations, 16+ sequences, head-major shadows (round 5): one launch with chunk-local statistics (k_dec_attn_hm_f16)
+static bool grouped_hm_f16(const AttnArgs& t, int n_seq)
+{
+    return n_seq >= 16 && t.adtype == GTEN_F16 && t.d_head == 64 && t.hm_k && !g_exact_now;
+}
+
 static bool grouped_one_pass(const AttnArgs& t, int n_seq)
 {
-    if (grouped_mm(t, n_seq)) return true;
+    if (grouped_mm(t, n_seq) || grouped_hm_f16(t, n_seq)) return true;
     // 8 sequences: one launch (per sequence the bytes of single-sequence decode).  From 16 sequences up the two
     // launches measured FASTER than the merged kernel (64 sequences, ctx 2048: 22.3 + 25.8 us against 62.4 us per
     // block -- the merged workgroup holds K rows, V chunk and every head's scores at once: 104 VGPRs, 27 KB of LDS,
@@ -292,6 +298,12 @@ static int launch_attention_g(const AttnArgs& t, int n_seq)
     if (smem2 > 64 * 1024) {
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, true, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_attn_pv_g<GRP, false, ADT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2));
+    }
+    if constexpr (ADT == GTEN_F16) if (grouped_hm_f16(t, n_seq)) {
+        const int n_cq = (t.n_chunks + HM_WAVES - 1) / HM_WAVES;
+        if (n_seq >= 128) DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_hm_f16<GRP, true>), dim3(n_seq * n_cq * t.n_kv), dim3(64 * HM_WAVES), 2048, t, n_seq, n_cq);
+        else DEC_LAUNCH(KT_DEC_ATTN_SCORE, (k_dec_attn_hm_f16<GRP, false>), dim3(n_seq * n_cq * t.n_kv), dim3(64 * HM_WAVES), 2048, t, n_seq, n_cq);
+        return 0;
     }
     if (ADT == GTEN_F16 && n_seq >= 16) {
         // 16 sequences and up: the scores of a group as a matrix product on the matrix cores (k_dec_attn_score_gm_f16)
@@ -1224,8 +1236,9 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
         GTR_CHECK(hipMalloc(&dc->dummy_kv, 2 * cache_bytes));
         GTR_CHECK(hipMemset(dc->dummy_kv, 0, 2 * cache_bytes));
         const int grp = d.n_heads / d.n_kv_heads;
-        if (wide && g_kv_head_major && !dc->exact && d.adtype == GTEN_Q8 && dh == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1)) {
-            dc->hm_cache_bytes = (size_t)d.n_kv_heads * dc->n_chunks * HM_CHUNK_BYTES;
+        if (wide && g_kv_head_major && !dc->exact && (d.adtype == GTEN_Q8 || d.adtype == GTEN_F16) && dh == 64 && (grp == 8 || grp == 4 || grp == 2 || grp == 1)) {
+            dc->hm_chunk_bytes = d.adtype == GTEN_Q8 ? HM_CHUNK_BYTES : HMF_CHUNK_BYTES;
+            dc->hm_cache_bytes = (size_t)d.n_kv_heads * dc->n_chunks * dc->hm_chunk_bytes;
             dc->hm_seq_stride = (size_t)d.n_layers * 2 * dc->hm_cache_bytes;
             GTR_CHECK(hipMalloc((void**)&dc->hm, S * dc->hm_seq_stride));
             GTR_CHECK(hipMemset(dc->hm, 0, S * dc->hm_seq_stride));
@@ -1434,9 +1447,14 @@ static int pre_run(gten_hip_decoder* dc)
     const size_t kv_pitch = gten_hip_row_bytes(d.adtype, (d.n_embd / d.n_heads) * d.n_kv_heads);
     auto flush = [&]() -> int {
         if (items.n == 0) return 0;
-        GTR_LAUNCH(KT_PACK, k_kv_import_hm, dim3(d.n_kv_heads * dc->n_chunks, d.n_layers * 2, items.n), dim3(256), (size_t)DEC_CHUNK * 68, items,
-                   (const DecStep*)dc->step, (const void* const*)dc->kv_tab, dc->hm, dc->hm_seq_stride, dc->hm_cache_bytes, d.n_layers, d.n_kv_heads, dc->n_chunks,
-                   d.max_ctx, kv_pitch);
+        if (d.adtype == GTEN_Q8)
+            GTR_LAUNCH(KT_PACK, k_kv_import_hm, dim3(d.n_kv_heads * dc->n_chunks, d.n_layers * 2, items.n), dim3(256), (size_t)DEC_CHUNK * 68, items,
+                       (const DecStep*)dc->step, (const void* const*)dc->kv_tab, dc->hm, dc->hm_seq_stride, dc->hm_cache_bytes, d.n_layers, d.n_kv_heads,
+                       dc->n_chunks, d.max_ctx, kv_pitch);
+        else
+            GTR_LAUNCH(KT_PACK, k_kv_import_hm_f16, dim3(d.n_kv_heads * dc->n_chunks, d.n_layers * 2, items.n), dim3(256), (size_t)DEC_CHUNK * 33 * 4, items,
+                       (const DecStep*)dc->step, (const void* const*)dc->kv_tab, dc->hm, dc->hm_seq_stride, dc->hm_cache_bytes, d.n_layers, d.n_kv_heads,
+                       dc->n_chunks, d.max_ctx, kv_pitch);
         dc->hm_import_launches++;
         dc->hm_imports += (unsigned long long)items.n;
         items.n = 0;

@@ -403,3 +403,220 @@ __global__ __launch_bounds__(64 * HM_WAVES) HM_OCC void k_dec_attn_hm(const Attn
         for (int et = 0; et < 4; et++) *(float4*)(o + 16 * et) = make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// f16 activations (the f16 configuration's wide decoders; round 5).  The same idea with nothing to dequantize: a shadow chunk
+// holds 256 positions x 64 halfs = 32 768 bytes per matrix, K as the A operands of v_mfma_f32_16x16x32_f16 (16 tiles x 2 steps
+// of 32 elements: lane l owns the 8 halfs [16 l, 16 l + 16) of a (tile, step)), V TRANSPOSED as the A operands of the p.V
+// products (8 steps of 32 positions x 4 element tiles; slot order as in the Q8 shadow).  One wave per (sequence, kv head, chunk):
+// scores = K . Q^T (f16 products are exact in f32; the matrix core adds them), columns 0 .. GRP - 1 = the group's heads; a lane of
+// a head column owns 4 positions per tile, so chunk maximum, sum of exponentials and the fp16 rounding of the probabilities
+// (gten/ops.h:996-997 stores them as f16) are in-lane loops + two cross-lane steps, and the rounded probabilities are the B
+// operand of p.V as they stand.  Chunk-local statistics, joined by the consumer (PRO_ATTW) -- the single-sequence f16 step's
+// scheme instead of the row-global rounding of the two-launch pair this replaces.
+#define HMF_CHUNK_BYTES 32768
+__host__ __device__ __forceinline__ unsigned hmf_k_off(unsigned p, unsigned e)
+{
+    return (p >> 4) * 2048u + (e >> 5) * 1024u + (((((e & 31u) >> 3) * 16u) + (p & 15u)) * 16u) + (e & 7u) * 2u;
+}
+__host__ __device__ __forceinline__ unsigned hmf_v_off(unsigned p, unsigned e)
+{
+    return (p >> 5) * 4096u + (e >> 4) * 1024u + (((((p & 15u) >> 2) * 16u) + (e & 15u)) * 16u) + (4u * ((p >> 4) & 1u) + (p & 3u)) * 2u;
+}
+
+__global__ __launch_bounds__(256) void k_kv_import_hm_f16(const HmImportList items, const DecStep* __restrict__ step, const void* const* __restrict__ kv_tab,
+                                                          uint8_t* __restrict__ hm_base, size_t hm_seq_stride, size_t hm_cache_bytes, int n_layers,
+                                                          int n_kv, int n_chunks, int max_ctx, size_t kv_pitch)
+{
+    const int seq = items.seq[blockIdx.z], layer = blockIdx.y >> 1, kv = blockIdx.y & 1;
+    const int g = blockIdx.x % n_kv, chunk = blockIdx.x / n_kv, c0 = chunk * DEC_CHUNK;
+    const int rows = step[seq].n - 1;
+    if (c0 >= rows) return;
+    const uint8_t* src = (const uint8_t*)kv_tab[((size_t)seq * n_layers + layer) * 2 + kv] + (size_t)g * 128;
+    uint8_t* dst = hm_base + (size_t)seq * hm_seq_stride + (size_t)(layer * 2 + kv) * hm_cache_bytes + (size_t)(g * n_chunks + chunk) * HMF_CHUNK_BYTES;
+    unsigned* raw = (unsigned*)g_smem;                            // [256][33]: the slices (32 dwords) as they lie in the cache, padded
+    {
+        const int p = threadIdx.x, row = min(c0 + p, max_ctx - 1);
+        const gmem_u32 s = as_global(src + (size_t)row * kv_pitch);
+        const bool known = c0 + p < rows;                         // (rows the sequence does not have yet become zeros: V must stay finite)
+#pragma unroll
+        for (int j = 0; j < 32; j++) { const unsigned v = s[j]; raw[p * 33 + j] = known ? v : 0u; }
+    }
+    __syncthreads();
+    const uint16_t* rh = (const uint16_t*)raw;
+    auto elem = [&](unsigned p, unsigned e) -> unsigned { return rh[p * 66u + e]; };
+    for (unsigned q = threadIdx.x; q < 2048u; q += 256u) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (kv == 0) {
+            // K piece q = 128 T + 64 ks + 16 lq + lc: elements 32 ks + 8 lq .. + 7 of position 16 T + lc
+            const unsigned T = q >> 7, ks = (q >> 6) & 1u, lq = (q >> 4) & 3u, lc = q & 15u, p = 16u * T + lc;
+#pragma unroll
+            for (unsigned j = 0; j < 8; j++) w[j >> 1] |= elem(p, 32u * ks + 8u * lq + j) << (16u * (j & 1u));
+        } else {
+            // V piece q = 256 s + 64 et + 16 lq + lc: element 16 et + lc at 8 positions
+            const unsigned s = q >> 8, et = (q >> 6) & 3u, lq = (q >> 4) & 3u, lc = q & 15u;
+#pragma unroll
+            for (unsigned j = 0; j < 8; j++) {
+                const unsigned p = 32u * s + 16u * (j >> 2) + 4u * lq + (j & 3u);
+                w[j >> 1] |= elem(p, 16u * et + lc) << (16u * (j & 1u));
+            }
+        }
+        *(uint4*)(dst + (size_t)q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <int GRP, bool NT>
+__global__ __launch_bounds__(64 * HM_WAVES) void k_dec_attn_hm_f16(const AttnArgs a0, const int n_seq, const int n_cq)
+{
+    constexpr int dh = 64, NWV = HM_WAVES;
+    const int g = blockIdx.x % a0.n_kv, sci = blockIdx.x / a0.n_kv, seq = sci % n_seq, cq = sci / n_seq;
+    const int w = threadIdx.x >> 6, t = threadIdx.x & 63, lc = t & 15, lq = t >> 4;
+    const int chunk = NWV * cq + w, c0 = chunk * DEC_CHUNK;
+    const AttnArgs a = attn_for_seq(a0, seq);
+    const int n = a.step->n, pos = n - 1;
+    if (NWV * cq * DEC_CHUNK >= n) return;
+    const bool alive = c0 < n;
+    const int len = min(DEC_CHUNK, pos - c0);
+    const bool has_new = alive && pos < c0 + DEC_CHUNK;
+    const int kv_dim = a.n_kv * dh;
+
+    uint16_t* qh = (uint16_t*)g_smem;                             // [8][64] head vectors as f16 (shared)
+    uint16_t* kh = qh + 8 * dh + w * 128;                         // per wave: the new K row [64], the new V row [64]
+    uint16_t* vh = kh + dh;
+    // head_prep_cs's Q8 outputs are unused for f16: a scratch corner they may write nothing into (act gates the stores on Q8 only)
+    int8_t* nul8 = (int8_t*)(qh + 8 * dh + NWV * 128);
+    float* nulf = (float*)(nul8 + 64);
+    uint16_t* nulh = (uint16_t*)(nulf + 2);
+
+    constexpr int NJ = (GRP + NWV - 1) / NWV;
+    float qraw[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) qraw[jj] = a.qkv_raw[(g * GRP + min(w + NWV * jj, GRP - 1)) * dh + t];
+    float kraw = a.qkv_raw[a.n_embd + g * dh + t], vraw = a.qkv_raw[a.n_embd + kv_dim + g * dh + t];
+    if (a.qkv_plane) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_raw[a.qkv_plane + (g * GRP + min(w + NWV * jj, GRP - 1)) * dh + t];
+        kraw += a.qkv_raw[a.qkv_plane + a.n_embd + g * dh + t];
+        vraw += a.qkv_raw[a.qkv_plane + a.n_embd + kv_dim + g * dh + t];
+    }
+    const float2 rot = a.rope_now[t & 31];
+    const uint8_t* kc = a.hm_k + (size_t)(g * a.n_chunks + (alive ? chunk : 0)) * HMF_CHUNK_BYTES;
+    const uint8_t* vc = kc + a.hm_cache_bytes;
+    const int Tl = max(len - 1, 0) >> 4, Sl = Tl >> 1;
+    typedef int hm_v4i __attribute__((ext_vector_type(4)));
+    typedef const hm_v4i __attribute__((address_space(1)))* gmem_v4i;
+    hm_v4i ka[16][2];
+    const gmem_v4i kq = (gmem_v4i)(uintptr_t)(kc + t * 16);
+    if (alive) {
+#pragma unroll
+        for (int T = 0; T < 8; T++) { ka[T][0] = HM_LD(kq + min(T, Tl) * 128); ka[T][1] = HM_LD(kq + min(T, Tl) * 128 + 64); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+        const int j = w + NWV * jj;
+        if (j < GRP) {
+            const float v = head_prep_cs(qraw[jj], true, true, rot, dh, GTEN_F16, nul8, nulf, nulh);
+            qh[j * dh + t] = f2h(v);
+        }
+    }
+    float vnew = 0.f;
+    if (has_new) {
+        const float kf = head_prep_cs(kraw, true, true, rot, dh, GTEN_F16, nul8, nulf, nulh);
+        vnew = head_prep_cs(vraw, true, false, rot, dh, GTEN_F16, nul8, nulf, nulh);
+        kh[t] = f2h(kf);
+        vh[t] = f2h(vnew);
+    }
+    __syncthreads();
+    if (!alive) return;
+    // B operand: column lc = head lc (lc < GRP), two steps of 32 elements
+    att_h8 qb[2];
+    {
+        const hm_v4i z = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const hm_v4i v = *(const hm_v4i*)(qh + min(lc, GRP - 1) * dh + 32 * ks + 8 * lq);
+            qb[ks] = __builtin_bit_cast(att_h8, lc < GRP ? v : z);
+        }
+    }
+    const unsigned pn = (unsigned)(pos - c0);
+    float scn = -INFINITY;
+    if (has_new) {
+        uint8_t* krow = a.kcache + (size_t)pos * a.kv_pitch + (size_t)g * 128, *vrow = a.vcache + (size_t)pos * a.kv_pitch + (size_t)g * 128;
+        const uint16_t kb = kh[t], vb = vh[t];
+        store_global<uint16_t>(krow + 2 * t, kb);
+        store_global<uint16_t>(vrow + 2 * t, vb);
+        uint8_t* kcw = a.hm_k + (size_t)(g * a.n_chunks + chunk) * HMF_CHUNK_BYTES;
+        store_global<uint16_t>(kcw + hmf_k_off(pn, (unsigned)t), kb);
+        store_global<uint16_t>(kcw + a.hm_cache_bytes + hmf_v_off(pn, (unsigned)t), vb);
+        att_f4 cn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const att_h8 kn = __builtin_bit_cast(att_h8, *(const hm_v4i*)(kh + 32 * ks + 8 * lq));     // every row of A is the new K row
+            cn = __builtin_amdgcn_mfma_f32_16x16x32_f16(kn, qb[ks], cn, 0, 0, 0);
+        }
+        scn = cn[0] * 0.125f;
+    }
+    // ---- scores: lane (lc, lq) holds positions 16 T + 4 lq + i under head lc
+    float sc[16][4];
+#pragma unroll
+    for (int T = 0; T < 16; T++) {
+        if (T == 8) {
+#pragma unroll
+            for (int U = 8; U < 16; U++) { ka[U][0] = HM_LD(kq + min(U, Tl) * 128); ka[U][1] = HM_LD(kq + min(U, Tl) * 128 + 64); }
+        }
+        att_f4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(att_h8, ka[T][0]), qb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(att_h8, ka[T][1]), qb[1], c, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) sc[T][i] = (16 * T + 4 * lq + i < len) ? c[i] * 0.125f : -INFINITY;
+    }
+    // ---- the V chunk (the K registers are free)
+    hm_v4i va[8][4];
+    {
+        const gmem_v4i vq = (gmem_v4i)(uintptr_t)(vc + t * 16);
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+#pragma unroll
+            for (int et = 0; et < 4; et++) va[s][et] = HM_LD(vq + min(s, Sl) * 256 + et * 64);
+    }
+    float M = scn;
+#pragma unroll
+    for (int T = 0; T < 16; T++) M = fmaxf(M, fmaxf(fmaxf(sc[T][0], sc[T][1]), fmaxf(sc[T][2], sc[T][3])));
+    M = hm_rows_max(M);
+    float L = 0.f;
+#pragma unroll
+    for (int T = 0; T < 16; T++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { sc[T][i] = __expf(sc[T][i] - M); L += sc[T][i]; }
+    L = hm_rows_sum(L);
+    float en = 0.f;
+    if (has_new) { en = __expf(scn - M); L += en; }
+    if (lq == 0 && lc < GRP)
+        *(float2*)(a.stats + ((size_t)(g * GRP + lc) * a.n_chunks + chunk) * 2) = make_float2(M, L);
+    const float rL = recip_rn(L);
+    // ---- p.V: the probabilities rounded to f16 (as the reference stores them) are the B operand as they stand
+    att_f4 acc[4];
+#pragma unroll
+    for (int et = 0; et < 4; et++) acc[et] = att_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        att_h8 bp;
+#pragma unroll
+        for (int j = 0; j < 8; j++) bp[j] = f2hv(sc[2 * s + (j >> 2)][j & 3] * rL);
+#pragma unroll
+        for (int et = 0; et < 4; et++) acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(att_h8, va[s][et]), bp, acc[et], 0, 0, 0);
+    }
+    if (has_new) {
+        const float pv = (float)f2hv(en * rL);
+#pragma unroll
+        for (int et = 0; et < 4; et++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[et][i] += pv * h2f(vh[16 * et + 4 * lq + i]);
+    }
+    if (lc < GRP) {
+        float* o = a.att_part + ((size_t)(g * GRP + lc) * a.n_chunks + chunk) * dh + 4 * lq;
+#pragma unroll
+        for (int et = 0; et < 4; et++) *(float4*)(o + 16 * et) = make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
+    }
+}

@@ -3,8 +3,8 @@
 #   1. batch-1 decode step, per configuration (q4 q8 f16): rocprofv3 --kernel-trace --stats -> <tag>_fused_<mode>_kernel_stats.csv, and
 #      --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes (eager launches: counters are per dispatch) -> traffic.json
 #      (HBM bytes per launch per kernel family, gfx950 correction applied: tools/traffic_from_pmc.py)
-#   2. the multi-sequence legs (8, 64, 256 sequences; q4): the same two counters over the decoder's dispatches -> counters.json
-#      sections lanes8 / lanes64 / lanes256 (HBM bytes per step: tools/counters_from_pmc.py), and the kernel trace of the
+#   2. the multi-sequence legs (8, 64, 256, 512 sequences; q4): the same two counters over the decoder's dispatches -> counters.json
+#      sections lanes8 / lanes64 / lanes256 / lanes512 (HBM bytes per step: tools/counters_from_pmc.py), and the kernel trace of the
 #      256-sequence step -> <tag>_lanes256_kernel_stats.csv
 #   3. prompts: kernel traces of a 512- and a 2048-id prompt -> <tag>_prefill{512,2048}_kernel_stats.csv; SQ_VALU_MFMA_BUSY_CYCLES and
 #      GRBM_GUI_ACTIVE (separate passes) of the 2048-id prompt -> counters.json section prefill2048
@@ -37,7 +37,7 @@ rm -rf $OUT/pmc_*
 
 # ---- 2. the multi-sequence legs
 COMMON="--no-cpu-baseline --no-graph --no-lanes --prefill 0 --generate 0 --serve 0 --steps 4 --warmup 2 --fill prefill"
-for S in 8 64 256; do
+for S in 8 64 256 512; do
   if [ $S -eq 8 ]; then SEL="--streams 8 --wide-streams 0"; else SEL="--streams 0 --wide-streams $S"; fi
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 420 $RP --kernel-trace --pmc $C -d $OUT/lanes${S}_$C -- python3 $R/bench.py $COMMON $SEL > $OUT/lanes${S}_$C.json 2> $OUT/lanes${S}_$C.err

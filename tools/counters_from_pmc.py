@@ -45,7 +45,7 @@ def main():
             args = name.split("k_dec_gemv8<")[1].split(">")[0].split(",")
             return len(args) >= 5 and args[4].strip() in ("2", "3")
         return False
-    for S, lanes in ((8, 1), (64, 1), (256, 2)):
+    for S, lanes in ((8, 1), (64, 1), (256, 2), (512, 4)):
         key = f"lanes{S}"
         try:
             fetch, write = rows_of(os.path.join(d, f"{key}_FETCH_SIZE"), "FETCH_SIZE"), rows_of(os.path.join(d, f"{key}_WRITE_SIZE"), "WRITE_SIZE")
