@@ -85,6 +85,7 @@ enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2, EPI_STAGE_FRAG = 3 };
 
 #include "gten_decode_wx.h"
 #include "gten_decode_wide_wx.h"
+#include "gten_decode_ffn.h"
 #include "gten_decode_attn.h"
 #include "gten_decode_attn_exact64.h"
 #include "gten_decode_attn_wide.h"
@@ -729,6 +730,13 @@ struct MmvhArgs {
     float* out; int out_cols;
     int S, d_in, ks, plane;
 };
+// (A/B switch of the streamed gate | up and lm_head kernel, gten_decode_ffn.h: 0 keeps k_dec_mmvh<.., 8, 4, ..> for 128-row lanes too)
+static bool g_ffn_streamed = true;
+extern "C" int gten_hip_set_ffn_streamed(int on)
+{
+    g_ffn_streamed = on != 0;
+    return 0;
+}
 template <int WT, int RT>
 static int launch_mmvh_rt(int tag, const MmvhArgs& a)
 {
@@ -750,6 +758,12 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
     // 512 KB of staged activations through L2 -- 512 MB per launch, which is what its 53 us were; 501 workgroups of 64 features
     // halve that (the same sums per row: a row's K slices and their order do not depend on the feature tiles beside it).
     if constexpr (RT == 8 && WT == GTEN_Q4) {
+        if (a.n_mats == 1 && ks == 1 && cols >= 16384 && g_ffn_streamed && a.S == 128 && a.d_in == 2048) {
+            // ... and as the streamed kernel of gten_decode_ffn.h (the same sums): no cross-wave sum, the weights slice by slice
+            DEC_LAUNCH(tag, k_dec_ffn_q4<false>, dim3((cols + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, a.ah, a.w[0], a.w[0], (uint16_t*)a.out, a.d_in,
+                       a.d_out[0], a.S, a.out_cols);
+            return 0;
+        }
         if (a.n_mats == 1 && ks == 1 && cols >= 16384 && ppr <= 32 * (MMV_MAXP / 4)) {
             const size_t smem4 = std::max((size_t)64 * nbs * 16, (size_t)8 * 16 * RT * 64) + 64 * nbs * 2;
             GTR_REQUIRE(smem4 <= 150 * 1024, "decoder: the weight slab of d_in %d does not fit LDS", a.d_in);
@@ -777,6 +791,11 @@ static int launch_mmvh_silu(int tag, const uint16_t* ah, const void* wgate, cons
     GTR_REQUIRE(rt_s <= 4 || rt_s == 8, "decoder: a lane of %d rows (one to four row tiles, or exactly eight)", S);
     const size_t smem = std::max((size_t)64 * nbs * (WQ == GTEN_Q4 ? 16 : 32), (size_t)8 * 16 * rt * 64) + 64 * nbs * 2 + 4 * 16 * rt * 16 * 4;
     GTR_REQUIRE(smem <= 150 * 1024 && nbs * (WQ == GTEN_Q4 ? 1 : 2) <= (size_t)32 * (MMV_MAXP / 4), "decoder: the FFN slab of d_in %d does not fit", d_in);
+    // full 128-row lanes at K = 2048, q4: the streamed form (gten_decode_ffn.h) -- the same sums bit for bit, 15.1 -> 12.2 us per launch
+    if (WQ == GTEN_Q4 && g_ffn_streamed && rt == 8 && S == 128 && d_in == 2048) {
+        DEC_LAUNCH(tag, k_dec_ffn_q4<true>, dim3(n_ffn / 32), dim3(512), (size_t)2 * 8 * 4 * 1024, ah, wgate, wup, out_frag, d_in, n_ffn, S, 0);
+        return 0;
+    }
     const MmvRest rest{wup, nullptr, n_ffn, 0, 0};
     const dim3 grid(n_ffn / 32, 1);
 #define MMVH_S(RT_) DEC_LAUNCH(tag, (k_dec_mmvh<WQ, RT_, 4, true>), grid, dim3(512), smem, ah, wgate, (float*)out_frag, d_in, n_ffn, 0, S, 2, rest)
@@ -821,6 +840,10 @@ static int mmvh_prepare()
     MMVH_ATTR_S(1); MMVH_ATTR_S(2); MMVH_ATTR_S(3); MMVH_ATTR_S(4); MMVH_ATTR_S(8);
 #undef MMVH_ATTR_S
 #undef MMVH_ATTR
+    if (WT == GTEN_Q4) {
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+    }
     return 0;
 }
 // the wide path's W.x form: f16 fragments with folded deltas (k_dec_mmvh) unless the exact forms are selected
