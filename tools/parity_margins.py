@@ -32,6 +32,24 @@ ALL_PATHS = ("fused", "exact", "operators", "wide-64", "wide-128")
 
 
 def main():
+    # every walk builds its own model (the exact / fast choice is made when a decoder is created): generate each configuration's
+    # synthetic weights ONCE and let the other walks read them back (host/tinyllama_model.h load_synthetic_cached), 45 s -> 1 s each
+    cache = None
+    if os.path.isdir("/dev/shm") and "GTEN_SYNTH_CACHE_DIR" not in os.environ:
+        cache = os.environ["GTEN_SYNTH_CACHE_DIR"] = "/dev/shm"
+    try:
+        run()
+    finally:
+        if cache:
+            import glob
+            for f in glob.glob(os.path.join(cache, "gten_synth_*")):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="q4,q8,f16")
     ap.add_argument("--paths", default=",".join(ALL_PATHS))
