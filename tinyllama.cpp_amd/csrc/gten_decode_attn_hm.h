@@ -157,6 +157,12 @@ __device__ __forceinline__ void hm_bytes_to_h4(unsigned b4, unsigned& lo, unsign
 // per SIMD instead of three 3.161 / 1.517.  So: pairs of chunks per workgroup, and the K / V stream -- read once per step, 6 GB
 // at 256 sequences, far beyond the memory-side cache -- nontemporal from 128 rows per lane up (it then stops displacing the
 // weights the other lane is about to read), default policy below.
+// (Built and measured, round 5, not kept: ALL eight chunks of a (sequence, kv head) in one workgroup of eight waves, the partials and
+//  statistics parked in LDS and joined on the chip with the consumer's arithmetic -- bit-identical logits, 1 MB of joined rows per
+//  lane launch instead of 8.4 MB of partials written and read back -- 256 sequences 3.183 / 3.184 ms against 3.042 / 3.064 on the
+//  same box, the launch 30.0 against 27.9 us; 64 sequences 1.500 against 1.488 ms.  One 512-thread workgroup per CU at 159 registers
+//  runs its eight waves through request / softmax / p.V in lockstep and waits at the barrier for its slowest chunk, where six
+//  independent pairs of waves per CU interleave those phases: the 17 MB per launch are cheaper than that.  HISTORY.md, round 5.)
 #ifndef HM_WAVES
 #define HM_WAVES 2            // waves per workgroup = consecutive chunks of one (sequence, kv head) that share the head vectors
 #endif
