@@ -1,6 +1,8 @@
 """gate | up and the lm_head of a full 128-row q4 lane as the streamed kernel (csrc/gten_decode_ffn.h, round 5) against
 k_dec_mmvh<Q4, 8, 4, ..>: the same f16 operands, the same eight K slices accumulated in the matrix core from zero and added in the
-same order -- so not a band but THE SAME BITS, for every sequence of one lane (128) and of two (256)."""
+same order -- so not a band but THE SAME BITS, for every sequence of one lane (128) and of two (256).  q8 weights: gate | up + the
+silu . mul chain as ONE streamed launch (k_dec_ffn_q8) against the k_dec_mmvh<Q8, 8, 2, false> + k_dec_silumul_rows pair (two K planes
+of eight wave slices): the same bits again."""
 import numpy as np
 import pytest
 
@@ -12,13 +14,14 @@ from test_model_gpu import host_cfg
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("wd", [Q4, Q8])
 @pytest.mark.parametrize("n_seq", [128, 256])
-def test_streamed_gate_up_equals_the_slab_kernel_bit_for_bit(hip, n_seq):
+def test_streamed_gate_up_equals_the_slab_kernel_bit_for_bit(hip, n_seq, wd):
     pkg = load_package()
     host = pkg.load_host()
     # the kernel is selected at K = 2048 (TinyLlama's width) -- for the lm_head from 16 384 columns up (a ragged last tile here);
     # a narrow FFN and two blocks keep the model small
-    cfg = host_cfg(tiny_config(Q4, Q8, n_embd=2048, n_heads=32, n_kv_heads=4, n_ffn=768, n_layers=2, n_vocab=16403, max_ctx=64))
+    cfg = host_cfg(tiny_config(wd, Q8, n_embd=2048, n_heads=32, n_kv_heads=4, n_ffn=768, n_layers=2, n_vocab=16403, max_ctx=64))
     weights = [host.synth_weight(cfg, 31, i) for i in range(len(cfg.weight_shapes()))]
     streams = [host.synthetic_tokens(40, seed=7000 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
     out = []

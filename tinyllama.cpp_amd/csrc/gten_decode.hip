@@ -772,6 +772,14 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
             return 0;
         }
     }
+    if constexpr (RT == 8 && WT == GTEN_Q8) {
+        if (a.n_mats == 1 && ks == 1 && cols >= 16384 && g_ffn_streamed && a.S == 128 && a.d_in == 2048) {
+            // q8 lm_head of a full lane: streamed, the sums of the two-tile launch below (one K plane of eight wave slices)
+            DEC_LAUNCH(tag, k_dec_ffn_q8<false>, dim3((cols + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, a.ah, a.w[0], a.w[0], (uint16_t*)a.out, a.d_in,
+                       a.d_out[0], a.S, a.out_cols);
+            return 0;
+        }
+    }
     const dim3 grid((cols + 16 * ft - 1) / (16 * ft), ks);
     if (ft > 1)
         DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, FTW, false>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
@@ -843,6 +851,9 @@ static int mmvh_prepare()
     if (WT == GTEN_Q4) {
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+    }
+    if (WT == GTEN_Q8) {
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
     }
     return 0;
 }
@@ -1005,6 +1016,11 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         const bool fuse_ffn = folded && WT == GTEN_Q4 && E / 32 <= 32 * (MMV_MAXP / 4);      // (a tile's slab: <= 2 pieces per thread)
         if (fuse_ffn) {
             if ((rc = launch_mmvh_silu<WT>(KT_DEC_GEMV_GATEUP, (const uint16_t*)b.stg_q, L.wgate, L.wup, F, E, S, (uint16_t*)b.act_q))) return rc;
+        } else if (folded && WT == GTEN_Q8 && g_ffn_streamed && S == 128 && E == 2048 && ks_gu == 2 && F % 32 == 0) {
+            // q8 weights, a full 128-row lane: gate | up and the silu . mul chain as ONE streamed launch (gten_decode_ffn.h) -- the bits of the
+            // k_dec_mmvh<Q8, 8, 2, false> + k_dec_silumul_rows pair below (two K planes of eight wave slices each)
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_ffn_q8<true>, dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, L.wgate, L.wup,
+                       (uint16_t*)b.act_q, E, F, S, 0);
         } else {
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, b.stg_q, b.stg_d, b.gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)

@@ -21,8 +21,9 @@
 // 128 registers so that two workgroups share a CU (hipcc spills 48 of them): 17.5 us -- not kept.  What is left of the launch:
 // ~2.5 us until the first slice is there, ~4.5 us of matrix instructions on the 176 CUs that have a workgroup, ~2.2 us of the
 // silu . mul chain (eight outputs per lane x ~75 dependent instructions: the reference's expf and division and four Q8 roundings).
+#include <type_traits>
 #ifndef FFN_OCC
-#define FFN_OCC 2             // waves per SIMD the register budget is set for (4 = two workgroups per CU within 128 registers: 48 spilled, 17.5 against 12.2 us)
+#define FFN_OCC 4             // waves per SIMD the register budget is set for: 128 registers, two workgroups per CU (the K loop rolled: no spill)
 #endif
 
 __device__ __forceinline__ float ffn_row16_max(float v)         // maximum over the 16 lanes of a row (non-negative values)
@@ -90,12 +91,12 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
 #pragma unroll
     for (int f = 0; f < 4; f++) total[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
     constexpr int n_slices = 8;                                   // (d_in = 2048: the launcher selects this kernel for that width only)
-#pragma unroll
-    for (int c = 0; c < n_slices; c++) {                          // (fully unrolled: the two register sets are picked at compile time)
-        const int cur = c & 1;
-        if (c + 1 < n_slices) {
+    // one slice; MORE1 / MORE2: a slice / two slices follow (compile-time: no branch around a request); c may be a run-time value
+    auto slice = [&](const int c, const int cur, auto more1, auto more2) {
+        constexpr bool MORE1 = decltype(more1)::value, MORE2 = decltype(more2)::value;
+        if (MORE1) {
             expand(cur ^ 1, cur ^ 1);                             // slice c + 1 -> the buffer slice c - 1 was read from (every wave is past the barrier behind it)
-            if (c + 2 < n_slices) request_w(c + 2, cur);
+            if (MORE2) request_w(c + 2, cur);
         }
         mmvh_f4 acc[4];
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
                 __builtin_memcpy(&bh, &b, 16);
                 acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[f], 0, 0, 0);
             }
-            if (c + 1 < n_slices) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(((c + 1) * NBW + k) * RT * 1024)));
+            if (MORE1) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(((c + 1) * NBW + k) * RT * 1024)));
         }
         // the slice sums join the running totals in slice order: ((((0 + s0) + s1) + ...) -- k_dec_mmvh's wave order
 #pragma unroll
@@ -121,6 +122,19 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
             for (int i = 0; i < 4; i++) total[f][i] = total[f][i] + acc[f][i];
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);                        // (nothing of the next slice is scheduled into this one: registers)
+    };
+    // slices in pairs (the two LDS buffers and weight-register slots alternate) as a ROLLED loop, the last pair peeled: unrolled eight
+    // times hipcc kept 180 registers live across the slices, rolled it needs two thirds of that -- two workgroups per CU
+    {
+        using Y = std::true_type;
+        using N = std::false_type;
+#pragma unroll 1
+        for (int c2 = 0; c2 < n_slices - 2; c2 += 2) {
+            slice(c2, 0, Y{}, Y{});
+            slice(c2 + 1, 1, Y{}, Y{});
+        }
+        slice(n_slices - 2, 0, Y{}, N{});
+        slice(n_slices - 1, 1, N{}, N{});
     }
 
     if (!SILU) {
@@ -155,6 +169,181 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
         {
             const Q8Scale s = q8_scale_from_absmax(ffn_row16_max(fmaxf(fabsf(total[2][i]), fabsf(total[3][i]))));     // up projection written
             uv[0] = (float)q8_round(total[2][i], s.scale) * s.ddeq; uv[1] = (float)q8_round(total[3][i], s.scale) * s.ddeq;
+        }
+        v[0] = gv[0] * uv[0]; v[1] = gv[1] * uv[1];                                                                      // mul in place, then written:
+        const Q8Scale sc = q8_scale_from_absmax(ffn_row16_max(fmaxf(fabsf(v[0]), fabsf(v[1]))));
+        const int r = 16 * wid + 4 * g + i;
+        if (r < S) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = 16 * h + l16, kp = (k & ~3) | ((k & 1) << 1) | ((k >> 1) & 1);
+                const int qv = q8_round(v[h], sc.scale);
+                out_frag[(((size_t)blockIdx.x * RT + wid) * 64 + (kp >> 3) * 16 + (r & 15)) * 8 + (kp & 7)] = f2h((float)qv * sc.ddeq);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same for Q8 WEIGHTS (round 5; SILU: gate | up + chain, !SILU: the lm_head as k_dec_mmvh<Q8, 8, 2, false> at ks = 1 sums it).  A Q8 slice's slab (64 rows x 64 blocks x 32 B + deltas = 139 KB, + the cross-wave sums) does not fit
+// LDS, so the q8 configuration's wide decoders ran gate | up as k_dec_mmvh<Q8, 8, 2, false> in two K planes (352 x 2 workgroups) and
+// the silu . mul chain as a second launch (k_dec_silumul_rows) on the raw sums: 24 us per block and lane at 128 rows against q4's 12.
+// Streamed, nothing has to fit: a K slice is FOUR quant blocks x 64 rows = 512 pieces of 16 bytes (one per thread: row, block, half of
+// the block's 32 quants), expanded to f16(q dw) into a double-buffered 16 KB chunk.  THE SAME SUMS as the pair it replaces, bit for
+// bit: sixteen slices of four blocks -- the eight wave slices of k_dec_mmvh's first plane, then those of the second -- each
+// accumulated in the matrix core from zero, added in order inside their plane, the two plane sums added as k_dec_silumul_rows adds
+// them, then that kernel's chain on the accumulators (tests/test_ffn_streamed_gpu.py).
+template <bool SILU>
+__global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __restrict__ a_ah, const void* __restrict__ w_gate, const void* __restrict__ w_up,
+                                                       uint16_t* __restrict__ out_frag, const int d_in, const int n_ffn, const int S, const int out_cols)
+{
+    // SILU: slices of 4 blocks (two K planes of eight wave slices: k_dec_mmvh<Q8, 8, 2, false> at ks = 2), one piece per thread.
+    // !SILU (the lm_head: 64 consecutive rows of ONE matrix, raw f32 sums out): slices of 8 blocks (ONE plane of eight wave slices,
+    // ks = 1), two pieces per thread.
+    constexpr int RT = 8, NBW = SILU ? 4 : 8, PPT = SILU ? 1 : 2; // row tiles of the lane; quant blocks per K slice; 16-byte pieces per thread and slice
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const int nb = d_in >> 5;
+    uint8_t* xb = g_smem;                                         // [2][NBW][4 tiles][64 lanes][16 B]
+
+    // ---- this thread's pieces of every slice: piece = (weight row rr of the 64, block bc of the slice, half hf of the block's 32 quants)
+    unsigned qoff[PPT], doff[PPT];
+    const PackedW pwg = packed_view(w_gate, GTEN_Q8, n_ffn, d_in), pwu = packed_view(SILU ? w_up : w_gate, GTEN_Q8, n_ffn, d_in);
+    const bool up_rows = SILU && (threadIdx.x >> 8) != 0;         // (SILU: pieces of tiles 2, 3 -- rows 32 .. 63 of the 64 -- come from w_up)
+    const uint8_t* qbase = up_rows ? pwu.qs : pwg.qs;
+    const uint8_t* dbase = (const uint8_t*)(up_rows ? pwu.ds : pwg.ds);
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+        const int p = (int)threadIdx.x + 512 * j;
+        const int rr = p / (2 * NBW), bc = (p >> 1) % NBW, hf = p & 1, f_own = rr >> 4, sr = rr & 15;
+        const size_t wrow = SILU ? (size_t)blockIdx.x * 32 + 16 * (f_own & 1) + sr : (size_t)min((int)blockIdx.x * 64 + rr, n_ffn - 1);
+        // a packed Q8 row: the first 16 quants of every block (nb x 16 B), then the last 16 (include/gten_hip.h); deltas apart
+        qoff[j] = (unsigned)wrow * (unsigned)nb * 32u + (unsigned)hf * (unsigned)nb * 16u + (unsigned)bc * 16u;
+        doff[j] = ((unsigned)wrow * (unsigned)nb + (unsigned)bc) * 2u;
+    }
+    uint4 raw[2][PPT];
+    unsigned rawd[2][PPT];
+    auto request_w = [&](int c, int slot) {
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            raw[slot][j] = *(const uint4*)(qbase + (qoff[j] + (unsigned)(c * NBW * 16)));
+            rawd[slot][j] = *(const uint16_t*)(dbase + (doff[j] + (unsigned)(c * NBW * 2)));
+        }
+    };
+    // f16(q dw) of a piece's 16 quants = k-groups 2 hf and 2 hf + 1 of the block's fragments (elements in the order 0 2 1 3 4 6 5 7:
+    // k_dec_mmvh's), placed as in k_dec_ffn_q4
+    auto expand = [&](int slot, int buf) {
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const unsigned d2 = rawd[slot][j] | (rawd[slot][j] << 16);
+            const unsigned src[4] = {raw[slot][j].x, raw[slot][j].y, raw[slot][j].z, raw[slot][j].w};
+            const int p = (int)threadIdx.x + 512 * j, rr = p / (2 * NBW), bc = (p >> 1) % NBW, hf = p & 1, f_own = rr >> 4, sr = rr & 15;
+            uint8_t* base = xb + (size_t)buf * (NBW * 4 * 1024) + (size_t)(bc * 4 + f_own) * 1024 + (size_t)((sr ^ bc) & 15) * 16 + (size_t)hf * 512;
+#pragma unroll
+            for (int gg = 0; gg < 2; gg++) {
+                const unsigned x = src[gg * 2], y = src[gg * 2 + 1];
+                uint4 u;
+                u.x = mmvh_scale((x & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                u.y = mmvh_scale(((x >> 8) & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                u.z = mmvh_scale((y & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                u.w = mmvh_scale(((y >> 8) & 0x00ff00ffu) ^ 0x64806480u, 1152.0f, d2);
+                *(uint4*)(base + gg * 256) = u;
+            }
+        }
+    };
+    const unsigned aoff = (unsigned)lane * 16u + (unsigned)wid * 1024u;      // this wave's activation fragments: row tile `wid`, 1 KB per block
+    uint4 aw[NBW];
+    request_w(0, 0);
+#pragma unroll
+    for (int k = 0; k < NBW; k++) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(k * RT * 1024)));
+    request_w(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    expand(0, 0);
+    __syncthreads();
+
+    mmvh_f4 total[2][4], tot[4];                                  // [K plane of k_dec_mmvh][feature tile]; the running plane
+#pragma unroll
+    for (int f = 0; f < 4; f++) tot[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
+    constexpr int n_slices = 64 / NBW;                            // (d_in = 2048: the launcher selects this kernel for that width only)
+    // one slice: LAST = nothing behind it to expand / request (compile-time: no branch around a request); c may be a run-time value
+    auto slice = [&](const int c, const int cur, auto more1, auto more2) {
+        constexpr bool MORE1 = decltype(more1)::value, MORE2 = decltype(more2)::value;
+        if (MORE1) {
+            expand(cur ^ 1, cur ^ 1);                             // slice c + 1 -> the buffer slice c - 1 was read from
+            if (MORE2) request_w(c + 2, cur);
+        }
+        mmvh_f4 acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) acc[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
+        const uint8_t* rb = xb + (size_t)cur * (NBW * 4 * 1024) + (size_t)g * 256;
+#pragma unroll
+        for (int k = 0; k < NBW; k++) {
+            mmvh_h8 ah;
+            __builtin_memcpy(&ah, &aw[k], 16);
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                mmvh_h8 bh;
+                const uint4 b = *(const uint4*)(rb + (size_t)(k * 4 + f) * 1024 + (size_t)((l16 ^ k) & 15) * 16);
+                __builtin_memcpy(&bh, &b, 16);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[f], 0, 0, 0);
+            }
+            if (MORE1) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(((c + 1) * NBW + k) * RT * 1024)));
+        }
+        // the slice sums join their PLANE's running total in slice order (k_dec_mmvh's wave order inside a K plane)
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) tot[f][i] = tot[f][i] + acc[f][i];
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    // slices 0 .. 13 in pairs (the two LDS buffers and register slots alternate), 14 and 15 peeled; the plane changes behind slice 7
+#pragma unroll 1
+    for (int c2 = 0; c2 < n_slices - 2; c2 += 2) {
+        slice(c2, 0, T{}, T{});
+        slice(c2 + 1, 1, T{}, T{});
+        if (SILU && c2 == 6) {                                    // (the second K plane starts from zero)
+#pragma unroll
+            for (int f = 0; f < 4; f++) { total[0][f] = tot[f]; tot[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f}; }
+        }
+    }
+    slice(n_slices - 2, 0, T{}, F{});
+    slice(n_slices - 1, 1, F{}, F{});
+#pragma unroll
+    for (int f = 0; f < 4; f++) total[1][f] = tot[f];
+    if (!SILU) {
+        // lane (l16, g): rows 16 wid + 4 g + i, columns 64 blockIdx.x + 16 f + l16 (one K plane: the eight slice sums as they stand)
+        float* out = (float*)out_frag;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int col = (int)blockIdx.x * 64 + 16 * f + l16;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 16 * wid + 4 * g + i;
+                if (r < S && col < n_ffn) out[(size_t)r * out_cols + col] = total[1][f][i];
+            }
+        }
+        return;
+    }
+    // ---- k_dec_silumul_rows on the accumulators: plane 0 + plane 1, then the chain of k_dec_ffn_q4's epilogue
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float tg[2], tu[2], gv[2], uv[2], v[2];
+        tg[0] = total[0][0][i] + total[1][0][i]; tg[1] = total[0][1][i] + total[1][1][i];
+        tu[0] = total[0][2][i] + total[1][2][i]; tu[1] = total[0][3][i] + total[1][3][i];
+        {
+            const Q8Scale s = q8_scale_from_absmax(ffn_row16_max(fmaxf(fabsf(tg[0]), fabsf(tg[1]))));                   // gate projection written
+            gv[0] = (float)q8_round(tg[0], s.scale) * s.ddeq; gv[1] = (float)q8_round(tg[1], s.scale) * s.ddeq;
+        }
+        {
+            const float s0 = gv[0] / (1.0f + expf(-gv[0])), s1 = gv[1] / (1.0f + expf(-gv[1]));                         // silu in place
+            const Q8Scale s = q8_scale_from_absmax(ffn_row16_max(fmaxf(fabsf(s0), fabsf(s1))));
+            gv[0] = (float)q8_round(s0, s.scale) * s.ddeq; gv[1] = (float)q8_round(s1, s.scale) * s.ddeq;
+        }
+        {
+            const Q8Scale s = q8_scale_from_absmax(ffn_row16_max(fmaxf(fabsf(tu[0]), fabsf(tu[1]))));                   // up projection written
+            uv[0] = (float)q8_round(tu[0], s.scale) * s.ddeq; uv[1] = (float)q8_round(tu[1], s.scale) * s.ddeq;
         }
         v[0] = gv[0] * uv[0]; v[1] = gv[1] * uv[1];                                                                      // mul in place, then written:
         const Q8Scale sc = q8_scale_from_absmax(ffn_row16_max(fmaxf(fabsf(v[0]), fabsf(v[1]))));
