@@ -2,7 +2,8 @@
 k_dec_mmvh<Q4, 8, 4, ..>: the same f16 operands, the same eight K slices accumulated in the matrix core from zero and added in the
 same order -- so not a band but THE SAME BITS, for every sequence of one lane (128) and of two (256).  q8 weights: gate | up + the
 silu . mul chain as ONE streamed launch (k_dec_ffn_q8) against the k_dec_mmvh<Q8, 8, 2, false> + k_dec_silumul_rows pair (two K planes
-of eight wave slices): the same bits again."""
+of eight wave slices): the same bits again.  64 sequences (four row tiles): the same kernels with waves 4 .. 7 expanding weights only,
+against k_dec_mmvh<.., 4, ..>."""
 import numpy as np
 import pytest
 
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("wd", [Q4, Q8])
-@pytest.mark.parametrize("n_seq", [128, 256])
+@pytest.mark.parametrize("n_seq", [64, 128, 256])
 def test_streamed_gate_up_equals_the_slab_kernel_bit_for_bit(hip, n_seq, wd):
     pkg = load_package()
     host = pkg.load_host()

@@ -761,7 +761,7 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
         if (a.n_mats == 1 && ks == 1 && cols >= 16384 && g_ffn_streamed && a.S == 128 && a.d_in == 2048) {
             // ... and as the streamed kernel of gten_decode_ffn.h (the same sums): no cross-wave sum, the weights slice by slice
             DEC_LAUNCH(tag, k_dec_ffn_q4<false>, dim3((cols + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, a.ah, a.w[0], a.w[0], (uint16_t*)a.out, a.d_in,
-                       a.d_out[0], a.S, a.out_cols);
+                       a.d_out[0], a.S, a.out_cols, 8);
             return 0;
         }
         if (a.n_mats == 1 && ks == 1 && cols >= 16384 && ppr <= 32 * (MMV_MAXP / 4)) {
@@ -776,7 +776,20 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
         if (a.n_mats == 1 && ks == 1 && cols >= 16384 && g_ffn_streamed && a.S == 128 && a.d_in == 2048) {
             // q8 lm_head of a full lane: streamed, the sums of the two-tile launch below (one K plane of eight wave slices)
             DEC_LAUNCH(tag, k_dec_ffn_q8<false>, dim3((cols + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, a.ah, a.w[0], a.w[0], (uint16_t*)a.out, a.d_in,
-                       a.d_out[0], a.S, a.out_cols);
+                       a.d_out[0], a.S, a.out_cols, 8);
+            return 0;
+        }
+    }
+    // ... and of a lane of four row tiles (49 .. 64 sequences): the same kernels, waves 4 .. 7 only expand weights (the sums of the
+    // k_dec_mmvh launch below: one K plane of eight wave slices)
+    if constexpr (RT == 4 && (WT == GTEN_Q4 || WT == GTEN_Q8)) {
+        if (a.n_mats == 1 && ks == 1 && cols >= 16384 && g_ffn_streamed && a.d_in == 2048) {
+            if constexpr (WT == GTEN_Q4)
+                DEC_LAUNCH(tag, (k_dec_ffn_q4<false, true>), dim3((cols + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, a.ah, a.w[0], a.w[0], (uint16_t*)a.out,
+                           a.d_in, a.d_out[0], a.S, a.out_cols, 4);
+            else
+                DEC_LAUNCH(tag, (k_dec_ffn_q8<false, true>), dim3((cols + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, a.ah, a.w[0], a.w[0], (uint16_t*)a.out,
+                           a.d_in, a.d_out[0], a.S, a.out_cols, 4);
             return 0;
         }
     }
@@ -801,7 +814,11 @@ static int launch_mmvh_silu(int tag, const uint16_t* ah, const void* wgate, cons
     GTR_REQUIRE(smem <= 150 * 1024 && nbs * (WQ == GTEN_Q4 ? 1 : 2) <= (size_t)32 * (MMV_MAXP / 4), "decoder: the FFN slab of d_in %d does not fit", d_in);
     // full 128-row lanes at K = 2048, q4: the streamed form (gten_decode_ffn.h) -- the same sums bit for bit, 15.1 -> 12.2 us per launch
     if (WQ == GTEN_Q4 && g_ffn_streamed && rt == 8 && S == 128 && d_in == 2048) {
-        DEC_LAUNCH(tag, k_dec_ffn_q4<true>, dim3(n_ffn / 32), dim3(512), (size_t)2 * 8 * 4 * 1024, ah, wgate, wup, out_frag, d_in, n_ffn, S, 0);
+        DEC_LAUNCH(tag, k_dec_ffn_q4<true>, dim3(n_ffn / 32), dim3(512), (size_t)2 * 8 * 4 * 1024, ah, wgate, wup, out_frag, d_in, n_ffn, S, 0, 8);
+        return 0;
+    }
+    if (WQ == GTEN_Q4 && g_ffn_streamed && rt == 4 && d_in == 2048) {          // four row tiles: waves 4 .. 7 only expand weights
+        DEC_LAUNCH(tag, (k_dec_ffn_q4<true, true>), dim3(n_ffn / 32), dim3(512), (size_t)2 * 8 * 4 * 1024, ah, wgate, wup, out_frag, d_in, n_ffn, S, 0, 4);
         return 0;
     }
     const MmvRest rest{wup, nullptr, n_ffn, 0, 0};
@@ -851,9 +868,12 @@ static int mmvh_prepare()
     if (WT == GTEN_Q4) {
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
     }
     if (WT == GTEN_Q8) {
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_q8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
     }
     return 0;
 }
@@ -1020,7 +1040,10 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
             // q8 weights, a full 128-row lane: gate | up and the silu . mul chain as ONE streamed launch (gten_decode_ffn.h) -- the bits of the
             // k_dec_mmvh<Q8, 8, 2, false> + k_dec_silumul_rows pair below (two K planes of eight wave slices each)
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_ffn_q8<true>, dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, L.wgate, L.wup,
-                       (uint16_t*)b.act_q, E, F, S, 0);
+                       (uint16_t*)b.act_q, E, F, S, 0, 8);
+        } else if (folded && WT == GTEN_Q8 && g_ffn_streamed && (S + 15) / 16 == 4 && E == 2048 && ks_gu == 2 && F % 32 == 0) {
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_ffn_q8<true, true>), dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, L.wgate, L.wup,
+                       (uint16_t*)b.act_q, E, F, S, 0, 4);
         } else {
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, b.stg_q, b.stg_d, b.gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)

@@ -33,11 +33,15 @@ __device__ __forceinline__ float ffn_row16_max(float v)         // maximum over 
 
 // SILU: the FFN slice (32 gate + 32 up rows, the chain in the epilogue, f16 fragments out).  !SILU: 64 consecutive rows of ONE
 // matrix (w_gate; the lm_head), the raw f32 sums out (out_frag = float rows of out_cols floats) -- k_dec_mmvh<Q4, 8, 4, false>'s bits.
-template <bool SILU>
+// PART: a lane of 1 .. 4 row tiles (16 .. 64 sequences; `frt` tiles were staged): waves frt .. 7 expand weights and keep the barriers, the
+// matrix work is the first frt waves' -- the same sums as k_dec_mmvh<Q4, frt, 4, ..> (whose eight waves split K into the same eight slices).
+template <bool SILU, bool PART = false>
 __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __restrict__ a_ah, const void* __restrict__ w_gate, const void* __restrict__ w_up,
-                                                       uint16_t* __restrict__ out_frag, const int d_in, const int n_ffn, const int S, const int out_cols)
+                                                       uint16_t* __restrict__ out_frag, const int d_in, const int n_ffn, const int S, const int out_cols, const int frt)
 {
-    constexpr int RT = 8, NBW = 8;                                // row tiles of the lane; quant blocks per K slice (d_in = 2048: 64 blocks = 8 slices)
+    constexpr int NBW = 8;                                        // quant blocks per K slice (d_in = 2048: 64 blocks = 8 slices)
+    const int RT = PART ? frt : 8;                                // row tiles of the lane = the fragment stride of the staging
+    const bool rows = !PART || (int)(threadIdx.x >> 6) < frt;     // (uniform per wave) this wave owns a row tile
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int nb = d_in >> 5;
     uint8_t* xb = g_smem;                                         // [2][NBW][4 tiles][64 lanes][16 B]: expanded weight fragments of a slice
@@ -80,8 +84,10 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
     //  176 workgroups each, then run side by side instead of in two rounds)
     uint4 aw[NBW];
     request_w(0, 0);
+    if (rows) {
 #pragma unroll
-    for (int k = 0; k < NBW; k++) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(k * RT * 1024)));
+        for (int k = 0; k < NBW; k++) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(k * RT * 1024)));
+    }
     request_w(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     expand(0, 0);
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
             expand(cur ^ 1, cur ^ 1);                             // slice c + 1 -> the buffer slice c - 1 was read from (every wave is past the barrier behind it)
             if (MORE2) request_w(c + 2, cur);
         }
+        if (rows) {
         mmvh_f4 acc[4];
 #pragma unroll
         for (int f = 0; f < 4; f++) acc[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
         for (int f = 0; f < 4; f++)
 #pragma unroll
             for (int i = 0; i < 4; i++) total[f][i] = total[f][i] + acc[f][i];
+        }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);                        // (nothing of the next slice is scheduled into this one: registers)
     };
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
         slice(n_slices - 1, 1, N{}, N{});
     }
 
+    if (!rows) return;
     if (!SILU) {
         // lane (l16, g): rows 16 wid + 4 g + i, columns 64 blockIdx.x + 16 f + l16
         float* out = (float*)out_frag;
@@ -193,14 +202,16 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q4(const uint16_t* __r
 // bit: sixteen slices of four blocks -- the eight wave slices of k_dec_mmvh's first plane, then those of the second -- each
 // accumulated in the matrix core from zero, added in order inside their plane, the two plane sums added as k_dec_silumul_rows adds
 // them, then that kernel's chain on the accumulators (tests/test_ffn_streamed_gpu.py).
-template <bool SILU>
+template <bool SILU, bool PART = false>
 __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __restrict__ a_ah, const void* __restrict__ w_gate, const void* __restrict__ w_up,
-                                                       uint16_t* __restrict__ out_frag, const int d_in, const int n_ffn, const int S, const int out_cols)
+                                                       uint16_t* __restrict__ out_frag, const int d_in, const int n_ffn, const int S, const int out_cols, const int frt)
 {
+    const int RT = PART ? frt : 8;                                // row tiles of the lane = the fragment stride of the staging (PART: as k_dec_ffn_q4)
+    const bool rows = !PART || (int)(threadIdx.x >> 6) < frt;     // (uniform per wave) this wave owns a row tile
     // SILU: slices of 4 blocks (two K planes of eight wave slices: k_dec_mmvh<Q8, 8, 2, false> at ks = 2), one piece per thread.
     // !SILU (the lm_head: 64 consecutive rows of ONE matrix, raw f32 sums out): slices of 8 blocks (ONE plane of eight wave slices,
     // ks = 1), two pieces per thread.
-    constexpr int RT = 8, NBW = SILU ? 4 : 8, PPT = SILU ? 1 : 2; // row tiles of the lane; quant blocks per K slice; 16-byte pieces per thread and slice
+    constexpr int NBW = SILU ? 4 : 8, PPT = SILU ? 1 : 2;         // quant blocks per K slice; 16-byte pieces per thread and slice
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int nb = d_in >> 5;
     uint8_t* xb = g_smem;                                         // [2][NBW][4 tiles][64 lanes][16 B]
@@ -253,8 +264,10 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __r
     const unsigned aoff = (unsigned)lane * 16u + (unsigned)wid * 1024u;      // this wave's activation fragments: row tile `wid`, 1 KB per block
     uint4 aw[NBW];
     request_w(0, 0);
+    if (rows) {
 #pragma unroll
-    for (int k = 0; k < NBW; k++) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(k * RT * 1024)));
+        for (int k = 0; k < NBW; k++) aw[k] = *(const uint4*)((const uint8_t*)a_ah + (aoff + (unsigned)(k * RT * 1024)));
+    }
     request_w(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     expand(0, 0);
@@ -271,6 +284,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __r
             expand(cur ^ 1, cur ^ 1);                             // slice c + 1 -> the buffer slice c - 1 was read from
             if (MORE2) request_w(c + 2, cur);
         }
+        if (rows) {
         mmvh_f4 acc[4];
 #pragma unroll
         for (int f = 0; f < 4; f++) acc[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __r
         for (int f = 0; f < 4; f++)
 #pragma unroll
             for (int i = 0; i < 4; i++) tot[f][i] = tot[f][i] + acc[f][i];
+        }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __r
     slice(n_slices - 1, 1, F{}, F{});
 #pragma unroll
     for (int f = 0; f < 4; f++) total[1][f] = tot[f];
+    if (!rows) return;
     if (!SILU) {
         // lane (l16, g): rows 16 wid + 4 g + i, columns 64 blockIdx.x + 16 f + l16 (one K plane: the eight slice sums as they stand)
         float* out = (float*)out_frag;
