@@ -137,8 +137,9 @@ int gten_hip_set_decode_exact(int on);
  * not possible through this interface; a caller that writes cache rows with its own kernels restarts the sequence --
  * slot_start / step at another position / generate_multi -- to the same effect). */
 int gten_hip_set_kv_head_major(int on);
-/* gate | up of a full 128-row lane (q4, K = 2048) as the streamed kernel of csrc/gten_decode_ffn.h (on != 0, the default) or as
- * k_dec_mmvh like every other shape (0): the same sums bit for bit (tests/test_ffn_streamed_gpu.py), a launch-structure switch only.
+/* gate | up (with the silu . mul chain) and the lm_head of lanes of 49-64 or 128 rows (q4 / q8 weights, K = 2048) as the streamed
+ * kernels of csrc/gten_decode_ffn.h (on != 0, the default) or as k_dec_mmvh (+ k_dec_silumul_rows for q8) like every other shape
+ * (0): the same sums bit for bit (tests/test_ffn_streamed_gpu.py), a launch-structure switch only.
  * Takes effect for steps enqueued or captured afterwards. */
 int gten_hip_set_ffn_streamed(int on);
 /* host-only self-test of the registry behind that guarantee (which ranges are watched, which writes hit them, whose flag is
