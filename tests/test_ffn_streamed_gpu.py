@@ -3,26 +3,26 @@ k_dec_mmvh<Q4, 8, 4, ..>: the same f16 operands, the same eight K slices accumul
 same order -- so not a band but THE SAME BITS, for every sequence of one lane (128) and of two (256).  q8 weights: gate | up + the
 silu . mul chain as ONE streamed launch (k_dec_ffn_q8) against the k_dec_mmvh<Q8, 8, 2, false> + k_dec_silumul_rows pair (two K planes
 of eight wave slices): the same bits again.  64 sequences (four row tiles): the same kernels with waves 4 .. 7 expanding weights only,
-against k_dec_mmvh<.., 4, ..>."""
+against k_dec_mmvh<.., 4, ..>.  f16 weights and activations (lanes of 64 rows): k_dec_ffn_f16 against k_dec_mmv_f16 + k_dec_silumul_rows_f16."""
 import numpy as np
 import pytest
 
 from gpu_common import hip  # noqa: F401
 from __graft_entry__ import load_package
-from helpers import Q4, Q8, tiny_config
+from helpers import F16, Q4, Q8, tiny_config
 from test_model_gpu import host_cfg
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("wd", [Q4, Q8])
+@pytest.mark.parametrize("wd", [Q4, Q8, F16])
 @pytest.mark.parametrize("n_seq", [64, 128, 256])
 def test_streamed_gate_up_equals_the_slab_kernel_bit_for_bit(hip, n_seq, wd):
     pkg = load_package()
     host = pkg.load_host()
     # the kernel is selected at K = 2048 (TinyLlama's width) -- for the lm_head from 16 384 columns up (a ragged last tile here);
     # a narrow FFN and two blocks keep the model small
-    cfg = host_cfg(tiny_config(wd, Q8, n_embd=2048, n_heads=32, n_kv_heads=4, n_ffn=768, n_layers=2, n_vocab=16403, max_ctx=64))
+    cfg = host_cfg(tiny_config(wd, F16 if wd == F16 else Q8, n_embd=2048, n_heads=32, n_kv_heads=4, n_ffn=768, n_layers=2, n_vocab=16403, max_ctx=64))
     weights = [host.synth_weight(cfg, 31, i) for i in range(len(cfg.weight_shapes()))]
     streams = [host.synthetic_tokens(40, seed=7000 + q, n_vocab=cfg.n_vocab) for q in range(n_seq)]
     out = []

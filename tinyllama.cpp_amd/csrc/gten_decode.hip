@@ -1044,6 +1044,11 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         } else if (folded && WT == GTEN_Q8 && g_ffn_streamed && (S + 15) / 16 == 4 && E == 2048 && ks_gu == 2 && F % 32 == 0) {
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_ffn_q8<true, true>), dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, L.wgate, L.wup,
                        (uint16_t*)b.act_q, E, F, S, 0, 4);
+        } else if (WT == GTEN_F16 && g_ffn_streamed && (S + 15) / 16 == 4 && E % 256 == 0 && (E / 128) % 2 == 0 && ks_gu == 2 && F % 32 == 0) {
+            // f16: gate | up and the chain of a lane of four row tiles as one streamed launch (gten_decode_ffn.h) -- the bits of the
+            // k_dec_mmv_f16 + k_dec_silumul_rows_f16 pair below
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_ffn_f16, dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, (const uint16_t*)L.wgate,
+                       (const uint16_t*)L.wup, (uint16_t*)b.act_q, E, F, S, 4);
         } else {
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, b.stg_q, b.stg_d, b.gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)

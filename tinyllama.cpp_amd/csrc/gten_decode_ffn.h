@@ -374,3 +374,120 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __r
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// f16 WEIGHTS x f16 ACTIVATIONS (the f16 configuration's wide decoders run lanes of 64 rows; round 5): gate | up and the silu . mul chain
+// as one streamed launch in place of k_dec_mmv_f16 (704 workgroups of 16 features in two K planes, every one of them reading all the
+// lane's activation rows) + k_dec_silumul_rows_f16.  Nothing to expand: a K slice is four 32-element steps x 64 weight rows = 1024
+// pieces of 16 bytes (two per thread: row, step, k-group -- 256 contiguous bytes per row), COPIED into the double-buffered chunk in
+// matrix-operand order; a wave's activation fragment is 16 bytes of its row tile's f16 rows (k_dec_mmv_f16's operands, natural element
+// order).  THE SAME SUMS as the pair, bit for bit: sixteen slices of four steps -- the eight wave ranges of k_dec_mmv_f16's first K
+// plane, then the second's -- each accumulated in the matrix core from zero, added in order inside their plane; then
+// k_dec_silumul_rows_f16's arithmetic per element (plane 0 + plane 1, rounded to f16 where the modules store: gate, silu, up, product).
+// `frt` row tiles (1 .. 4: the f16 lanes are 64 rows): waves frt .. 7 copy weights and keep the barriers.
+__global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_f16(const uint16_t* __restrict__ a_h, const uint16_t* __restrict__ w_gate, const uint16_t* __restrict__ w_up,
+                                                        uint16_t* __restrict__ out_h, const int d_in, const int n_ffn, const int S, const int frt)
+{
+    constexpr int NBW = 4, PPT = 2;                               // 32-element steps per K slice; 16-byte pieces per thread and slice
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
+    const bool rows = wid < frt;                                  // (uniform per wave) this wave owns a row tile
+    uint8_t* xb = g_smem;                                         // [2][NBW][4 tiles][4 k-groups][16 columns][16 B]
+
+    // ---- this thread's pieces of every slice: piece p = (weight row p / 16 of the 64, step (p / 4) % 4, k-group p % 4); threadIdx.x + 512 j:
+    //      the first piece is a gate row's (tiles 0, 1), the second an up row's (tiles 2, 3)
+    const int rr0 = threadIdx.x >> 4, bc = (threadIdx.x >> 2) & 3, gg = threadIdx.x & 3, sr = rr0 & 15;
+    const unsigned woff = (unsigned)(((size_t)blockIdx.x * 32 + rr0) * d_in + bc * 32 + gg * 8) * 2u;       // (bytes; gate and up rows alike)
+    const unsigned dst0 = (unsigned)((bc * 4 + (rr0 >> 4)) * 1024 + gg * 256 + ((sr ^ bc) & 15) * 16);
+    uint4 rg0, ru0, rg1, ru1;                                     // two register sets (named: an array of them went to scratch)
+    auto request_w = [&](int c, auto slot) {
+        const uint4 a = *(const uint4*)((const uint8_t*)w_gate + (woff + (unsigned)(c * (NBW * 64))));
+        const uint4 b = *(const uint4*)((const uint8_t*)w_up + (woff + (unsigned)(c * (NBW * 64))));
+        if constexpr (decltype(slot)::value == 0) { rg0 = a; ru0 = b; } else { rg1 = a; ru1 = b; }
+    };
+    auto place = [&](auto slot) {                                 // slot s -> LDS buffer s
+        constexpr int SL = decltype(slot)::value;
+        *(uint4*)(xb + (size_t)SL * (NBW * 4 * 1024) + dst0) = SL == 0 ? rg0 : rg1;
+        *(uint4*)(xb + (size_t)SL * (NBW * 4 * 1024) + dst0 + 2048) = SL == 0 ? ru0 : ru1;       // (tiles 2, 3)
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // ---- this wave's activation fragments: rows 16 wid + l16, elements 32 step + 8 g .. + 7 (k_dec_mmv_f16's A operand)
+    const uint8_t* arow = (const uint8_t*)(a_h + (size_t)(16 * wid + l16) * d_in + 8 * g);
+    uint4 aw[NBW];
+    request_w(0, I0{});
+    if (rows) {
+#pragma unroll
+        for (int k = 0; k < NBW; k++) aw[k] = *(const uint4*)(arow + (size_t)k * 64);
+    }
+    request_w(1, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    place(I0{});
+    __syncthreads();
+
+    mmvh_f4 total[2][4], tot[4];                                  // [K plane of k_dec_mmv_f16][feature tile]; the running plane
+#pragma unroll
+    for (int f = 0; f < 4; f++) tot[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
+    const int n_slices = d_in / (32 * NBW);                       // (2048: sixteen; the launcher requires two planes of eight)
+    auto slice = [&](const int c, auto curc, auto more1, auto more2) {
+        constexpr bool MORE1 = decltype(more1)::value, MORE2 = decltype(more2)::value;
+        constexpr int cur = decltype(curc)::value;
+        if (MORE1) {
+            place(std::integral_constant<int, cur ^ 1>{});
+            if (MORE2) request_w(c + 2, curc);
+        }
+        if (rows) {
+            mmvh_f4 acc[4];
+#pragma unroll
+            for (int f = 0; f < 4; f++) acc[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f};
+            const uint8_t* rb = xb + (size_t)cur * (NBW * 4 * 1024) + (size_t)g * 256;
+#pragma unroll
+            for (int k = 0; k < NBW; k++) {
+                mmvh_h8 ah;
+                __builtin_memcpy(&ah, &aw[k], 16);
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    mmvh_h8 bh;
+                    const uint4 b = *(const uint4*)(rb + (size_t)(k * 4 + f) * 1024 + (size_t)((l16 ^ k) & 15) * 16);
+                    __builtin_memcpy(&bh, &b, 16);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[f], 0, 0, 0);
+                }
+                if (MORE1) aw[k] = *(const uint4*)(arow + (size_t)((c + 1) * NBW + k) * 64);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) tot[f][i] = tot[f][i] + acc[f][i];
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        using Y = std::true_type;
+        using N = std::false_type;
+#pragma unroll 1
+        for (int c2 = 0; c2 < n_slices - 2; c2 += 2) {
+            slice(c2, I0{}, Y{}, Y{});
+            slice(c2 + 1, I1{}, Y{}, Y{});
+            if (c2 + 2 == n_slices / 2) {                         // (the second K plane starts from zero)
+#pragma unroll
+                for (int f = 0; f < 4; f++) { total[0][f] = tot[f]; tot[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f}; }
+            }
+        }
+        slice(n_slices - 2, I0{}, Y{}, N{});
+        slice(n_slices - 1, I1{}, N{}, N{});
+    }
+    if (!rows) return;
+    // ---- k_dec_silumul_rows_f16 on the accumulators: lane (l16, g) holds rows 16 wid + 4 g + i, feature 32 blockIdx.x + 16 h + l16 as gate
+    //      (tile h) and up (tile 2 + h)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = 16 * wid + 4 * g + i;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float gt = h2f(f2h(total[0][h][i] + tot[h][i]));
+            gt = h2f(f2h(gt / (1.0f + expf(-gt))));
+            const float ut = h2f(f2h(total[0][2 + h][i] + tot[2 + h][i]));
+            if (r < S) out_h[(size_t)r * n_ffn + (size_t)blockIdx.x * 32 + 16 * h + l16] = f2h(gt * ut);
+        }
+    }
+}
