@@ -914,6 +914,17 @@ static int launch_mmv(int tag, const MmvArgs& a)
     GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && a.S <= 64, "decoder: skinny W.x wants d_in %% 256 == 0 and <= 64 rows");
     if (WT == GTEN_F16) {
         for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
+        // the lm_head of a lane of four row tiles: streamed, 64 features per workgroup (gten_decode_ffn.h) -- the sums of k_dec_mmv_f16<4> at ks = 1
+        if (g_ffn_streamed && a.n_mats == 1 && a.ks <= 1 && a.d_out[0] >= 16384 && a.d_in == 2048 && (a.S + 15) / 16 == 4) {
+            static bool attr = false;
+            if (!attr) {
+                GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
+                attr = true;
+            }
+            DEC_LAUNCH(tag, k_dec_ffn_f16<false>, dim3((a.d_out[0] + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, (const uint16_t*)a.aq, (const uint16_t*)a.w[0],
+                       (const uint16_t*)a.w[0], (uint16_t*)a.out, a.d_in, a.d_out[0], a.S, 4, a.out_cols);
+            return 0;
+        }
         switch ((a.S + 15) / 16) {
         case 1: return launch_mmv_f16_rt<1>(tag, a);
         case 2: return launch_mmv_f16_rt<2>(tag, a);
@@ -1047,8 +1058,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         } else if (WT == GTEN_F16 && g_ffn_streamed && (S + 15) / 16 == 4 && E % 256 == 0 && (E / 128) % 2 == 0 && ks_gu == 2 && F % 32 == 0) {
             // f16: gate | up and the chain of a lane of four row tiles as one streamed launch (gten_decode_ffn.h) -- the bits of the
             // k_dec_mmv_f16 + k_dec_silumul_rows_f16 pair below
-            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_ffn_f16, dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, (const uint16_t*)L.wgate,
-                       (const uint16_t*)L.wup, (uint16_t*)b.act_q, E, F, S, 4);
+            DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_ffn_f16<true>, dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, (const uint16_t*)L.wgate,
+                       (const uint16_t*)L.wup, (uint16_t*)b.act_q, E, F, S, 4, 0);
         } else {
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, b.stg_q, b.stg_d, b.gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)

@@ -385,29 +385,41 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_q8(const uint16_t* __r
 // plane, then the second's -- each accumulated in the matrix core from zero, added in order inside their plane; then
 // k_dec_silumul_rows_f16's arithmetic per element (plane 0 + plane 1, rounded to f16 where the modules store: gate, silu, up, product).
 // `frt` row tiles (1 .. 4: the f16 lanes are 64 rows): waves frt .. 7 copy weights and keep the barriers.
+template <bool SILU>
 __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_f16(const uint16_t* __restrict__ a_h, const uint16_t* __restrict__ w_gate, const uint16_t* __restrict__ w_up,
-                                                        uint16_t* __restrict__ out_h, const int d_in, const int n_ffn, const int S, const int frt)
+                                                        uint16_t* __restrict__ out_h, const int d_in, const int n_ffn, const int S, const int frt, const int out_cols)
 {
-    constexpr int NBW = 4, PPT = 2;                               // 32-element steps per K slice; 16-byte pieces per thread and slice
+    // SILU: slices of 4 steps (two K planes of eight wave ranges: k_dec_mmv_f16 at ks = 2), rows 0 .. 31 of the 64 from w_gate, 32 .. 63 from
+    // w_up.  !SILU (the lm_head: 64 consecutive rows of ONE matrix, raw f32 sums out): slices of 8 steps (ONE plane, ks = 1).
+    constexpr int NBW = SILU ? 4 : 8, PPT = NBW / 2;              // 32-element steps per K slice; 16-byte pieces per thread and slice
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const bool rows = wid < frt;                                  // (uniform per wave) this wave owns a row tile
     uint8_t* xb = g_smem;                                         // [2][NBW][4 tiles][4 k-groups][16 columns][16 B]
 
-    // ---- this thread's pieces of every slice: piece p = (weight row p / 16 of the 64, step (p / 4) % 4, k-group p % 4); threadIdx.x + 512 j:
-    //      the first piece is a gate row's (tiles 0, 1), the second an up row's (tiles 2, 3)
-    const int rr0 = threadIdx.x >> 4, bc = (threadIdx.x >> 2) & 3, gg = threadIdx.x & 3, sr = rr0 & 15;
-    const unsigned woff = (unsigned)(((size_t)blockIdx.x * 32 + rr0) * d_in + bc * 32 + gg * 8) * 2u;       // (bytes; gate and up rows alike)
-    const unsigned dst0 = (unsigned)((bc * 4 + (rr0 >> 4)) * 1024 + gg * 256 + ((sr ^ bc) & 15) * 16);
-    uint4 rg0, ru0, rg1, ru1;                                     // two register sets (named: an array of them went to scratch)
+    // ---- this thread's pieces of every slice: piece p = threadIdx.x + 512 j = (weight row p / (4 NBW) of the 64, step, k-group): a row's
+    //      4 NBW pieces are one contiguous run.  SILU: rows 0 .. 31 are gate rows (tiles 0, 1), 32 .. 63 up rows (tiles 2, 3).
+    unsigned woff[PPT], dst[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+        const int p = (int)threadIdx.x + 512 * j, rr = p / (4 * NBW), wi = p % (4 * NBW), bc = wi >> 2, gg = wi & 3, f_own = rr >> 4, sr = rr & 15;
+        const size_t wrow = SILU ? (size_t)blockIdx.x * 32 + (rr & 31) : (size_t)min((int)blockIdx.x * 64 + rr, n_ffn - 1);
+        woff[j] = (unsigned)((wrow * d_in + bc * 32 + gg * 8) * 2);                      // (bytes from the matrix)
+        dst[j] = (unsigned)((bc * 4 + f_own) * 1024 + gg * 256 + ((sr ^ bc) & 15) * 16);
+    }
+    uint4 rw0[PPT], rw1[PPT];                                     // two register sets (indexed by compile-time constants only)
     auto request_w = [&](int c, auto slot) {
-        const uint4 a = *(const uint4*)((const uint8_t*)w_gate + (woff + (unsigned)(c * (NBW * 64))));
-        const uint4 b = *(const uint4*)((const uint8_t*)w_up + (woff + (unsigned)(c * (NBW * 64))));
-        if constexpr (decltype(slot)::value == 0) { rg0 = a; ru0 = b; } else { rg1 = a; ru1 = b; }
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            // (SILU: pieces j < PPT / 2 lie in rows 0 .. 31 -- 512 j / (4 NBW) -- the others in rows 32 .. 63)
+            const uint8_t* wm = (const uint8_t*)((SILU && j >= PPT / 2) ? w_up : w_gate);
+            const uint4 v = *(const uint4*)(wm + (woff[j] + (unsigned)(c * (NBW * 64))));
+            if constexpr (decltype(slot)::value == 0) rw0[j] = v; else rw1[j] = v;
+        }
     };
     auto place = [&](auto slot) {                                 // slot s -> LDS buffer s
         constexpr int SL = decltype(slot)::value;
-        *(uint4*)(xb + (size_t)SL * (NBW * 4 * 1024) + dst0) = SL == 0 ? rg0 : rg1;
-        *(uint4*)(xb + (size_t)SL * (NBW * 4 * 1024) + dst0 + 2048) = SL == 0 ? ru0 : ru1;       // (tiles 2, 3)
+#pragma unroll
+        for (int j = 0; j < PPT; j++) *(uint4*)(xb + (size_t)SL * (NBW * 4 * 1024) + dst[j]) = SL == 0 ? rw0[j] : rw1[j];
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_f16(const uint16_t* __
         for (int c2 = 0; c2 < n_slices - 2; c2 += 2) {
             slice(c2, I0{}, Y{}, Y{});
             slice(c2 + 1, I1{}, Y{}, Y{});
-            if (c2 + 2 == n_slices / 2) {                         // (the second K plane starts from zero)
+            if (SILU && c2 + 2 == n_slices / 2) {                 // (the second K plane starts from zero)
 #pragma unroll
                 for (int f = 0; f < 4; f++) { total[0][f] = tot[f]; tot[f] = (mmvh_f4){0.f, 0.f, 0.f, 0.f}; }
             }
@@ -477,6 +489,20 @@ __global__ __launch_bounds__(512, FFN_OCC) void k_dec_ffn_f16(const uint16_t* __
         slice(n_slices - 1, I1{}, N{}, N{});
     }
     if (!rows) return;
+    if (!SILU) {
+        // lane (l16, g): rows 16 wid + 4 g + i, columns 64 blockIdx.x + 16 f + l16 (one K plane: the eight range sums as they stand)
+        float* out = (float*)out_h;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int col = (int)blockIdx.x * 64 + 16 * f + l16;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 16 * wid + 4 * g + i;
+                if (r < S && col < n_ffn) out[(size_t)r * out_cols + col] = tot[f][i];
+            }
+        }
+        return;
+    }
     // ---- k_dec_silumul_rows_f16 on the accumulators: lane (l16, g) holds rows 16 wid + 4 g + i, feature 32 blockIdx.x + 16 h + l16 as gate
     //      (tile h) and up (tile 2 + h)
 #pragma unroll
