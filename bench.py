@@ -1031,15 +1031,15 @@ def worker(args, rank, local_rank, world, dist):
             # round 3: 256 sequences in ONE decoder -- lanes of 128 (f16: 64), each lane's launch chain a parallel branch of the
             # step's graph (round 2 measured the effect with two separate decoders on two streams: multi_stream_wide_x2)
             try:
-                out["multi_stream_lanes"] = multi_stream(256, "one decoder, two lanes of 128 sequences (q8 / q4; f16: four lanes of 64): the lanes' launch "
+                out["multi_stream_lanes"] = multi_stream(256, "one decoder, two lanes of 128 sequences: the lanes' launch "
                                                               "chains are parallel branches of one graph and fill each other's gaps, a lane's W.x workgroups "
                                                               "run eight row tiles per expanded weight fragment; per sequence the bits of a 64-sequence "
                                                               "decoder (tests/test_multiseq_gpu.py); wide attention on head-major K / V shadows (round 5: "
                                                               "csrc/gten_decode_attn_hm.h); 128 / 384 sequences measured 60.4 k / 90.3 k tok/s")
             except Exception as e:
                 out["multi_stream_lanes"] = {"tok_s": None, "note": "lanes leg unavailable: %r" % (e,)}
-            # ... and 512 sequences (four lanes of 128; q8 / q4): 12.5 GB of K / V per step, the weights' share of the bytes below 5 %
-            if args.mode != "f16":
+            # ... and 512 sequences (four lanes of 128): 12.5 GB of K / V per step (f16: 24 GB), the weights' share of the bytes below 5 %
+            if True:
                 try:
                     out["multi_stream_lanes512"] = multi_stream(512, "one decoder, four lanes of 128 sequences: the step is 95 % K / V bytes, read once per step as "
                                                                      "contiguous runs from head-major shadows (k_dec_attn_hm)")

@@ -50,3 +50,35 @@ def test_streamed_gate_up_equals_the_slab_kernel_bit_for_bit(hip, n_seq, wd):
             assert np.isfinite(a).all()
             assert np.array_equal(a, b_), (n_seq, q, float(np.abs(a - b_).max()))
     assert not np.array_equal(out[0][-1][0], out[0][-1][1])          # independent sequences
+
+
+@pytest.mark.parametrize("wd", [Q4, Q8, F16])
+def test_a_lane_of_128_rows_equals_64_sequence_decoders_at_full_width(hip, wd):
+    """at TinyLlama's width every configuration runs lanes of 128 rows (f16 since round 5: k_dec_mmv_f16<8>, k_dec_ffn_f16 on eight waves):
+    per sequence the logits and ids of a 64-sequence decoder holding the same sequences -- the streamed kernels, the eight-tile and the
+    four-tile launches all form a row's sums in the same order"""
+    pkg = load_package()
+    host = pkg.load_host()
+    cfg = host_cfg(tiny_config(wd, F16 if wd == F16 else Q8, n_embd=2048, n_heads=32, n_kv_heads=4, n_ffn=768, n_layers=2, n_vocab=16403, max_ctx=320))
+    weights = [host.synth_weight(cfg, 57, i) for i in range(len(cfg.weight_shapes()))]
+    N = 262
+    streams = [host.synthetic_tokens(N + 2, seed=4200 + q, n_vocab=cfg.n_vocab) for q in range(128)]
+    big = host.batch(cfg, 128)
+    for i, w in enumerate(weights):
+        big.set_weight(i, w)
+    for q in range(128):
+        big.decode_begin(q, streams[q])
+    big.decode_steps(1, N, True)
+    got = [(big.decode_result(q, N), big.logits(q).copy()) for q in range(128)]
+    big.close()
+    for half in range(2):
+        small = host.batch(cfg, 64)
+        for i, w in enumerate(weights):
+            small.set_weight(i, w)
+        for q in range(64):
+            small.decode_begin(q, streams[64 * half + q])
+        small.decode_steps(1, N, True)
+        for q in range(64):
+            ids, lg = got[64 * half + q]
+            assert small.decode_result(q, N) == ids and np.array_equal(small.logits(q), lg), (half, q)
+        small.close()

@@ -265,8 +265,8 @@ def test_multiseq_argument_errors_are_reported(hip):
 @pytest.mark.parametrize("n_seq", [128, 192, 256, 512])
 def test_lanes_equal_separate_64_sequence_decoders(hip, name, wd, ad, n_seq):
     """more than 64 sequences run as LANES -- parallel branches of one graph, each on its sequences' rows of every buffer; lanes
-    of 128 rows (eight row tiles per W.x workgroup) for q8 / q4 at 128, 256, 384, 512 sequences, lanes of 64 for f16 and for
-    192: per sequence the logits and ids of a 64-sequence decoder holding the same sequences, bit for bit, eager and
+    of 128 rows (eight row tiles per W.x workgroup) for q8 / q4 at 128, 256, 384, 512 sequences, lanes of 64 for f16 at this width (at
+    n_embd = 2048 f16 runs lanes of 128 too: tests/test_ffn_streamed_gpu.py) and for 192: per sequence the logits and ids of a 64-sequence decoder holding the same sequences, bit for bit, eager and
     replayed, from n = 1 across the attention chunk boundary, and with the sequences at different positions"""
     if n_seq == 512 and name == "f16":
         pytest.skip("f16 runs lanes of 64: at most 256 sequences")

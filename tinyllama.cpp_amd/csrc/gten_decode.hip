@@ -911,25 +911,27 @@ static int launch_mmv_f16_rt(int tag, const MmvArgs& a)
 template <int WT>
 static int launch_mmv(int tag, const MmvArgs& a)
 {
-    GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && a.S <= 64, "decoder: skinny W.x wants d_in %% 256 == 0 and <= 64 rows");
+    GTR_REQUIRE(a.d_in % 256 == 0 && a.S >= 1 && (a.S <= 64 || (WT == GTEN_F16 && a.S == 128)), "decoder: skinny W.x wants d_in %% 256 == 0 and <= 64 rows (f16: or 128)");
     if (WT == GTEN_F16) {
         for (int k = 0; k + 1 < a.n_mats; k++) GTR_REQUIRE(a.d_out[k] % 16 == 0, "decoder: concatenated matrices must be multiples of 16 wide");
         // the lm_head of a lane of four row tiles: streamed, 64 features per workgroup (gten_decode_ffn.h) -- the sums of k_dec_mmv_f16<4> at ks = 1
-        if (g_ffn_streamed && a.n_mats == 1 && a.ks <= 1 && a.d_out[0] >= 16384 && a.d_in == 2048 && (a.S + 15) / 16 == 4) {
+        const int frt16 = (a.S + 15) / 16;
+        if (g_ffn_streamed && a.n_mats == 1 && a.ks <= 1 && a.d_out[0] >= 16384 && a.d_in == 2048 && (frt16 == 4 || a.S == 128)) {
             static bool attr = false;
             if (!attr) {
                 GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_ffn_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 4 * 1024));
                 attr = true;
             }
             DEC_LAUNCH(tag, k_dec_ffn_f16<false>, dim3((a.d_out[0] + 63) / 64), dim3(512), (size_t)2 * 8 * 4 * 1024, (const uint16_t*)a.aq, (const uint16_t*)a.w[0],
-                       (const uint16_t*)a.w[0], (uint16_t*)a.out, a.d_in, a.d_out[0], a.S, 4, a.out_cols);
+                       (const uint16_t*)a.w[0], (uint16_t*)a.out, a.d_in, a.d_out[0], a.S, frt16, a.out_cols);
             return 0;
         }
         switch ((a.S + 15) / 16) {
         case 1: return launch_mmv_f16_rt<1>(tag, a);
         case 2: return launch_mmv_f16_rt<2>(tag, a);
         case 3: return launch_mmv_f16_rt<3>(tag, a);
-        default: return launch_mmv_f16_rt<4>(tag, a);
+        case 4: return launch_mmv_f16_rt<4>(tag, a);
+        default: return launch_mmv_f16_rt<8>(tag, a);          // a full lane of 128 rows
         }
     }
     GTR_REQUIRE((size_t)16 * (a.d_in / 32) * (WT == GTEN_Q4 ? 16 : 32) <= (size_t)MMV_MAXP * 512 * 16 && (size_t)(a.d_in / 32) * 64 * 4 <= (size_t)MMV_MAXD * 512 * 16,
@@ -1055,11 +1057,11 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         } else if (folded && WT == GTEN_Q8 && g_ffn_streamed && (S + 15) / 16 == 4 && E == 2048 && ks_gu == 2 && F % 32 == 0) {
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, (k_dec_ffn_q8<true, true>), dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, L.wgate, L.wup,
                        (uint16_t*)b.act_q, E, F, S, 0, 4);
-        } else if (WT == GTEN_F16 && g_ffn_streamed && (S + 15) / 16 == 4 && E % 256 == 0 && (E / 128) % 2 == 0 && ks_gu == 2 && F % 32 == 0) {
+        } else if (WT == GTEN_F16 && g_ffn_streamed && ((S + 15) / 16 == 4 || S == 128) && E % 256 == 0 && (E / 128) % 2 == 0 && ks_gu == 2 && F % 32 == 0) {
             // f16: gate | up and the chain of a lane of four row tiles as one streamed launch (gten_decode_ffn.h) -- the bits of the
             // k_dec_mmv_f16 + k_dec_silumul_rows_f16 pair below
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_ffn_f16<true>, dim3(F / 32), dim3(512), (size_t)2 * 4 * 4 * 1024, (const uint16_t*)b.stg_q, (const uint16_t*)L.wgate,
-                       (const uint16_t*)L.wup, (uint16_t*)b.act_q, E, F, S, 4, 0);
+                       (const uint16_t*)L.wup, (uint16_t*)b.act_q, E, F, S, (S + 15) / 16, 0);
         } else {
         if ((rc = mmk(KT_DEC_GEMV_GATEUP, b.stg_q, b.stg_d, b.gu_raw, 2 * F, E, ks_gu, L.wgate, F, L.wup, F))) return rc;
         if (WT == GTEN_F16)
@@ -1231,11 +1233,14 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     dc->persist_on = g_persist_on;
     {
         // Rows per lane: 128 where the folded W.x form runs eight row tiles per workgroup (k_dec_mmvh<.., 8, ..>: every expanded
-        // weight fragment feeds eight matrix instructions and the weights are read once per 128 sequences), else 64 (f16 weights,
-        // the exact forms, 192 sequences).  Per sequence the same bits either way (tests/test_multiseq_gpu.py).  Measured (q4,
+        // weight fragment feeds eight matrix instructions and the weights are read once per 128 sequences), else 64 (the exact forms,
+        // 192 sequences, f16 at other widths).  Per sequence the same bits either way (tests/test_multiseq_gpu.py).  Measured (q4,
         // ctx -> 2048, tok/s): 128 sequences 50.8 k as two lanes of 64, 51.7 k as one of 128; 256 sequences 56.9 k as four
         // lanes of 64, 67.3 k as two of 128; serving 1024 prompts through 128 slots 29.9 k -> 31.5 k new ids/s.
-        const bool can128 = !g_decode_exact && d.wdtype != GTEN_F16 && d.adtype == GTEN_Q8 && n_seq % 128 == 0;
+        // (round 5: f16 weights too, at TinyLlama's width -- k_dec_mmv_f16<8> and the streamed k_dec_ffn_f16 with all eight waves on row tiles:
+        //  256 sequences 5.71 -> 5.38 ms per step as two lanes of 128 instead of four of 64, 128 sequences 3.25 -> 3.17)
+        const bool can128 = !g_decode_exact && n_seq % 128 == 0 &&
+                            ((d.wdtype != GTEN_F16 && d.adtype == GTEN_Q8) || (d.wdtype == GTEN_F16 && d.adtype == GTEN_F16 && d.n_embd == 2048));
         const int lane_rows = can128 ? 128 : 64;
         const int lanes = (n_seq + lane_rows - 1) / lane_rows;
         GTR_REQUIRE(lanes <= DEC_MAX_LANES, "decoder_create: %d sequences need %d lanes of %d (at most %d: f16 weights and the exact forms run lanes of 64)",

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512) void k_dec_mmv_f16(const uint16_t* __restrict_
                                                      const int a_d_in, const int a_d_out0, const int a_out_cols, const int a_S,
                                                      const int a_n_mats, const MmvRest rest)
 {
-    constexpr int SP = 16 * RT, CBK = 4;
+    constexpr int SP = 16 * RT, CBK = RT > 4 ? 2 : 4;         // (eight row tiles: two steps ahead -- the fragments of four would not fit the registers)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     float* red = (float*)g_smem;                              // [8][SP][16]
     int colw = blockIdx.x * 16, colbase = 0, m = 0;
