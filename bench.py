@@ -95,6 +95,7 @@ def parse_args(argv=None):
     ap.add_argument("--lane-skip", action="store_true", help="serving: a shared run leaves out lanes whose slots are all parked (A/B; measured slower)")
     ap.add_argument("--kv-rows", action="store_true", help="wide decoders read the K / V cache rows as they lie (round 4's attention kernel) instead of "
                     "head-major shadows (A/B of csrc/gten_decode_attn_hm.h)")
+    ap.add_argument("--no-wx-planes", action="store_true", help="f16 wide decoders: o and down as k_dec_mmv_f16 in two K planes instead of k_dec_wxp_f16 in eight (A/B)")
     ap.add_argument("--brief", action="store_true", help="only the metric line: no secondary legs, no CPU baseline")
     ap.add_argument("--curve", action="store_true",
                     help="with --gpus N > 1 under this file's own launcher: first run 1, 2, 4, ... < N replicas (brief) and "
@@ -639,6 +640,8 @@ def worker(args, rank, local_rank, world, dist):
         hip = pkg.hipabi.load(local_rank)
         if args.kv_rows:
             hip.set_kv_head_major(False)
+        if args.no_wx_planes:
+            hip.set_wx_planes(False)
         host = pkg.load_host()
         cfg = host.default_config(wd, ad)
         model = host.model(cfg)

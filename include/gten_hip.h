@@ -142,6 +142,12 @@ int gten_hip_set_kv_head_major(int on);
  * (0): the same sums bit for bit (tests/test_ffn_streamed_gpu.py), a launch-structure switch only.
  * Takes effect for steps enqueued or captured afterwards. */
 int gten_hip_set_ffn_streamed(int on);
+/* The o and down projections of f16 decoders of 16+ sequences (fast forms) as EIGHT K planes of 64-feature workgroups
+ * (csrc/gten_decode_wxp.h; on != 0, the default) or as k_dec_mmv_f16 in two planes (0).  The two differ in the association of the f32
+ * sums only (not in any rounding point of the reference); every wide f16 decoder takes the same form, so sequences agree bit for bit
+ * whatever the batch they are decoded in.  Takes effect for steps enqueued or captured afterwards: set it before creating decoders
+ * that are to agree. */
+int gten_hip_set_wx_planes(int on);
 /* host-only self-test of the registry behind that guarantee (which ranges are watched, which writes hit them, whose flag is
  * set): needs no GPU and no gten_hip_init; returns 0 or the number of the first failing case */
 int gten_hip_kv_watch_selftest(void);

@@ -347,6 +347,7 @@ int gten_hip_decoder_slots_apply(gten_hip_decoder* dc, int count, const int* seq
     return 0;
 }
 int gten_hip_set_kv_head_major(int) { return 0; }
+int gten_hip_set_wx_planes(int) { return 0; }
 int gten_hip_set_ffn_streamed(int) { return 0; }
 int gten_hip_kv_watch_selftest(void) { return 0; }
 int gten_hip_decoder_kv_info(gten_hip_decoder* dc, int* head_major, unsigned long long* seq_imports, unsigned long long* import_launches)

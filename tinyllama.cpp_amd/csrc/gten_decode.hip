@@ -83,9 +83,11 @@ enum { PRO_EMBED = 0, PRO_RESID = 1, PRO_ATT = 2, PRO_ATTW = 3, PRO_ACTQ8 = 4 };
 // attention (k_dec_attn_one64) left chunk-local partials and statistics, the prologue joins them with their weights
 enum { EPI_RAW = 0, EPI_SILUMUL = 1, EPI_STAGE = 2, EPI_STAGE_FRAG = 3 };
 
+#define WXP_PLANES 8             // K planes of k_dec_wxp_f16 (gten_decode_wxp.h), added by the staging launches
 #include "gten_decode_wx.h"
 #include "gten_decode_wide_wx.h"
 #include "gten_decode_ffn.h"
+#include "gten_decode_wxp.h"
 #include "gten_decode_attn.h"
 #include "gten_decode_attn_exact64.h"
 #include "gten_decode_attn_wide.h"
@@ -185,7 +187,9 @@ static LaneBufs lane_bufs(const gten_hip_decoder* dc, int lane)
     LaneBufs b;
     b.n_seq = (int)SL;
     b.step = dc->step + o; b.tokens = dc->tokens + o * (d.max_ctx + 1); b.result = dc->result + o * (d.max_ctx + 2);
-    b.qkv_raw = dc->qkv_raw + o * planes * (E + 2 * KV); b.proj_raw = dc->proj_raw + o * planes * E; b.down_raw = dc->down_raw + o * planes * E;
+    b.qkv_raw = dc->qkv_raw + o * planes * (E + 2 * KV);
+    const size_t rplanes = dc->n_seq >= 16 ? (size_t)WXP_PLANES : 1;        // (k_dec_wxp_f16: eight K planes)
+    b.proj_raw = dc->proj_raw + o * rplanes * E; b.down_raw = dc->down_raw + o * rplanes * E;
     b.scores = dc->scores + o * H * d.max_ctx; b.stats = dc->stats + o * H * C * 2; b.att_part = dc->att_part + o * H * C * dh;
     b.xbuf = dc->xbuf + o * E * 4; b.hbuf = dc->hbuf + o * E * 4;
     b.act_f = dc->act_f + o * F; b.act_q = dc->act_q + o * 2 * F; b.act_d = dc->act_d + o * (F / 32); b.act_sum = dc->act_sum + o * (F / 32);
@@ -800,6 +804,45 @@ static int launch_mmvh_rt(int tag, const MmvhArgs& a)
         DEC_LAUNCH(tag, (k_dec_mmvh<WT, RT, 1, false>), grid, dim3(512), smem, a.ah, a.w[0], a.out, a.d_in, a.d_out[0], a.out_cols, a.S, a.n_mats, rest);
     return 0;
 }
+// o and down of every f16 decoder of 16+ sequences in eight K planes of 64-feature workgroups (gten_decode_wxp.h) -- or as k_dec_mmv_f16 in
+// two (0: A/B; the sums differ in the association of the f32 additions, so the switch is read when a step is enqueued or captured and
+// holds for every decoder alike)
+static bool g_wx_planes = true;
+extern "C" int gten_hip_set_wx_planes(int on)
+{
+    g_wx_planes = on != 0;
+    return 0;
+}
+static bool wxp_shape(int wt, int d_in, int d_out)
+{
+    const int nbk = d_in / 32 / WXP_PLANES;
+    return g_wx_planes && !g_exact_now && wt == GTEN_F16 && d_in % (32 * WXP_PLANES) == 0 && d_out % 64 == 0 &&
+           (nbk == 1 || nbk == 2 || nbk == 3 || nbk == 4 || nbk == 8 || nbk == 22);
+}
+static int launch_wxp_f16(int tag, const uint16_t* ah, const void* w, float* out, int d_in, int d_out, int S, int out_cols)
+{
+    const int rt_s = (S + 15) / 16, frt = rt_s <= 4 ? rt_s : 8, nbk = d_in / 32 / WXP_PLANES;
+    GTR_REQUIRE(rt_s <= 4 || S == 128, "decoder: a lane of %d rows (one to four row tiles, or 128 rows)", S);
+    const dim3 grid(d_out / 64, WXP_PLANES);
+    const size_t smem = (size_t)nbk * 4096;
+    static bool attr = false;
+    if (!attr) {
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_wxp_f16<22>, hipFuncAttributeMaxDynamicSharedMemorySize, 22 * 4096));
+        attr = true;
+    }
+#define WXP_GO(N_) DEC_LAUNCH(tag, k_dec_wxp_f16<N_>, grid, dim3(512), smem, ah, (const uint16_t*)w, out, d_in, d_out, S, out_cols, S * out_cols, frt)
+    switch (nbk) {
+    case 1: WXP_GO(1); break;
+    case 2: WXP_GO(2); break;
+    case 3: WXP_GO(3); break;
+    case 4: WXP_GO(4); break;
+    case 8: WXP_GO(8); break;
+    default: WXP_GO(22); break;
+    }
+#undef WXP_GO
+    return 0;
+}
+
 // gate | up with the silu * mul chain in the epilogue: one workgroup per 32-wide FFN slice, fragments for the down projection
 template <int WT>
 static int launch_mmvh_silu(int tag, const uint16_t* ah, const void* wgate, const void* wup, int n_ffn, int d_in, int S, uint16_t* out_frag)
@@ -996,6 +1039,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         return launch_mmv<WT>(tag, a);
     };
     auto ks_of = [&](int d_in) { return (ksplit > 1 && (d_in / 32) % (8 * ksplit) == 0) ? ksplit : 1; };
+    // f16: o and down as eight K planes of 64-feature workgroups (gten_decode_wxp.h)
+    const bool down_planes = wxp_shape(WT, F, E), o_planes = wxp_shape(WT, E, E);
     for (int l = 0; l < d.n_layers; l++) {
         const gten_hip_layer_ptrs& L = dc->layers[l];
         Gemv8Args st = base;
@@ -1005,7 +1050,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
             st.table = d.embed; st.rope = dc->rope; st.rope_now = b.rope_now; st.rope_half = dh / 2; st.n_vocab = V; st.tokens = b.tokens;
             rc = launch_stage_frag<WT, PRO_EMBED>(KT_DEC_STAGE, st, S);
         } else {
-            st.res_a = hbuf; st.res_raw = b.down_raw; st.raw_stride = E; st.raw_plane = ks_of(F) > 1 ? S * E : 0;
+            st.res_a = hbuf; st.res_raw = b.down_raw; st.raw_stride = E; st.raw_plane = (down_planes || ks_of(F) > 1) ? S * E : 0;
+            st.raw_nplanes = down_planes ? WXP_PLANES : 0;
             rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, st, S);
         }
         if (rc) return rc;
@@ -1037,10 +1083,13 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         rc = (grouped ? grouped_one_pass(t, S) : attention_one_pass(dh)) ? launch_stage_frag<WT, PRO_ATTW>(KT_DEC_STAGE, sa, S)
                                                                          : launch_stage_frag<WT, PRO_ATT>(KT_DEC_STAGE, sa, S);
         if (rc) return rc;
-        if ((rc = mmk(KT_DEC_GEMV_O, b.stg_q, b.stg_d, b.proj_raw, E, E, ks_of(E), L.wo, E))) return rc;
+        if (o_planes) {
+            if ((rc = launch_wxp_f16(KT_DEC_GEMV_O, (const uint16_t*)b.stg_q, L.wo, b.proj_raw, E, E, S, E))) return rc;
+        } else if ((rc = mmk(KT_DEC_GEMV_O, b.stg_q, b.stg_d, b.proj_raw, E, E, ks_of(E), L.wo, E))) return rc;
         Gemv8Args sh = base;
         sh.d_in = E; sh.res_a = xbuf; sh.res_raw = b.proj_raw; sh.raw_stride = E; sh.x_out = hbuf;
-        sh.raw_plane = ks_of(E) > 1 ? S * E : 0;
+        sh.raw_plane = (o_planes || ks_of(E) > 1) ? S * E : 0;
+        sh.raw_nplanes = o_planes ? WXP_PLANES : 0;
         sh.norm_w = (const uint16_t*)L.ffn_norm;
         sh.act_q = b.stg_q; sh.act_d = b.stg_d; sh.act_sum = b.stg_sum; sh.act_f = b.stg_f;
         if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sh, S))) return rc;
@@ -1071,11 +1120,14 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
             DEC_LAUNCH(KT_DEC_GEMV_GATEUP, k_dec_silumul_rows, dim3(F / 256, S), dim3(256), 0, (const float*)b.gu_raw, F, (S + 15) / 16,
                        ks_gu > 1 ? S * 2 * F : 0, b.act_q, b.act_d, b.act_sum, folded ? 1 : 0);
         }
-        if ((rc = mmk(KT_DEC_GEMV_DOWN, b.act_q, b.act_d, b.down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
+        if (down_planes) {
+            if ((rc = launch_wxp_f16(KT_DEC_GEMV_DOWN, (const uint16_t*)b.act_q, L.wdown, b.down_raw, F, E, S, E))) return rc;
+        } else if ((rc = mmk(KT_DEC_GEMV_DOWN, b.act_q, b.act_d, b.down_raw, E, F, ks_of(F), L.wdown, E))) return rc;
     }
     Gemv8Args sf = base;
     sf.d_in = E; sf.res_a = hbuf; sf.res_raw = b.down_raw; sf.raw_stride = E; sf.norm_w = (const uint16_t*)d.final_norm;
-    sf.raw_plane = ks_of(F) > 1 ? S * E : 0;
+    sf.raw_plane = (down_planes || ks_of(F) > 1) ? S * E : 0;
+    sf.raw_nplanes = down_planes ? WXP_PLANES : 0;
     sf.act_q = b.stg_q; sf.act_d = b.stg_d; sf.act_sum = b.stg_sum; sf.act_f = b.stg_f;
     if ((rc = launch_stage_frag<WT, PRO_RESID>(KT_DEC_STAGE, sf, S))) return rc;
     if ((rc = mm(KT_DEC_GEMV_HEAD, b.stg_q, b.stg_d, b.stg_sum, b.logits_m, V, E, d.lm_head, V))) return rc;
@@ -1265,8 +1317,8 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     GTR_CHECK(hipMemset(dc->result, 0, S * (size_t)(d.max_ctx + 2) * 4));
     const size_t planes = wide ? 2 : 1;                       // k_dec_mmv may split K over two workgroups: one output plane each
     GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, planes * S * (size_t)(E + 2 * KV) * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->proj_raw, planes * S * (size_t)E * 4));
-    GTR_CHECK(hipMalloc((void**)&dc->down_raw, planes * S * (size_t)E * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->proj_raw, (wide ? (size_t)WXP_PLANES : 1) * S * (size_t)E * 4));      // (k_dec_wxp_f16: eight K planes)
+    GTR_CHECK(hipMalloc((void**)&dc->down_raw, (wide ? (size_t)WXP_PLANES : 1) * S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->scores, S * (size_t)d.n_heads * d.max_ctx * 4));
     GTR_CHECK(hipMalloc((void**)&dc->stats, (S * (size_t)d.n_heads * dc->n_chunks * 2 + 16) * 4));   // + 8 chunks of slack: the one-launch kernel reads 8 per head
     GTR_CHECK(hipMemset(dc->stats, 0, (S * (size_t)d.n_heads * dc->n_chunks * 2 + 16) * 4));

@@ -49,6 +49,7 @@ struct Gemv8Args {
     // multi-sequence decode (EPI_STAGE / k_dec_gemvm): element strides between consecutive sequences
     int raw_stride;               // res_raw / out rows
     int raw_plane;                // staging launches: floats to the second K-split plane of res_raw (0: a single plane)
+    int raw_nplanes;              // ... WXP_PLANES when the producer was k_dec_wxp_f16 (raw_plane floats apart), else 0: one or two planes
     int tok_stride;               // token id rows
     int part_stride;              // att_part
     int best_stride;              // best_val / best_idx
@@ -303,6 +304,14 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
     // plane of partial sums is requested unconditionally (plane 0: the same row again) and added below
     float pin0b[(STG && PRO == PRO_RESID) ? EPT : 1];
     if constexpr (STG && PRO == PRO_RESID) ldN<EPT>(res_raw + a.raw_plane + sbase, pin0b);
+    // ... or eight (k_dec_wxp_f16, gten_decode_wxp.h): planes 2 .. 7 (uniform branch; a staging launch requests nothing behind it)
+    float pinx[(STG && PRO == PRO_RESID) ? WXP_PLANES - 2 : 1][EPT];
+    if constexpr (STG && PRO == PRO_RESID) {
+        if (a.raw_nplanes == WXP_PLANES) {
+#pragma unroll
+            for (int q = 2; q < WXP_PLANES; q++) ldN<EPT>(res_raw + (size_t)q * a.raw_plane + sbase, pinx[q - 2]);
+        }
+    }
     // (norm_w is required for PRO_EMBED / PRO_RESID: a null check here would be a branch whose join
     // makes hipcc wait for every outstanding load BEFORE the weight rows below are even requested)
     unsigned nw[4] = {0, 0, 0, 0};
@@ -425,6 +434,12 @@ __global__ __launch_bounds__(NT) void k_dec_gemv8(const unsigned long long h0, c
             if constexpr (STG && PRO == PRO_RESID) {
 #pragma unroll
                 for (int i = 0; i < EPT; i++) v[i] += a.raw_plane ? pin0b[i] : 0.f;
+                if (a.raw_nplanes == WXP_PLANES) {
+#pragma unroll
+                    for (int q = 2; q < WXP_PLANES; q++)
+#pragma unroll
+                        for (int i = 0; i < EPT; i++) v[i] += pinx[q - 2][i];
+                }
             }
             act_roundN<WT, EPT>(v);                       // Linear output written in the activation dtype
 #pragma unroll

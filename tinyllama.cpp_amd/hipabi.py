@@ -93,7 +93,7 @@ class GtenHip:
         "gten_hip_decoder_create_multi", "gten_hip_decoder_set_tokens_seq", "gten_hip_decoder_result_seq",
         "gten_hip_decoder_logits_seq",
         "gten_hip_decoder_lane_info", "gten_hip_set_lane_skip", "gten_hip_decoder_slot_start", "gten_hip_decoder_slot_start_until", "gten_hip_decoder_slot_park", "gten_hip_decoder_slot_bind", "gten_hip_decoder_slots_apply", "gten_hip_decoder_run", "gten_hip_decoder_run_lanes", "gten_hip_decoder_slot_ids", "gten_hip_decoder_slot_ids_all",
-        "gten_hip_set_kv_head_major", "gten_hip_decoder_kv_info", "gten_hip_kv_watch_selftest", "gten_hip_set_ffn_streamed",
+        "gten_hip_set_kv_head_major", "gten_hip_decoder_kv_info", "gten_hip_kv_watch_selftest", "gten_hip_set_ffn_streamed", "gten_hip_set_wx_planes",
     ]
 
     def __init__(self, path=None):
@@ -136,6 +136,7 @@ class GtenHip:
         self._kv_head_major = _sig(L, "gten_hip_set_kv_head_major", ci, [ci])
         self._kv_watch_selftest = _sig(L, "gten_hip_kv_watch_selftest", ci, [])
         self._ffn_streamed = _sig(L, "gten_hip_set_ffn_streamed", ci, [ci])
+        self._wx_planes = _sig(L, "gten_hip_set_wx_planes", ci, [ci])
         self._lane_skip = _sig(L, "gten_hip_set_lane_skip", ci, [ci])
         self._persist_status = _sig(L, "gten_hip_persist_status", ci, [C.POINTER(ci), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.c_void_p, ci])
         self._set_row_segments = _sig(L, "gten_hip_set_row_segments", ci, [C.c_void_p, ci])
@@ -196,6 +197,10 @@ class GtenHip:
     def set_ffn_streamed(self, on):
         """gate | up of full 128-row q4 lanes as the streamed kernel (default) or as k_dec_mmvh: the same bits"""
         self._check(self._ffn_streamed(1 if on else 0))
+
+    def set_wx_planes(self, on):
+        """f16 wide decoders: o and down in eight K planes of 64-feature workgroups (default) or as k_dec_mmv_f16 in two"""
+        self._check(self._wx_planes(1 if on else 0))
 
     def kv_watch_selftest(self):
         """host-only check of the watched-cache registry (no GPU needed): 0 = every case as expected, else the failing case"""
