@@ -187,8 +187,8 @@ static LaneBufs lane_bufs(const gten_hip_decoder* dc, int lane)
     LaneBufs b;
     b.n_seq = (int)SL;
     b.step = dc->step + o; b.tokens = dc->tokens + o * (d.max_ctx + 1); b.result = dc->result + o * (d.max_ctx + 2);
-    b.qkv_raw = dc->qkv_raw + o * planes * (E + 2 * KV);
     const size_t rplanes = dc->n_seq >= 16 ? (size_t)WXP_PLANES : 1;        // (k_dec_wxp_f16: eight K planes)
+    b.qkv_raw = dc->qkv_raw + o * rplanes * (E + 2 * KV);
     b.proj_raw = dc->proj_raw + o * rplanes * E; b.down_raw = dc->down_raw + o * rplanes * E;
     b.scores = dc->scores + o * H * d.max_ctx; b.stats = dc->stats + o * H * C * 2; b.att_part = dc->att_part + o * H * C * dh;
     b.xbuf = dc->xbuf + o * E * 4; b.hbuf = dc->hbuf + o * E * 4;
@@ -813,30 +813,37 @@ extern "C" int gten_hip_set_wx_planes(int on)
     g_wx_planes = on != 0;
     return 0;
 }
-static bool wxp_shape(int wt, int d_in, int d_out)
+static bool wxp_shape(int wt, int d_in, int d_out, int planes = WXP_PLANES)
 {
-    const int nbk = d_in / 32 / WXP_PLANES;
-    return g_wx_planes && !g_exact_now && wt == GTEN_F16 && d_in % (32 * WXP_PLANES) == 0 && d_out % 64 == 0 &&
-           (nbk == 1 || nbk == 2 || nbk == 3 || nbk == 4 || nbk == 8 || nbk == 22);
+    const int nbk = d_in / 32 / planes;
+    return g_wx_planes && !g_exact_now && wt == GTEN_F16 && d_in % (32 * planes) == 0 && d_out % 64 == 0 &&
+           (nbk == 1 || nbk == 2 || nbk == 3 || nbk == 4 || nbk == 6 || nbk == 8 || nbk == 16 || nbk == 22);
 }
-static int launch_wxp_f16(int tag, const uint16_t* ah, const void* w, float* out, int d_in, int d_out, int S, int out_cols)
+#define WXP_QKV_PLANES 4         // q | k | v: four planes (every attention workgroup of a (sequence, kv head) re-reads them)
+static int launch_wxp_f16(int tag, const uint16_t* ah, const void* w, float* out, int d_in, int d_out, int S, int out_cols,
+                          const void* w1 = nullptr, int d1 = 0, const void* w2 = nullptr, int d2 = 0, int planes = WXP_PLANES)
 {
-    const int rt_s = (S + 15) / 16, frt = rt_s <= 4 ? rt_s : 8, nbk = d_in / 32 / WXP_PLANES;
+    const int n_mats = w2 ? 3 : (w1 ? 2 : 1);
+    const MmvRest rest{w1, w2, d1, d2, 0};
+    const int rt_s = (S + 15) / 16, frt = rt_s <= 4 ? rt_s : 8, nbk = d_in / 32 / planes;
     GTR_REQUIRE(rt_s <= 4 || S == 128, "decoder: a lane of %d rows (one to four row tiles, or 128 rows)", S);
-    const dim3 grid(d_out / 64, WXP_PLANES);
+    const dim3 grid((d_out + d1 + d2) / 64, planes);
     const size_t smem = (size_t)nbk * 4096;
     static bool attr = false;
     if (!attr) {
         GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_wxp_f16<22>, hipFuncAttributeMaxDynamicSharedMemorySize, 22 * 4096));
+        GTR_CHECK(hipFuncSetAttribute((const void*)k_dec_wxp_f16<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096));
         attr = true;
     }
-#define WXP_GO(N_) DEC_LAUNCH(tag, k_dec_wxp_f16<N_>, grid, dim3(512), smem, ah, (const uint16_t*)w, out, d_in, d_out, S, out_cols, S * out_cols, frt)
+#define WXP_GO(N_) DEC_LAUNCH(tag, k_dec_wxp_f16<N_>, grid, dim3(512), smem, ah, (const uint16_t*)w, out, d_in, d_out, S, out_cols, S * out_cols, frt, n_mats, rest)
     switch (nbk) {
     case 1: WXP_GO(1); break;
     case 2: WXP_GO(2); break;
     case 3: WXP_GO(3); break;
     case 4: WXP_GO(4); break;
+    case 6: WXP_GO(6); break;
     case 8: WXP_GO(8); break;
+    case 16: WXP_GO(16); break;
     default: WXP_GO(22); break;
     }
 #undef WXP_GO
@@ -1058,7 +1065,12 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         const int QW = E + 2 * KV;
         // (measured: 160 x 2 workgroups of 4 row tiles run slower than 160; of 8 row tiles too: 11.8 against 9.0 us per launch)
         const int ks_qkv = S <= 32 ? ks_of(E) : 1;
-        if ((rc = mmk(KT_DEC_GEMV_QKV, b.stg_q, b.stg_d, b.qkv_raw, QW, E, ks_qkv, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
+        // f16 on head-major shadows: q | k | v in eight K planes too (k_dec_attn_hm_f16 adds them)
+        const bool qkv_planes = wxp_shape(WT, E, E, WXP_QKV_PLANES) && dc->hm && dh == 64 && KV % 64 == 0 && !g_exact_now &&
+                                (d.n_heads / d.n_kv_heads == 8 || d.n_heads / d.n_kv_heads == 4 || d.n_heads / d.n_kv_heads == 2 || d.n_heads / d.n_kv_heads == 1);
+        if (qkv_planes) {
+            if ((rc = launch_wxp_f16(KT_DEC_GEMV_QKV, (const uint16_t*)b.stg_q, L.wq, b.qkv_raw, E, E, S, QW, L.wk, KV, L.wv, KV, WXP_QKV_PLANES))) return rc;
+        } else if ((rc = mmk(KT_DEC_GEMV_QKV, b.stg_q, b.stg_d, b.qkv_raw, QW, E, ks_qkv, L.wq, E, L.wk, KV, L.wv, KV))) return rc;
         AttnArgs t{};
         t.step = b.step; t.qkv_raw = b.qkv_raw; t.kv_pitch = kv_pitch; t.scores = b.scores; t.stats = b.stats;
         t.att_part = b.att_part; t.rope = dc->rope; t.rope_now = b.rope_now;
@@ -1067,7 +1079,8 @@ static int enqueue_step_wide(gten_hip_decoder* dc, int lane)
         t.kv_tab = (const void* const*)b.kv_tab; t.layer = l; t.n_layers = d.n_layers;
         t.qkv_stride = QW; t.scores_stride = d.n_heads * d.max_ctx; t.stats_stride = d.n_heads * dc->n_chunks * 2;
         t.part_stride = d.n_heads * dc->n_chunks * dh;
-        t.qkv_plane = ks_qkv > 1 ? S * QW : 0;
+        t.qkv_plane = (qkv_planes || ks_qkv > 1) ? S * QW : 0;
+        t.qkv_nplanes = qkv_planes ? WXP_QKV_PLANES : 0;
         if (dc->hm) {
             t.hm_k = dc->hm + (size_t)lane * S * dc->hm_seq_stride + (size_t)l * 2 * dc->hm_cache_bytes;
             t.hm_seq_stride = dc->hm_seq_stride; t.hm_cache_bytes = dc->hm_cache_bytes;
@@ -1316,7 +1329,7 @@ static int decoder_build(gten_hip_decoder* dc, const gten_hip_decoder_desc& d, c
     GTR_CHECK(hipMalloc((void**)&dc->result, S * (size_t)(d.max_ctx + 2) * 4));
     GTR_CHECK(hipMemset(dc->result, 0, S * (size_t)(d.max_ctx + 2) * 4));
     const size_t planes = wide ? 2 : 1;                       // k_dec_mmv may split K over two workgroups: one output plane each
-    GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, planes * S * (size_t)(E + 2 * KV) * 4));
+    GTR_CHECK(hipMalloc((void**)&dc->qkv_raw, (wide ? (size_t)WXP_PLANES : 1) * S * (size_t)(E + 2 * KV) * 4));
     GTR_CHECK(hipMalloc((void**)&dc->proj_raw, (wide ? (size_t)WXP_PLANES : 1) * S * (size_t)E * 4));      // (k_dec_wxp_f16: eight K planes)
     GTR_CHECK(hipMalloc((void**)&dc->down_raw, (wide ? (size_t)WXP_PLANES : 1) * S * (size_t)E * 4));
     GTR_CHECK(hipMalloc((void**)&dc->scores, S * (size_t)d.n_heads * d.max_ctx * 4));

@@ -20,6 +20,7 @@ struct AttnArgs {
     const void* const* kv_tab; int layer, n_layers;
     int qkv_stride, scores_stride, stats_stride, part_stride;
     int qkv_plane;                // grouped kernels: floats to the second K-split plane of qkv_raw (0: a single plane)
+    int qkv_nplanes;              // k_dec_attn_hm_f16 only: 4 planes qkv_plane floats apart (k_dec_wxp_f16 at WXP_QKV_PLANES), else 0: one or two
     // head-major shadows of the caches (gten_decode_attn_hm.h; decoders of 16+ sequences): this layer's K shadow of the lane's
     // first sequence, bytes from one sequence's shadows to the next, bytes of one shadow (the V shadow follows the K shadow)
     uint8_t* hm_k; size_t hm_seq_stride, hm_cache_bytes;

@@ -504,6 +504,24 @@ __global__ __launch_bounds__(64 * HM_WAVES) void k_dec_attn_hm_f16(const AttnArg
         for (int jj = 0; jj < NJ; jj++) qraw[jj] += a.qkv_raw[a.qkv_plane + (g * GRP + min(w + NWV * jj, GRP - 1)) * dh + t];
         kraw += a.qkv_raw[a.qkv_plane + a.n_embd + g * dh + t];
         vraw += a.qkv_raw[a.qkv_plane + a.n_embd + kv_dim + g * dh + t];
+        if (a.qkv_nplanes == 4) {                                 // (uniform) four planes of k_dec_wxp_f16: 2 and 3 behind the first two, in order
+            float qx[2][NJ], kx[2], vx[2];
+#pragma unroll
+            for (int q = 2; q < 4; q++) {
+                const float* pl = a.qkv_raw + (size_t)q * a.qkv_plane;
+#pragma unroll
+                for (int jj = 0; jj < NJ; jj++) qx[q - 2][jj] = pl[(g * GRP + min(w + NWV * jj, GRP - 1)) * dh + t];
+                kx[q - 2] = pl[a.n_embd + g * dh + t];
+                vx[q - 2] = pl[a.n_embd + kv_dim + g * dh + t];
+            }
+#pragma unroll
+            for (int q = 2; q < 4; q++) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; jj++) qraw[jj] += qx[q - 2][jj];
+                kraw += kx[q - 2];
+                vraw += vx[q - 2];
+            }
+        }
     }
     const float2 rot = a.rope_now[t & 31];
     const uint8_t* kc = a.hm_k + (size_t)(g * a.n_chunks + (alive ? chunk : 0)) * HMF_CHUNK_BYTES;

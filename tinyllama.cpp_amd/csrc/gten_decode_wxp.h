@@ -17,10 +17,19 @@
 // 128 rows, 64-sequence and 16-sequence decoders agree bit for bit (tests/test_multiseq_gpu.py, tests/test_ffn_streamed_gpu.py).
 // (The q4 / q8 analogue was built and measured in this round and is not in the library: +1.8 % for 1.1 GB more planes per step,
 //  tools/experiments/gten_decode_wxp.h; for f16 the same change is 26.9 -> 9 us on the largest launch of the step.)
+// Up to three matrices concatenated along the output (q | k | v: every one a multiple of 64 wide, so a workgroup's 64 columns lie in one):
+// n_mats, rest.w1 / w2 / d_out1 / d_out2 as in k_dec_mmv_f16; the planes of q | k | v are added by the attention launch (k_dec_attn_hm_f16).
 template <int NBK>
-__global__ __launch_bounds__(512, 2) void k_dec_wxp_f16(const uint16_t* __restrict__ a_h, const uint16_t* __restrict__ w, float* __restrict__ out, const int d_in,
-                                                        const int d_out, const int S, const int out_cols, const int plane_floats, const int frt)
+__global__ __launch_bounds__(512, 2) void k_dec_wxp_f16(const uint16_t* __restrict__ a_h, const uint16_t* __restrict__ w0, float* __restrict__ out, const int d_in,
+                                                        const int d_out0, const int S, const int out_cols, const int plane_floats, const int frt,
+                                                        const int n_mats, const MmvRest rest)
 {
+    int colw = (int)blockIdx.x * 64, d_out = d_out0;
+    const uint16_t* w = w0;
+    if (n_mats > 1 && colw >= d_out0) {
+        colw -= d_out0; w = (const uint16_t*)rest.w1; d_out = rest.d_out1;
+        if (n_mats > 2 && colw >= rest.d_out1) { colw -= rest.d_out1; w = (const uint16_t*)rest.w2; d_out = rest.d_out2; }
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l16 = lane & 15, g = lane >> 4;
     const int kb0 = (int)blockIdx.y * NBK;                        // this plane's first step of 32 elements
     uint8_t* xb = g_smem;                                         // [NBK][4 tiles][4 k-groups][16 columns][16 B]
@@ -39,8 +48,13 @@ __global__ __launch_bounds__(512, 2) void k_dec_wxp_f16(const uint16_t* __restri
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
         const int p = min((int)threadIdx.x + 512 * j, NPC - 1), rr = p / (4 * NBK), wi = p - rr * (4 * NBK);
-        const size_t wrow = (size_t)min((int)blockIdx.x * 64 + rr, d_out - 1);
-        raw[j] = *(const uint4*)(w + wrow * d_in + (size_t)kb0 * 32 + wi * 8);
+        const size_t wrow = (size_t)min(colw + rr, d_out - 1);
+        // (w may come out of the argument struct: say that it is global memory, or the loads are FLAT ones -- which may alias LDS, so
+        //  every piece would have to land before the first ds_write: the pieces went through scratch)
+        typedef int wxp_v4i __attribute__((ext_vector_type(4)));
+        typedef const wxp_v4i __attribute__((address_space(1)))* gmem_w4;
+        const wxp_v4i v = *(gmem_w4)(uintptr_t)(w + wrow * d_in + (size_t)kb0 * 32 + wi * 8);
+        raw[j] = make_uint4((unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -74,11 +88,11 @@ __global__ __launch_bounds__(512, 2) void k_dec_wxp_f16(const uint16_t* __restri
     float* po = out + (size_t)blockIdx.y * plane_floats;
 #pragma unroll
     for (int f = 0; f < 4; f++) {
-        const int col = (int)blockIdx.x * 64 + 16 * f + l16;
+        const int cm = colw + 16 * f + l16, col = (int)blockIdx.x * 64 + 16 * f + l16;     // column inside its matrix / of the concatenated row
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 16 * wid + 4 * g + i;
-            if (r < S && col < d_out) po[(size_t)r * out_cols + col] = acc[f][i];
+            if (r < S && cm < d_out) po[(size_t)r * out_cols + col] = acc[f][i];
         }
     }
 }
