@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_g(const AttnArgs a0)
     int8_t* qi8 = (int8_t*)(d16 + 4 * (GRP + 2));                 // [GRP][64]
     int8_t* ki8 = qi8 + GRP * dh;                                 // 64
     int8_t* vi8 = ki8 + dh;                                       // 64
-    float* qfa = (float*)(((uintptr_t)(vi8 + dh) + 15) & ~(uintptr_t)15);   // f16 activations: [GRP][64] q values, then the new k row [64]
+    // (16-byte alignment by OFFSET arithmetic on g_smem: through an integer the pointer would come back as a generic one and every access
+    //  behind it would be a FLAT instruction)
+    float* qfa = (float*)(g_smem + (((size_t)((uint8_t*)(vi8 + dh) - g_smem) + 15) & ~(size_t)15));   // f16 activations: [GRP][64] q values, then the new k row [64]
     float* kfa = qfa + GRP * dh;
 
     // ---- requests, none of which needs the context length: the raw projections this wave turns into head vectors
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_score_gm_f16(const AttnArgs a0
     uint16_t* d16 = (uint16_t*)(mxs + 16);                        // scratch of head_prep (unused for f16)
     float* qd = (float*)(d16 + 64);                               // scratch
     int8_t* qi8 = (int8_t*)(qd + 32);                             // scratch [64]
-    uint16_t* qh = (uint16_t*)(((uintptr_t)(qi8 + 64) + 15) & ~(uintptr_t)15);   // [16][64] f16: the group's q vectors, zero rows beyond
+    uint16_t* qh = (uint16_t*)(g_smem + (((size_t)((uint8_t*)(qi8 + 64) - g_smem) + 15) & ~(size_t)15));   // [16][64] f16: the group's q vectors, zero rows beyond (offset arithmetic: see k_dec_attn_score_g)
     uint16_t* kh = qh + 16 * dh;                                  // [64] f16: the new k row
 
     // ---- requests, none of which needs the context length
@@ -521,7 +523,9 @@ __global__ __launch_bounds__(256) void k_dec_attn_one_g(const AttnArgs a0)
     int8_t* qi8 = (int8_t*)(d16 + 4 * (GRP + 2));                 // [GRP][64]
     int8_t* ki8 = qi8 + GRP * dh;                                 // 64
     int8_t* vi8 = ki8 + dh;                                       // 64
-    float* qfa = (float*)(((uintptr_t)(vi8 + dh) + 15) & ~(uintptr_t)15);   // f16 activations: [GRP][64] q values, then the new k row [64]
+    // (16-byte alignment by OFFSET arithmetic on g_smem: through an integer the pointer would come back as a generic one and every access
+    //  behind it would be a FLAT instruction)
+    float* qfa = (float*)(g_smem + (((size_t)((uint8_t*)(vi8 + dh) - g_smem) + 15) & ~(size_t)15));   // f16 activations: [GRP][64] q values, then the new k row [64]
     float* kfa = qfa + GRP * dh;
     float* p = (ADT == GTEN_Q8) ? qfa : kfa + dh;                 // [GP][4][64][2]: position c of heads 2 jj, 2 jj + 1 at [jj][c & 3][c >> 2][.]
     float* part = p;                                              // OVER p (see k_dec_attn_pv_g)
