@@ -50,6 +50,18 @@ def test_generated_code_has_no_packed_f32_instructions(tmp_path):
         mixed = MIXED.findall(text)
         assert not mixed, f"{os.path.basename(src)}: {len(mixed)} mixed-precision fused instructions ({sorted(set(mixed))})"
     assert n_kernels > 100          # every template instance of the library went through the check
+    # No FLAT memory instruction in the decode, prompt-GEMM and prompt-attention translation units (round 5): a pointer that went through an
+    # integer (an LDS pointer aligned via uintptr_t) or out of an argument struct comes back generic, hipcc then emits flat_load / flat_store,
+    # which may alias LDS: they count on both counters, order against every LDS access, and sent k_dec_wxp_f16's weight pieces through
+    # scratch.  (gten_ops.hip's self-test kernel takes a generic pointer on purpose.)
+    for src, text in zip(srcs, texts):
+        if os.path.basename(src) in ("gten_decode.hip", "gten_mfma.hip", "gten_attn_tiled.hip"):
+            flat = re.findall(r"^\s*(flat_(?:load|store|atomic)\w*)", text, re.M)
+            assert not flat, f"{os.path.basename(src)}: {len(flat)} flat memory instructions ({sorted(set(flat))})"
+    # ... and no kernel of the decode unit spills more than a handful of registers (k_dec_ffn_q8<false>: 4) or indexes a register array at run time
+    dec = texts[[os.path.basename(x) for x in srcs].index("gten_decode.hip")]
+    worst = max((int(m) for m in re.findall(r"; ScratchSize: (\d+)", dec)), default=0)
+    assert worst <= 32, f"gten_decode.hip: a kernel with {worst} bytes of scratch"
     # row16_max (gten_attn_tiled.hip) is a hand-written DPP chain: the hazard recogniser does not look inside inline assembly,
     # so whatever the compiler places behind it -- possibly a DPP or readlane consumer of the result -- gets no wait states of
     # its own.  The text therefore ends with `s_nop 1`; here: every last step of the chain is followed by exactly that.
