@@ -8,7 +8,7 @@ every attention chunk boundary, the last one the BASELINE.json metric point.  At
   * exact        the same with gten_hip_set_decode_exact(1) (two launches, whole-row statistics),
   * operators    the operator path, row by row (gten_hip_* operators, gten/modules.h without the fused rows),
   * wide-64      a 64-sequence decoder (matrix-core W.x and attention), slots 0 / 31 / 63,
-  * wide-128     one lane of 128 rows (q4 / q8), slots 0 / 31 / 127
+  * wide-128     one lane of 128 rows, slots 0 / 31 / 127
 are compared with the reference's AVX build on the fixture's ids (its top logits + the fixed probe ids), beside the
 reference's OWN spread on the same ids -- its AVX build against its scalar build -- which is the yardstick of the three
 long-context tests (bar: 1.35 x that spread, max <= 0.5; f16: max |dlogit| <= 0.03).  The product path only; the
@@ -113,7 +113,7 @@ def run():
 
         runs = {}
         for p in ALL_PATHS:
-            if p not in want_paths or (p == "wide-128" and name == "f16"):
+            if p not in want_paths:
                 continue
             t0 = time.time()
             runs[p] = walk_wide(int(p.split("-")[1])) if p.startswith("wide") else walk_single(p)
