@@ -85,6 +85,7 @@ def parse_args(argv=None):
     ap.add_argument("--serve-slice", type=int, default=8, help="shared steps per slice of the serving leg")
     ap.add_argument("--serve-spares", type=int, default=-1,
                     help="cache sets the serving leg fills ahead of the slots that will take them (-1: the library's default, a quarter of the slots, at most 64; 0: none)")
+    ap.add_argument("--serve-ramp", type=int, default=-1, help="serving: percent of the slots that hold a processed prompt before a queue's first slice (-1: the library's default, 100)")
     ap.add_argument("--ctx", type=int, default=N_CTX, help="context length the timed steps end at (metric: 2048)")
     ap.add_argument("--fill", choices=["decode", "prefill"], default="decode",
                     help="how the (untimed) context below the timed window is produced: single-token decode steps "
@@ -1085,6 +1086,8 @@ def worker(args, rank, local_rank, world, dist):
             batch.load_synthetic(args.seed)
             prompts, budgets = serving_queue(args.serve, lambda n, j: host.synthetic_tokens(n, seed=rep_seed(999, j)))
             batch.set_serve_spares(batch_spares)
+            if args.serve_ramp >= 0:
+                batch.set_serve_ramp(args.serve_ramp)
             batch.serve(prompts[:S], N_CTX, -1, args.serve_slice, max_new=4)           # warm-up: graphs, first-use allocations
             t0 = time.perf_counter()
             got, st = batch.serve(prompts, N_CTX, -1, args.serve_slice, max_new_each=budgets)
